@@ -1,0 +1,261 @@
+/*
+ * libctrhip — C ABI of the MI355X (gfx950) CTR hot path.
+ *
+ * The reference (LiuJun523/recommendation) has no FFI of its own: its hot path is the
+ * TensorFlow-1.x graph built in each model class's define_model() and executed by
+ * session.run() (e.g. DeepFM/DeepFM.py:34-100, :114-123).  Each entry point below
+ * replaces one cluster of graph ops; the cluster is cited at the declaration.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), allocates
+ *     nothing, never synchronises the host and never throws;
+ *   - scratch memory comes in through (workspace, workspace_bytes); the matching
+ *     *_workspace_bytes() query is a pure host function;
+ *   - return value: 0 = ok, <0 = bad argument (ctr_last_error() tells which),
+ *     >0 = a hipError_t;
+ *   - matrices are row-major fp32 with an explicit leading dimension (elements);
+ *   - indices are int32 (the reference narrows int64 feeds to int32, DeepFM/DeepFM.py:37);
+ *   - "keep threshold" = floor(keep_prob * 2^24); element i of dropout stream s is kept
+ *     iff hash24(seed, s, i) < threshold (ctr_keep_hash24 is the host copy of the hash).
+ */
+#ifndef CTRHIP_H
+#define CTRHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTR_OK 0
+#define CTR_EINVAL (-1)
+#define CTR_EWORKSPACE (-2)
+#define CTR_EUNSUPPORTED (-3)
+
+const char* ctr_last_error(void);
+int ctr_version(void);
+/* Host copy of the device dropout hash (24 random bits). */
+uint32_t ctr_keep_hash24(uint64_t seed, uint64_t stream_id, uint64_t index);
+
+/* Dropout descriptor: threshold == 0 or >= 2^24 with scale == 1 means "off". */
+typedef struct {
+  uint64_t seed;
+  uint64_t stream_id;
+  uint32_t keep_threshold; /* floor(keep_prob * 2^24) */
+  float scale;             /* 1 / keep_prob */
+} ctr_dropout_t;
+
+/* ------------------------------------------------------------------------------------
+ * Embedding + FM front end.
+ * Replaces: tf.one_hot + tf.nn.embedding_lookup + tf.multiply + tf.concat
+ * (DeepFM/DeepFM.py:43-53 and its copies), the standard lookup (Wide_Deep/Wide_Deep.py:51,
+ * DIN/DIN.py:26), the value-scaled continuous embedding (AFM/AFM.py:52-57, PNN/PNN.py:55-59),
+ * FM first/second order (DeepFM/DeepFM.py:55-63), bi-interaction (NFM/NFM.py:53-57),
+ * the sum over the embedding axis of ESMM (ESMM/ESMM.py:50) and the deep-input concat
+ * (DeepFM/DeepFM.py:66).
+ *
+ *   Z[b,f,:]   = tables[row_offset[f] + idx[b,f], :]   (zero row if idx outside [0, V_f))
+ *   Z[b,F+c,:] = cont_w[c,:] * x_cont[b,c]             (only when cont_w != NULL; N = F + C)
+ *   first[b,n] = sum_e Z[b,n,e]                         (then dropout drop_first)
+ *   s[b,e]     = sum_n Z[b,n,e]
+ *   second[b,e]= 0.5 * (s^2 - sum_n Z^2)                (then dropout drop_second)
+ * Outputs are optional (NULL = skip).  z_out row b starts at z_out + b*z_ld, holds N*E
+ * values and, when cont_tail != 0, x_cont[b,0..C) right behind them.
+ * E must be a power of two in [4, 256]; z_ld must be a multiple of 4.
+ * oor_count (optional) is incremented once per out-of-range id.
+ * ---------------------------------------------------------------------------------- */
+int ctr_embed_fwd(const float* tables, const int64_t* row_offset, const int32_t* idx,
+                  const float* x_cont, const float* cont_w,
+                  int B, int F, int C, int E,
+                  float* z_out, int64_t z_ld, int cont_tail,
+                  float* first_out, int64_t first_ld,
+                  float* s_out,
+                  float* second_out, int64_t second_ld,
+                  const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second,
+                  int32_t* oor_count, void* stream);
+
+/* FM reductions over an already materialised Z (leading dimension z_ld, N rows of E per
+ * sample): first / s / second exactly as in ctr_embed_fwd (DeepFM/DeepFM.py:55-63). */
+int ctr_fm_fwd(const float* z, int64_t z_ld, int B, int N, int E,
+               float* first_out, int64_t first_ld, float* s_out,
+               float* second_out, int64_t second_ld,
+               const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second, void* stream);
+
+/* Reference-exact ("R-mode") embedding block, DeepFM/DeepFM.py:43-53 as written:
+ *   Z[b, off_f + k, :] = tables[row_offset[f] + 1, :] if k == idx[b,f] else 0,  k in [0, V_f)
+ * z_out row b has sum(V)*E values (+ the x_cont tail when cont_tail != 0).
+ * pos_out (optional, [B,F] int32) receives off_f + idx[b,f], or -1 when out of range:
+ * the row of Z that sample b activates for field f. */
+int ctr_embed_onehot_fwd(const float* tables, const int64_t* row_offset, const int32_t* idx,
+                         const float* x_cont, int B, int F, int C, int E,
+                         float* z_out, int64_t z_ld, int cont_tail,
+                         int32_t* pos_out, void* stream);
+
+/* Backward of the front end with respect to Z (gradient of DeepFM/DeepFM.py:55-66):
+ *   dZ[b,n,e] = gz[b,n,e] + g_first[b,n]*keep_first + g_second[b,e]*keep_second*(s[b,e] - Z[b,n,e])
+ * Every g* term is optional.  z (the forward's Z, leading dimension z_ld) is needed only
+ * with g_second.  dz may alias gz (in-place).  N is the number of rows of Z per sample. */
+int ctr_embed_bwd_dz(const float* gz, int64_t gz_ld,
+                     const float* g_first, int64_t g_first_ld,
+                     const float* g_second, int64_t g_second_ld,
+                     const float* s, const float* z, int64_t z_ld,
+                     int B, int N, int E,
+                     const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second,
+                     float* dz, int64_t dz_ld, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Deterministic embedding backward: sort + segment-reduce + fused row update.
+ * Replaces: the IndexedSlices gradient of tf.nn.embedding_lookup, its
+ * unsorted_segment_sum de-duplication and the optimizer apply inside
+ * optimizer.minimize (DeepFM/DeepFM.py:100; AFM/AFM.py:29,97; DIN/DIN.py:110).
+ *
+ * ctr_emb_sort builds one (key, src) pair per (b,f):
+ *   S-mode (rmode == 0): key = row_offset[f] + idx[b,f],   src = b*N + f
+ *   R-mode (rmode != 0): key = row_offset[f] + 1,          src = b*N + row_offset[f] + idx[b,f]
+ * (out-of-range ids get key = total_rows and are ignored later), and sorts the pairs by
+ * key with a stable LSD radix sort.  keys_out / src_out: [B*F] uint32.
+ * ---------------------------------------------------------------------------------- */
+size_t ctr_emb_sort_workspace_bytes(int64_t n_items);
+int ctr_emb_sort(const int32_t* idx, const int64_t* row_offset, int B, int F, int N,
+                 int64_t total_rows, int rmode,
+                 uint32_t* keys_out, uint32_t* src_out,
+                 void* workspace, size_t workspace_bytes, void* stream);
+/* Plain stable radix sort of (key, value) uint32 pairs on keys < 2^key_bits. */
+int ctr_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, int64_t n, int key_bits,
+                   uint32_t* keys_out, uint32_t* vals_out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+#define CTR_OPT_GRAD_ONLY 0 /* grad_out[key,:] = summed gradient (dense-gradient path)  */
+#define CTR_OPT_ADAM 1      /* row-wise Adam on rows that received a gradient           */
+#define CTR_OPT_ADAGRAD 2   /* tf.train.AdagradOptimizer semantics (AFM/AFM.py:29)      */
+#define CTR_OPT_SGD 3       /* tf.train.GradientDescentOptimizer (DIN/DIN.py:110)       */
+
+typedef struct {
+  int kind;     /* CTR_OPT_*                                            */
+  float lr;     /* Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t), computed by the host */
+  float beta1;  /* Adam                                                 */
+  float beta2;  /* Adam                                                 */
+  float eps;    /* Adam (outside the sqrt, TF-1.x)                      */
+} ctr_opt_t;
+
+/* For every run of equal keys in the sorted pairs: g = sum (in sorted order, so bitwise
+ * reproducible) of scale_j * dz[b_j*dz_ld + n_j*E : +E] with src_j = b_j*N + n_j and
+ * scale_j = src_scale[src_j] (1 when src_scale == NULL), then apply `opt` to row `key`
+ * of tables (slot0/slot1 = Adam m/v, slot0 = Adagrad accumulator) or, for
+ * CTR_OPT_GRAD_ONLY, store g into slot0[key,:].  Keys >= total_rows are skipped. */
+int ctr_emb_sparse_apply(const uint32_t* keys_sorted, const uint32_t* src_sorted, int64_t n_items,
+                         int N, int E, int64_t total_rows,
+                         const float* dz, int64_t dz_ld, const float* src_scale,
+                         float* tables, float* slot0, float* slot1,
+                         const ctr_opt_t* opt, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Dense tower pieces.
+ * Replaces: tf.matmul + bias + relu + tf.layers.dropout chains and their gradients
+ * (DeepFM/DeepFM.py:65-88, DCN/DCN.py:67-89, NFM/NFM.py:59-81, PNN/PNN.py:98-117,
+ * ESMM/ESMM.py:52-92, DIN/DIN.py:47-58).
+ *
+ * C[M,N] = epilogue( op(A)[M,K] * op(B)[K,N] )   on the fp32 MFMA (exact fp32 FMA chain)
+ *   trans_a == 0: A is stored [M,K] (lda >= K);  != 0: stored [K,M] (lda >= M)
+ *   trans_b == 0: B is stored [K,N] (ldb >= N);  != 0: stored [N,K] (ldb >= K)
+ * epilogue, in this order: += bias[n] (optional); accumulate (C += result, when
+ * accumulate != 0); relu (when relu != 0); dropout (optional); mask: where
+ * mask_src[m*mask_ld+n] <= 0 the result is 0, elsewhere it is multiplied by mask_scale
+ * (optional; this is the relu+dropout backward given the layer's stored output).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* bias;
+  int relu;
+  int accumulate;
+  const ctr_dropout_t* dropout;
+  const float* mask_src;
+  int64_t mask_ld;
+  float mask_scale;
+} ctr_epilogue_t;
+
+size_t ctr_gemm_f32_workspace_bytes(int M, int N, int K);
+int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K,
+                 const float* A, int64_t lda, const float* B, int64_t ldb,
+                 float* C, int64_t ldc, const ctr_epilogue_t* epi,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[j] = sum_b X[b*ld + j] * (w ? w[b*w_ld + j / w_group] : 1),  j in [0, K).
+ * Two fixed-order passes (bitwise reproducible).  Serves bias gradients (w == NULL),
+ * output-unit weight gradients (w = dlogit, w_group = K) and the continuous-embedding
+ * gradient (w = x_cont, w_group = E). */
+size_t ctr_colsum_workspace_bytes(int B, int K);
+int ctr_colsum(const float* X, int64_t ld, const float* w, int64_t w_ld, int w_group,
+               int B, int K, float* out, int accumulate,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* logit[b] = sum_k X[b*ld + k] * w[k] + bias[0]   (output unit, DeepFM/DeepFM.py:83-88) */
+int ctr_rowdot_fwd(const float* X, int64_t ld, const float* w, const float* bias,
+                   int B, int K, float* out, void* stream);
+/* dX[b*ld + k] (+)= g[b] * w[k] */
+int ctr_rowdot_bwd_x(const float* g, const float* w, int B, int K,
+                     float* dX, int64_t ld, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Loss head: activation + loss + gradient with respect to the pre-activation.
+ * Replaces: tf.sigmoid + tf.losses.log_loss (DeepFM/DeepFM.py:88-91) and
+ * tf.nn.sigmoid_cross_entropy_with_logits (PNN/PNN.py:120, ESMM/ESMM.py:95-96, DIN/DIN.py:101).
+ *   CTR_LOSS_SIGMOID_LOGLOSS   y_out = sigmoid(x);  loss = log_loss(y, y_out)  (eps 1e-7)
+ *   CTR_LOSS_IDENTITY_LOGLOSS  y_out = x;           loss = log_loss(y, y_out)  (AFM/AFM.py:85-88)
+ *   CTR_LOSS_SIGMOID_SCE_PROB  y_out = sigmoid(x);  loss = sce(labels=y, logits=y_out)
+ *   CTR_LOSS_SCE_LOGIT         y_out = sigmoid(x);  loss = sce(labels=y, logits=x)
+ *   CTR_LOSS_PROB_SCE          y_out = x (already a probability); loss = sce(labels=y, logits=x)
+ * loss_out[0] = mean over B (fixed-order reduction); dx[b] = d loss / d x[b].
+ * y_out, dx, loss_out optional.
+ * ---------------------------------------------------------------------------------- */
+#define CTR_LOSS_SIGMOID_LOGLOSS 0
+#define CTR_LOSS_IDENTITY_LOGLOSS 1
+#define CTR_LOSS_SIGMOID_SCE_PROB 2
+#define CTR_LOSS_SCE_LOGIT 3
+#define CTR_LOSS_PROB_SCE 4
+int ctr_loss_head(int kind, const float* x, const float* y, int B,
+                  float* y_out, float* loss_out, float* dx, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Dense optimizers over one flat parameter buffer (multi-tensor in one launch).
+ * Replaces: tf.train.AdamOptimizer / AdagradOptimizer / GradientDescentOptimizer apply
+ * for dense variables (DeepFM/DeepFM.py:93-100).
+ * ---------------------------------------------------------------------------------- */
+int ctr_dense_update(float* param, const float* grad, float* slot0, float* slot1,
+                     int64_t n, const ctr_opt_t* opt, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * DCN cross network, all layers fused (DCN/DCN.py:56-65 without the [B,D,D] product):
+ *   x_{l+1} = x0 * (x_l . w_l) + b_l + x_l,   l = 0..L-1,   1 <= L <= 8,  D <= 8192
+ * w, b: [L, D] contiguous.  Every x_l lies in span{x0, prefix sums of b}, so the kernels
+ * carry only per-sample scalars: aux_out[b, 0..L) = x0 . w_l and aux_out[b, L..2L) = c_{l+1}
+ * with x_l = x0*c_l + sum_{l'<l} b_l'.  aux_out ([B, 2L]) is what the backward needs.
+ * Backward: given g = dLoss/dx_L, produces dx0 (+= when accumulate), dw[L,D], db[L,D].
+ * ---------------------------------------------------------------------------------- */
+size_t ctr_cross_fwd_workspace_bytes(int D, int L);
+int ctr_cross_fwd(const float* x0, int64_t x0_ld, const float* w, const float* b,
+                  int B, int D, int L, float* xL, int64_t xL_ld, float* aux_out,
+                  void* workspace, size_t workspace_bytes, void* stream);
+size_t ctr_cross_bwd_workspace_bytes(int B, int D, int L);
+int ctr_cross_bwd(const float* x0, int64_t x0_ld, const float* w, const float* b,
+                  const float* aux, const float* g, int64_t g_ld,
+                  int B, int D, int L,
+                  float* dx0, int64_t dx0_ld, int accumulate, float* dw, float* db,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* g[r,c] = act[r,c] > 0 ? g[r,c]*scale : 0 — gradient of relu followed by dropout through a
+ * layer whose stored output is `act` (DeepFM/DeepFM.py:71-72). */
+int ctr_relu_mask_apply(float* g, int64_t g_ld, const float* act, int64_t act_ld,
+                        int rows, int cols, float scale, void* stream);
+
+/* Small strided 2-D helpers (concat/slice plumbing of the graphs). */
+int ctr_copy2d(const float* src, int64_t src_ld, float* dst, int64_t dst_ld,
+               int rows, int cols, int accumulate, void* stream);
+int ctr_dropout_apply(float* x, int64_t ld, int rows, int cols, const ctr_dropout_t* drop,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTRHIP_H */

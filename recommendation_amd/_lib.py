@@ -1,0 +1,102 @@
+"""ctypes binding of libctrhip.so (the C ABI declared in include/ctrhip.h).
+
+The library is built in-tree by `__graft_entry__.build()` (or `make -C recommendation_amd/csrc`).
+There is no fallback: if the shared object is missing the import fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libctrhip.so')
+
+c_f32p = C.c_void_p   # device pointers travel as integers
+c_i32p = C.c_void_p
+c_i64p = C.c_void_p
+c_u32p = C.c_void_p
+vp = C.c_void_p
+
+
+class Dropout(C.Structure):
+    _fields_ = [('seed', C.c_uint64), ('stream_id', C.c_uint64),
+                ('keep_threshold', C.c_uint32), ('scale', C.c_float)]
+
+
+class Opt(C.Structure):
+    _fields_ = [('kind', C.c_int), ('lr', C.c_float), ('beta1', C.c_float),
+                ('beta2', C.c_float), ('eps', C.c_float)]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [('bias', C.c_void_p), ('relu', C.c_int), ('accumulate', C.c_int),
+                ('dropout', C.POINTER(Dropout)), ('mask_src', C.c_void_p),
+                ('mask_ld', C.c_int64), ('mask_scale', C.c_float)]
+
+
+OPT_GRAD_ONLY, OPT_ADAM, OPT_ADAGRAD, OPT_SGD = 0, 1, 2, 3
+LOSS_SIGMOID_LOGLOSS, LOSS_IDENTITY_LOGLOSS, LOSS_SIGMOID_SCE_PROB, LOSS_SCE_LOGIT, LOSS_PROB_SCE = 0, 1, 2, 3, 4
+
+i, i64, sz, f = C.c_int, C.c_int64, C.c_size_t, C.c_float
+DP = C.POINTER(Dropout)
+
+# name -> (restype, argtypes); mirrors include/ctrhip.h one to one
+SIGNATURES = {
+    'ctr_last_error': (C.c_char_p, []),
+    'ctr_version': (i, []),
+    'ctr_keep_hash24': (C.c_uint32, [C.c_uint64, C.c_uint64, C.c_uint64]),
+    'ctr_embed_fwd': (i, [vp, vp, vp, vp, vp, i, i, i, i, vp, i64, i, vp, i64, vp, vp, i64, DP, DP, vp, vp]),
+    'ctr_fm_fwd': (i, [vp, i64, i, i, i, vp, i64, vp, vp, i64, DP, DP, vp]),
+    'ctr_relu_mask_apply': (i, [vp, i64, vp, i64, i, i, f, vp]),
+    'ctr_embed_onehot_fwd': (i, [vp, vp, vp, vp, i, i, i, i, vp, i64, i, vp, vp]),
+    'ctr_embed_bwd_dz': (i, [vp, i64, vp, i64, vp, i64, vp, vp, i64, i, i, i, DP, DP, vp, i64, vp]),
+    'ctr_emb_sort_workspace_bytes': (sz, [i64]),
+    'ctr_emb_sort': (i, [vp, vp, i, i, i, i64, i, vp, vp, vp, sz, vp]),
+    'ctr_sort_pairs': (i, [vp, vp, i64, i, vp, vp, vp, sz, vp]),
+    'ctr_emb_sparse_apply': (i, [vp, vp, i64, i, i, i64, vp, i64, vp, vp, vp, vp, C.POINTER(Opt), vp]),
+    'ctr_gemm_f32_workspace_bytes': (sz, [i, i, i]),
+    'ctr_gemm_f32': (i, [i, i, i, i, i, vp, i64, vp, i64, vp, i64, C.POINTER(Epilogue), vp, sz, vp]),
+    'ctr_colsum_workspace_bytes': (sz, [i, i]),
+    'ctr_colsum': (i, [vp, i64, vp, i64, i, i, i, vp, i, vp, sz, vp]),
+    'ctr_rowdot_fwd': (i, [vp, i64, vp, vp, i, i, vp, vp]),
+    'ctr_rowdot_bwd_x': (i, [vp, vp, i, i, vp, i64, i, vp]),
+    'ctr_loss_head': (i, [i, vp, vp, i, vp, vp, vp, vp]),
+    'ctr_dense_update': (i, [vp, vp, vp, vp, i64, C.POINTER(Opt), vp]),
+    'ctr_cross_fwd_workspace_bytes': (sz, [i, i]),
+    'ctr_cross_fwd': (i, [vp, i64, vp, vp, i, i, i, vp, i64, vp, vp, sz, vp]),
+    'ctr_cross_bwd_workspace_bytes': (sz, [i, i, i]),
+    'ctr_cross_bwd': (i, [vp, i64, vp, vp, vp, vp, i64, i, i, i, vp, i64, i, vp, vp, vp, sz, vp]),
+    'ctr_copy2d': (i, [vp, i64, vp, i64, i, i, i, vp]),
+    'ctr_dropout_apply': (i, [vp, i64, i, i, DP, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libctrhip.so and attach the argument types; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'libctrhip.so is not built (%s missing). Build it with '
+            '`python -c "import __graft_entry__ as g; g.build()"` or `make -C recommendation_amd/csrc`. '
+            'There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class CtrError(RuntimeError):
+    pass
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().ctr_last_error().decode('utf-8', 'replace')
+        raise CtrError('%s failed with code %d: %s' % (what or 'libctrhip call', rc, msg))

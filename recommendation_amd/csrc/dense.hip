@@ -1,0 +1,263 @@
+// Small dense helpers around the towers: fixed-order column sums (bias / output-weight /
+// continuous-embedding gradients), the output unit (row dot), the loss heads and strided
+// copies.  All reductions run in a fixed order so results are bitwise reproducible.
+#include "common.h"
+
+namespace ctr {
+
+constexpr int CS_ROWS = 256;  // rows per partial chunk
+
+// grid (ceil(K/64), nchunks); block (64, 4)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int64_t ld,
+                                                            const float* __restrict__ w, int64_t w_ld,
+                                                            int w_group, int B, int K, int rows_per_chunk,
+                                                            float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + tx;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+  const int64_t r1 = r0 + rows_per_chunk < B ? r0 + rows_per_chunk : B;
+  float acc = 0.f;
+  if (j < K) {
+    const int wj = w ? j / w_group : 0;
+    for (int64_t r = r0 + ty; r < r1; r += 4) {
+      float v = X[r * ld + j];
+      if (w) v *= w[r * w_ld + wj];
+      acc += v;
+    }
+  }
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && j < K) part[(int64_t)blockIdx.y * K + j] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nchunks, int K,
+                                                          float* __restrict__ out, int accumulate) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  float acc = 0.f;
+  for (int c = 0; c < nchunks; ++c) acc += part[(int64_t)c * K + j];
+  out[j] = accumulate ? out[j] + acc : acc;
+}
+
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict__ X, int64_t ld,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias, int B, int K,
+                                                        float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc += X[b * ld + k] * w[k];
+  acc = wave_sum(acc);
+  if (lane == 0) out[b] = acc + (bias ? bias[0] : 0.f);
+}
+
+__global__ __launch_bounds__(256) void rowdot_bwd_x_kernel(const float* __restrict__ g,
+                                                          const float* __restrict__ w, int B, int K,
+                                                          float* __restrict__ dX, int64_t ld, int accumulate) {
+  const int64_t total = (int64_t)B * K;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+       p += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(p % K);
+    const int64_t b = p / K;
+    const float v = g[b] * w[k];
+    float* d = dX + b * ld + k;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+__device__ static inline float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ static inline float sce_(float x, float z) { return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x))); }
+
+// One 1024-thread block; fixed-order tree reduction of the per-thread partial sums.
+__global__ __launch_bounds__(1024) void loss_head_kernel(int kind, const float* __restrict__ x,
+                                                        const float* __restrict__ y, int B,
+                                                        float* __restrict__ y_out,
+                                                        float* __restrict__ loss_out,
+                                                        float* __restrict__ dx) {
+  __shared__ float red[1024];
+  const float invB = 1.f / (float)B;
+  const float eps = 1e-7f;
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += 1024) {
+    const float xv = x[b], yv = y[b];
+    float p, l, d;
+    if (kind == CTR_LOSS_SIGMOID_LOGLOSS || kind == CTR_LOSS_IDENTITY_LOGLOSS) {
+      p = kind == CTR_LOSS_SIGMOID_LOGLOSS ? sigmoidf_(xv) : xv;
+      l = -yv * logf(p + eps) - (1.f - yv) * logf(1.f - p + eps);
+      d = -yv / (p + eps) + (1.f - yv) / (1.f - p + eps);
+      if (kind == CTR_LOSS_SIGMOID_LOGLOSS) d *= p * (1.f - p);
+    } else if (kind == CTR_LOSS_SIGMOID_SCE_PROB) {
+      p = sigmoidf_(xv);
+      l = sce_(p, yv);
+      d = (sigmoidf_(p) - yv) * p * (1.f - p);
+    } else if (kind == CTR_LOSS_SCE_LOGIT) {
+      p = sigmoidf_(xv);
+      l = sce_(xv, yv);
+      d = p - yv;
+    } else {  // CTR_LOSS_PROB_SCE
+      p = xv;
+      l = sce_(xv, yv);
+      d = sigmoidf_(xv) - yv;
+    }
+    if (y_out) y_out[b] = p;
+    if (dx) dx[b] = d * invB;
+    acc += l;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && loss_out) loss_out[0] = red[0] * invB;
+}
+
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ src, int64_t src_ld,
+                                                    float* __restrict__ dst, int64_t dst_ld, int rows,
+                                                    int cols, int accumulate) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+       p += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(p % cols);
+    const int64_t r = p / cols;
+    const float v = src[r * src_ld + c];
+    float* d = dst + r * dst_ld + c;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+__global__ __launch_bounds__(256) void dropout_apply_kernel(float* __restrict__ x, int64_t ld, int rows,
+                                                           int cols, Drop d) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+       p += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(p % cols);
+    const int64_t r = p / cols;
+    x[r * ld + c] *= drop_mul(d, (uint64_t)p);
+  }
+}
+
+// g *= (act > 0 ? scale : 0): backward of relu followed by dropout, given the stored output
+__global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ g, int64_t g_ld,
+                                                       const float* __restrict__ act, int64_t act_ld, int rows,
+                                                       int cols, float scale) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+       p += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(p % cols);
+    const int64_t r = p / cols;
+    float* d = g + r * g_ld + c;
+    *d = act[r * act_ld + c] > 0.f ? *d * scale : 0.f;
+  }
+}
+
+static unsigned grid_for(int64_t total) {
+  const int64_t b = cdiv(total, 256);
+  return (unsigned)(b < 4096 ? (b > 0 ? b : 1) : 4096);
+}
+
+static int cs_chunks(int B) {
+  int64_t n = cdiv(B, CS_ROWS);
+  if (n < 1) n = 1;
+  if (n > 512) n = 512;
+  return (int)n;
+}
+
+}  // namespace ctr
+
+using namespace ctr;
+
+extern "C" size_t ctr_colsum_workspace_bytes(int B, int K) {
+  return (size_t)cs_chunks(B) * (size_t)(K > 0 ? K : 1) * sizeof(float);
+}
+
+extern "C" int ctr_colsum(const float* X, int64_t ld, const float* w, int64_t w_ld, int w_group, int B,
+                          int K, float* out, int accumulate, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  CTR_REQUIRE(B >= 0 && K >= 0, "ctr_colsum: bad size");
+  if (K == 0) return CTR_OK;
+  CTR_REQUIRE(X && out && workspace, "ctr_colsum: null pointer");
+  CTR_REQUIRE(!w || w_group > 0, "ctr_colsum: w_group must be positive");
+  if (workspace_bytes < ctr_colsum_workspace_bytes(B, K)) {
+    set_error("ctr_colsum: workspace %zu < %zu", workspace_bytes, ctr_colsum_workspace_bytes(B, K));
+    return CTR_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int nchunks = cs_chunks(B);
+  const int rows_per_chunk = (int)cdiv(B > 0 ? B : 1, nchunks);
+  float* part = (float*)workspace;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(K, 64), nchunks), dim3(256), 0, st, X, ld, w,
+                     w_ld, w_group, B, K, rows_per_chunk, part);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(K, 256)), dim3(256), 0, st, part, nchunks, K,
+                     out, accumulate);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_rowdot_fwd(const float* X, int64_t ld, const float* w, const float* bias, int B, int K,
+                              float* out, void* stream) {
+  CTR_REQUIRE(B >= 0 && K >= 0, "ctr_rowdot_fwd: bad size");
+  if (B == 0) return CTR_OK;
+  CTR_REQUIRE(X && w && out, "ctr_rowdot_fwd: null pointer");
+  hipLaunchKernelGGL(rowdot_fwd_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, X, ld,
+                     w, bias, B, K, out);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_rowdot_bwd_x(const float* g, const float* w, int B, int K, float* dX, int64_t ld,
+                                int accumulate, void* stream) {
+  CTR_REQUIRE(B >= 0 && K >= 0, "ctr_rowdot_bwd_x: bad size");
+  if ((int64_t)B * K == 0) return CTR_OK;
+  CTR_REQUIRE(g && w && dX, "ctr_rowdot_bwd_x: null pointer");
+  hipLaunchKernelGGL(rowdot_bwd_x_kernel, dim3(grid_for((int64_t)B * K)), dim3(256), 0, (hipStream_t)stream,
+                     g, w, B, K, dX, ld, accumulate);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_loss_head(int kind, const float* x, const float* y, int B, float* y_out, float* loss_out,
+                             float* dx, void* stream) {
+  CTR_REQUIRE(kind >= 0 && kind <= CTR_LOSS_PROB_SCE, "ctr_loss_head: unknown kind %d", kind);
+  CTR_REQUIRE(B > 0 && x && y, "ctr_loss_head: bad argument");
+  hipLaunchKernelGGL(loss_head_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, kind, x, y, B, y_out,
+                     loss_out, dx);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_copy2d(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int rows, int cols,
+                          int accumulate, void* stream) {
+  CTR_REQUIRE(rows >= 0 && cols >= 0, "ctr_copy2d: bad size");
+  if ((int64_t)rows * cols == 0) return CTR_OK;
+  CTR_REQUIRE(src && dst, "ctr_copy2d: null pointer");
+  hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((int64_t)rows * cols)), dim3(256), 0, (hipStream_t)stream,
+                     src, src_ld, dst, dst_ld, rows, cols, accumulate);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_dropout_apply(float* x, int64_t ld, int rows, int cols, const ctr_dropout_t* drop,
+                                 void* stream) {
+  CTR_REQUIRE(rows >= 0 && cols >= 0, "ctr_dropout_apply: bad size");
+  const Drop d = make_drop(drop);
+  if ((int64_t)rows * cols == 0 || !d.on) return CTR_OK;
+  CTR_REQUIRE(x, "ctr_dropout_apply: null pointer");
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid_for((int64_t)rows * cols)), dim3(256), 0,
+                     (hipStream_t)stream, x, ld, rows, cols, d);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_relu_mask_apply(float* g, int64_t g_ld, const float* act, int64_t act_ld, int rows, int cols,
+                                   float scale, void* stream) {
+  CTR_REQUIRE(rows >= 0 && cols >= 0, "ctr_relu_mask_apply: bad size");
+  if ((int64_t)rows * cols == 0) return CTR_OK;
+  CTR_REQUIRE(g && act, "ctr_relu_mask_apply: null pointer");
+  hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_for((int64_t)rows * cols)), dim3(256), 0, (hipStream_t)stream,
+                     g, g_ld, act, act_ld, rows, cols, scale);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}

@@ -1,0 +1,259 @@
+// Embedding + FM front end: gather, value-scaled continuous rows, first/second order,
+// deep-input concat, and the backward with respect to Z.  One wave per sample; a row of
+// E floats is covered by G = E/4 lanes (16 B per lane), so a wave moves R = 64/G rows
+// per step and every row read/write is one contiguous 4*E-byte segment.
+#include "common.h"
+
+namespace ctr {
+
+__device__ static inline float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// DENSE: Z already sits in z_out (N = F rows per sample); only the reductions are computed.
+template <int G, bool DENSE>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(
+    const float* __restrict__ tables, const int64_t* __restrict__ row_offset,
+    const int32_t* __restrict__ idx, const float* __restrict__ x_cont,
+    const float* __restrict__ cont_w, int B, int F, int C, int E,
+    float* __restrict__ z_out, int64_t z_ld, int cont_tail,
+    float* __restrict__ first_out, int64_t first_ld, float* __restrict__ s_out,
+    float* __restrict__ second_out, int64_t second_ld, Drop d_first, Drop d_second,
+    int32_t* __restrict__ oor_count) {
+  constexpr int R = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const int g = lane % G;
+  const int r = lane / G;
+  const int N = F + (cont_w ? C : 0);
+  float4 s = f4_zero(), q = f4_zero();
+  for (int n0 = 0; n0 < N; n0 += R) {
+    const int n = n0 + r;
+    const bool active = n < N;
+    float4 z = f4_zero();
+    if (active && DENSE) {
+      z = *reinterpret_cast<const float4*>(z_out + b * z_ld + (int64_t)n * E + g * 4);
+    } else if (active) {
+      if (n < F) {
+        const int x = idx[b * F + n];
+        const int64_t off = row_offset[n];
+        const int64_t V = row_offset[n + 1] - off;
+        if (x >= 0 && x < V) {
+          z = *reinterpret_cast<const float4*>(tables + (off + x) * E + g * 4);
+        } else if (oor_count && g == 0) {
+          atomicAdd(oor_count, 1);
+        }
+      } else {
+        const int c = n - F;
+        const float v = x_cont[b * C + c];
+        const float4 w = *reinterpret_cast<const float4*>(cont_w + (int64_t)c * E + g * 4);
+        z = make_float4(w.x * v, w.y * v, w.z * v, w.w * v);
+      }
+      if (!DENSE && z_out) *reinterpret_cast<float4*>(z_out + b * z_ld + (int64_t)n * E + g * 4) = z;
+    }
+    s.x += z.x; s.y += z.y; s.z += z.z; s.w += z.w;
+    q.x += z.x * z.x; q.y += z.y * z.y; q.z += z.z * z.z; q.w += z.w * z.w;
+    if (first_out) {
+      float t = (z.x + z.y) + (z.z + z.w);
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) t += __shfl_xor(t, o);
+      if (active && g == 0) first_out[b * first_ld + n] = t * drop_mul(d_first, (uint64_t)b * N + n);
+    }
+  }
+#pragma unroll
+  for (int o = G; o < 64; o <<= 1) {
+    s.x += __shfl_xor(s.x, o); s.y += __shfl_xor(s.y, o); s.z += __shfl_xor(s.z, o); s.w += __shfl_xor(s.w, o);
+    q.x += __shfl_xor(q.x, o); q.y += __shfl_xor(q.y, o); q.z += __shfl_xor(q.z, o); q.w += __shfl_xor(q.w, o);
+  }
+  if (r == 0) {
+    if (s_out) *reinterpret_cast<float4*>(s_out + b * E + g * 4) = s;
+    if (second_out) {
+      const uint64_t base = (uint64_t)b * E + g * 4;
+      float* o = second_out + b * second_ld + g * 4;
+      o[0] = 0.5f * (s.x * s.x - q.x) * drop_mul(d_second, base + 0);
+      o[1] = 0.5f * (s.y * s.y - q.y) * drop_mul(d_second, base + 1);
+      o[2] = 0.5f * (s.z * s.z - q.z) * drop_mul(d_second, base + 2);
+      o[3] = 0.5f * (s.w * s.w - q.w) * drop_mul(d_second, base + 3);
+    }
+  }
+  if (!DENSE && cont_tail && z_out) {
+    for (int c = lane; c < C; c += 64) z_out[b * z_ld + (int64_t)N * E + c] = x_cont[b * C + c];
+  }
+}
+
+// Reference-exact one-hot block: every (row n of Z, 16-byte slot) is a pure function of
+// (b, n): find the field that owns row n, compare with the sample's id, copy row 1 or zero.
+__global__ __launch_bounds__(256) void embed_onehot_fwd_kernel(
+    const float* __restrict__ tables, const int64_t* __restrict__ row_offset,
+    const int32_t* __restrict__ idx, const float* __restrict__ x_cont, int B, int F, int C, int E,
+    float* __restrict__ z_out, int64_t z_ld, int cont_tail, int32_t* __restrict__ pos_out) {
+  extern __shared__ int64_t offs[];  // [F+1] offsets, then [F] ids as int64
+  int64_t* ids = offs + (F + 1);
+  const int64_t b = blockIdx.x;
+  for (int f = threadIdx.x; f <= F; f += blockDim.x) offs[f] = row_offset[f];
+  for (int f = threadIdx.x; f < F; f += blockDim.x) ids[f] = idx[b * F + f];
+  __syncthreads();
+  const int G = E / 4;
+  const int64_t total = offs[F];
+  for (int64_t p = threadIdx.x; p < total * G; p += blockDim.x) {
+    const int64_t n = p / G;
+    const int g = (int)(p % G);
+    int lo = 0, hi = F;  // field f with offs[f] <= n < offs[f+1]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (offs[mid] <= n) lo = mid; else hi = mid;
+    }
+    float4 z = f4_zero();
+    if (n - offs[lo] == ids[lo]) z = *reinterpret_cast<const float4*>(tables + (offs[lo] + 1) * E + g * 4);
+    *reinterpret_cast<float4*>(z_out + b * z_ld + n * E + g * 4) = z;
+  }
+  if (cont_tail)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) z_out[b * z_ld + total * E + c] = x_cont[b * C + c];
+  if (pos_out)
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+      const int64_t V = offs[f + 1] - offs[f];
+      pos_out[b * F + f] = (ids[f] >= 0 && ids[f] < V) ? (int32_t)(offs[f] + ids[f]) : -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_dz_kernel(
+    const float* gz, int64_t gz_ld, const float* __restrict__ g_first, int64_t g_first_ld,
+    const float* __restrict__ g_second, int64_t g_second_ld, const float* __restrict__ s,
+    const float* __restrict__ z, int64_t z_ld, int B, int N, int E, Drop d_first, Drop d_second,
+    float* dz, int64_t dz_ld) {
+  const int G = E / 4;
+  const int64_t total = (int64_t)B * N * G;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+       p += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(p % G);
+    const int64_t bn = p / G;
+    const int n = (int)(bn % N);
+    const int64_t b = bn / N;
+    float4 a = f4_zero();
+    if (gz) a = *reinterpret_cast<const float4*>(gz + b * gz_ld + (int64_t)n * E + g * 4);
+    if (g_first) {
+      const float t = g_first[b * g_first_ld + n] * drop_mul(d_first, (uint64_t)b * N + n);
+      a.x += t; a.y += t; a.z += t; a.w += t;
+    }
+    if (g_second) {
+      const float4 zz = *reinterpret_cast<const float4*>(z + b * z_ld + (int64_t)n * E + g * 4);
+      const float4 ss = *reinterpret_cast<const float4*>(s + b * E + g * 4);
+      const float* g2 = g_second + b * g_second_ld + g * 4;
+      const uint64_t base = (uint64_t)b * E + g * 4;
+      a.x += g2[0] * drop_mul(d_second, base + 0) * (ss.x - zz.x);
+      a.y += g2[1] * drop_mul(d_second, base + 1) * (ss.y - zz.y);
+      a.z += g2[2] * drop_mul(d_second, base + 2) * (ss.z - zz.z);
+      a.w += g2[3] * drop_mul(d_second, base + 3) * (ss.w - zz.w);
+    }
+    *reinterpret_cast<float4*>(dz + b * dz_ld + (int64_t)n * E + g * 4) = a;
+  }
+}
+
+static bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+}  // namespace ctr
+
+using namespace ctr;
+
+extern "C" int ctr_embed_fwd(const float* tables, const int64_t* row_offset, const int32_t* idx,
+                             const float* x_cont, const float* cont_w, int B, int F, int C, int E,
+                             float* z_out, int64_t z_ld, int cont_tail, float* first_out,
+                             int64_t first_ld, float* s_out, float* second_out, int64_t second_ld,
+                             const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second,
+                             int32_t* oor_count, void* stream) {
+  CTR_REQUIRE(B >= 0 && F >= 0 && C >= 0, "ctr_embed_fwd: negative size");
+  CTR_REQUIRE(pow2(E) && E >= 4 && E <= 256, "ctr_embed_fwd: E=%d must be a power of two in [4,256]", E);
+  CTR_REQUIRE(F == 0 || (tables && row_offset && idx), "ctr_embed_fwd: null table/index pointer");
+  CTR_REQUIRE(!z_out || (z_ld % 4 == 0 && ((uintptr_t)z_out % 16) == 0),
+              "ctr_embed_fwd: z_out must be 16-byte aligned with z_ld %% 4 == 0");
+  CTR_REQUIRE(!(cont_w || cont_tail) || x_cont || C == 0, "ctr_embed_fwd: x_cont missing");
+  const int N = F + (cont_w ? C : 0);
+  CTR_REQUIRE(!z_out || z_ld >= (int64_t)N * E + (cont_tail ? C : 0), "ctr_embed_fwd: z_ld too small");
+  if (B == 0) return CTR_OK;
+  const Drop d1 = make_drop(drop_first), d2 = make_drop(drop_second);
+  const dim3 grid((unsigned)cdiv(B, 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(GG)                                                                                  \
+  hipLaunchKernelGGL((embed_fwd_kernel<GG, false>), grid, block, 0, st, tables, row_offset, idx, x_cont, \
+                     cont_w, B, F, C, E, z_out, z_ld, cont_tail, first_out, first_ld, s_out,       \
+                     second_out, second_ld, d1, d2, oor_count)
+  switch (E / 4) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 4: LAUNCH(4); break;
+    case 8: LAUNCH(8); break;
+    case 16: LAUNCH(16); break;
+    case 32: LAUNCH(32); break;
+    case 64: LAUNCH(64); break;
+  }
+#undef LAUNCH
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_fm_fwd(const float* z, int64_t z_ld, int B, int N, int E, float* first_out,
+                         int64_t first_ld, float* s_out, float* second_out, int64_t second_ld,
+                         const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second, void* stream) {
+  CTR_REQUIRE(B >= 0 && N >= 0, "ctr_fm_fwd: negative size");
+  CTR_REQUIRE(pow2(E) && E >= 4 && E <= 256, "ctr_fm_fwd: E=%d must be a power of two in [4,256]", E);
+  CTR_REQUIRE(z && z_ld % 4 == 0 && ((uintptr_t)z % 16) == 0 && z_ld >= (int64_t)N * E, "ctr_fm_fwd: z alignment/size");
+  if (B == 0) return CTR_OK;
+  const Drop d1 = make_drop(drop_first), d2 = make_drop(drop_second);
+  const dim3 grid((unsigned)cdiv(B, 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  float* zz = const_cast<float*>(z);  // the DENSE instantiation only reads it
+#define LAUNCH(GG)                                                                                  \
+  hipLaunchKernelGGL((embed_fwd_kernel<GG, true>), grid, block, 0, st, (const float*)nullptr,      \
+                     (const int64_t*)nullptr, (const int32_t*)nullptr, (const float*)nullptr,      \
+                     (const float*)nullptr, B, N, 0, E, zz, z_ld, 0, first_out, first_ld, s_out,   \
+                     second_out, second_ld, d1, d2, (int32_t*)nullptr)
+  switch (E / 4) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 4: LAUNCH(4); break;
+    case 8: LAUNCH(8); break;
+    case 16: LAUNCH(16); break;
+    case 32: LAUNCH(32); break;
+    case 64: LAUNCH(64); break;
+  }
+#undef LAUNCH
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_embed_onehot_fwd(const float* tables, const int64_t* row_offset,
+                                    const int32_t* idx, const float* x_cont, int B, int F, int C,
+                                    int E, float* z_out, int64_t z_ld, int cont_tail,
+                                    int32_t* pos_out, void* stream) {
+  CTR_REQUIRE(B >= 0 && F > 0 && C >= 0, "ctr_embed_onehot_fwd: bad size");
+  CTR_REQUIRE(E >= 4 && E % 4 == 0, "ctr_embed_onehot_fwd: E=%d must be a multiple of 4", E);
+  CTR_REQUIRE(tables && row_offset && idx && z_out, "ctr_embed_onehot_fwd: null pointer");
+  CTR_REQUIRE(z_ld % 4 == 0 && ((uintptr_t)z_out % 16) == 0, "ctr_embed_onehot_fwd: z_out alignment");
+  CTR_REQUIRE(F <= 4096, "ctr_embed_onehot_fwd: F too large");
+  if (B == 0) return CTR_OK;
+  const size_t shmem = (size_t)(2 * F + 1) * sizeof(int64_t);
+  hipLaunchKernelGGL(embed_onehot_fwd_kernel, dim3(B), dim3(256), shmem, (hipStream_t)stream, tables,
+                     row_offset, idx, x_cont, B, F, C, E, z_out, z_ld, cont_tail, pos_out);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_embed_bwd_dz(const float* gz, int64_t gz_ld, const float* g_first,
+                                int64_t g_first_ld, const float* g_second, int64_t g_second_ld,
+                                const float* s, const float* z, int64_t z_ld, int B, int N, int E,
+                                const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second,
+                                float* dz, int64_t dz_ld, void* stream) {
+  CTR_REQUIRE(B >= 0 && N >= 0 && E >= 4 && E % 4 == 0, "ctr_embed_bwd_dz: bad size");
+  CTR_REQUIRE(dz && dz_ld % 4 == 0 && ((uintptr_t)dz % 16) == 0, "ctr_embed_bwd_dz: dz alignment");
+  CTR_REQUIRE(!gz || (gz_ld % 4 == 0 && ((uintptr_t)gz % 16) == 0), "ctr_embed_bwd_dz: gz alignment");
+  CTR_REQUIRE(!g_second || (s && z && z_ld % 4 == 0 && ((uintptr_t)z % 16) == 0 && ((uintptr_t)s % 16) == 0),
+              "ctr_embed_bwd_dz: g_second needs s and z (16-byte aligned)");
+  const int64_t total = (int64_t)B * N * (E / 4);
+  if (total == 0) return CTR_OK;
+  const int64_t blocks = cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096;
+  hipLaunchKernelGGL(embed_bwd_dz_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gz,
+                     gz_ld, g_first, g_first_ld, g_second, g_second_ld, s, z, z_ld, B, N, E,
+                     make_drop(drop_first), make_drop(drop_second), dz, dz_ld);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}

@@ -1,0 +1,243 @@
+// Stable LSD radix sort of (uint32 key, uint32 value) pairs, 8 bits per pass, and the
+// (key, src) pair builder of the embedding backward.  Each pass is three launches:
+// per-tile digit histogram -> exclusive scan of the [digit][tile] counts -> stable scatter.
+// Stability inside a tile comes from wave-level peer masks (ballots over the 8 digit bits)
+// plus per-wave running digit counters in LDS, so the result is bitwise reproducible.
+#include "common.h"
+
+namespace ctr {
+
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_WAVES = SORT_THREADS / 64;
+constexpr int SORT_CHUNKS = 16;                      // 64-key chunks per wave
+constexpr int SORT_TILE = SORT_THREADS * SORT_CHUNKS;  // 4096 keys per block
+
+__global__ __launch_bounds__(256) void build_pairs_kernel(
+    const int32_t* __restrict__ idx, const int64_t* __restrict__ row_offset, int B, int F, int N,
+    int64_t total_rows, int rmode, uint32_t* __restrict__ keys, uint32_t* __restrict__ src) {
+  const int64_t n = (int64_t)B * F;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % F);
+    const int64_t b = i / F;
+    const int x = idx[i];
+    const int64_t off = row_offset[f];
+    const int64_t V = row_offset[f + 1] - off;
+    const bool ok = x >= 0 && x < V;
+    uint32_t k, s;
+    if (rmode) {
+      k = ok ? (uint32_t)(off + 1) : (uint32_t)total_rows;
+      s = ok ? (uint32_t)(b * N + off + x) : 0u;
+    } else {
+      k = ok ? (uint32_t)(off + x) : (uint32_t)total_rows;
+      s = (uint32_t)(b * N + f);
+    }
+    keys[i] = k;
+    src[i] = s;
+  }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(
+    const uint32_t* __restrict__ keys, int64_t n, int shift, int nblocks, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+  for (int i = threadIdx.x; i < SORT_TILE; i += SORT_THREADS) {
+    const int64_t p = base + i;
+    if (p < n) atomicAdd(&hist[(keys[p] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  counts[(int64_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
+}
+
+// Exclusive scan of `len` uint32 counters by one 1024-thread block.
+__global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t* __restrict__ counts, int64_t len) {
+  __shared__ uint32_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (len + 1023) / 1024;
+  const int64_t lo = (int64_t)t * per;
+  const int64_t hi = lo + per < len ? lo + per : len;
+  uint32_t sum = 0;
+  for (int64_t i = lo; i < hi; ++i) sum += counts[i];
+  part[t] = sum;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over the 1024 partials
+  for (int o = 1; o < 1024; o <<= 1) {
+    uint32_t v = t >= o ? part[t - o] : 0u;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[t] - sum;  // exclusive prefix of this thread's range
+  for (int64_t i = lo; i < hi; ++i) {
+    const uint32_t c = counts[i];
+    counts[i] = run;
+    run += c;
+  }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t n, int shift,
+    int nblocks, const uint32_t* __restrict__ scanned, uint32_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out) {
+  __shared__ uint32_t whist[SORT_WAVES][256];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < SORT_WAVES * 256; i += SORT_THREADS) (&whist[0][0])[i] = 0;
+  __syncthreads();
+  const int64_t wbase = (int64_t)blockIdx.x * SORT_TILE + (int64_t)wave * SORT_CHUNKS * 64;
+  uint32_t key[SORT_CHUNKS], val[SORT_CHUNKS], rank[SORT_CHUNKS];
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int c = 0; c < SORT_CHUNKS; ++c) {
+    const int64_t p = wbase + c * 64 + lane;
+    const bool valid = p < n;
+    key[c] = valid ? keys_in[p] : 0u;
+    val[c] = valid ? vals_in[p] : 0u;
+  }
+#pragma unroll
+  for (int c = 0; c < SORT_CHUNKS; ++c) {
+    const int64_t p = wbase + c * 64 + lane;
+    const bool valid = p < n;
+    const uint32_t d = (key[c] >> shift) & 255u;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool set = (d >> bit) & 1u;
+      const unsigned long long m = __ballot(valid && set);
+      peers &= set ? m : ~m;
+    }
+    uint32_t prior = 0;
+    if (valid) prior = whist[wave][d];
+    const uint32_t in_chunk = (uint32_t)__popcll(peers & lt_mask);
+    rank[c] = prior + in_chunk;
+    // the lowest peer lane publishes the chunk's count for this digit
+    if (valid && in_chunk == 0) whist[wave][d] = prior + (uint32_t)__popcll(peers);
+  }
+  __syncthreads();
+  {  // per digit: exclusive prefix over the waves + this tile's global base
+    const int d = threadIdx.x;
+    uint32_t run = scanned[(int64_t)d * nblocks + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) {
+      const uint32_t c = whist[w][d];
+      whist[w][d] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < SORT_CHUNKS; ++c) {
+    const int64_t p = wbase + c * 64 + lane;
+    if (p < n) {
+      const uint32_t d = (key[c] >> shift) & 255u;
+      const uint32_t dst = whist[wave][d] + rank[c];
+      keys_out[dst] = key[c];
+      vals_out[dst] = val[c];
+    }
+  }
+}
+
+static int bits_for(uint64_t max_value) {
+  int b = 1;
+  while (b < 32 && (max_value >> b) != 0) ++b;
+  return b;
+}
+
+struct SortWs {
+  uint32_t *keys_tmp, *vals_tmp, *counts;
+  int nblocks;
+};
+
+static size_t sort_ws_bytes(int64_t n) {
+  const int64_t nblocks = cdiv(n > 0 ? n : 1, SORT_TILE);
+  return align_up((size_t)n * 4, 256) * 2 + align_up((size_t)nblocks * 256 * 4, 256);
+}
+
+static SortWs carve(void* ws, int64_t n) {
+  SortWs w;
+  char* p = (char*)ws;
+  w.nblocks = (int)cdiv(n > 0 ? n : 1, SORT_TILE);
+  w.keys_tmp = (uint32_t*)p; p += align_up((size_t)n * 4, 256);
+  w.vals_tmp = (uint32_t*)p; p += align_up((size_t)n * 4, 256);
+  w.counts = (uint32_t*)p;
+  return w;
+}
+
+// Sorts the pairs currently in (ka, va); the result lands in (keys_out, vals_out).
+// (ka, va) must be (keys_out, vals_out) when the pass count is even, else the tmp pair.
+static int run_passes(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, int64_t n, int passes,
+                      const SortWs& w, hipStream_t st) {
+  for (int p = 0; p < passes; ++p) {
+    const int shift = 8 * p;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, n, shift,
+                       w.nblocks, w.counts);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, (int64_t)w.nblocks * 256);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, va, n,
+                       shift, w.nblocks, w.counts, kb, vb);
+    uint32_t* t;
+    t = ka; ka = kb; kb = t;
+    t = va; va = vb; vb = t;
+  }
+  return 0;
+}
+
+}  // namespace ctr
+
+using namespace ctr;
+
+extern "C" size_t ctr_emb_sort_workspace_bytes(int64_t n_items) { return sort_ws_bytes(n_items); }
+
+extern "C" int ctr_emb_sort(const int32_t* idx, const int64_t* row_offset, int B, int F, int N,
+                            int64_t total_rows, int rmode, uint32_t* keys_out, uint32_t* src_out,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  const int64_t n = (int64_t)B * F;
+  CTR_REQUIRE(B >= 0 && F >= 0 && N > 0, "ctr_emb_sort: bad size");
+  CTR_REQUIRE(total_rows > 0 && total_rows < 0xFFFFFFFFll, "ctr_emb_sort: total_rows must fit 32 bits");
+  CTR_REQUIRE((int64_t)B * N < 0xFFFFFFFFll, "ctr_emb_sort: B*N must fit 32 bits");
+  if (n == 0) return CTR_OK;
+  CTR_REQUIRE(idx && row_offset && keys_out && src_out && workspace, "ctr_emb_sort: null pointer");
+  if (workspace_bytes < sort_ws_bytes(n)) {
+    set_error("ctr_emb_sort: workspace %zu < %zu", workspace_bytes, sort_ws_bytes(n));
+    return CTR_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const SortWs w = carve(workspace, n);
+  const int passes = (bits_for((uint64_t)total_rows) + 7) / 8;
+  uint32_t* ka = (passes % 2 == 0) ? keys_out : w.keys_tmp;
+  uint32_t* va = (passes % 2 == 0) ? src_out : w.vals_tmp;
+  uint32_t* kb = (passes % 2 == 0) ? w.keys_tmp : keys_out;
+  uint32_t* vb = (passes % 2 == 0) ? w.vals_tmp : src_out;
+  const int64_t blocks = cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048;
+  hipLaunchKernelGGL(build_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, idx, row_offset, B, F,
+                     N, total_rows, rmode, ka, va);
+  run_passes(ka, va, kb, vb, n, passes, w, st);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, int64_t n, int key_bits,
+                              uint32_t* keys_out, uint32_t* vals_out, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  CTR_REQUIRE(n >= 0 && key_bits >= 1 && key_bits <= 32, "ctr_sort_pairs: bad size");
+  if (n == 0) return CTR_OK;
+  CTR_REQUIRE(keys_in && vals_in && keys_out && vals_out && workspace, "ctr_sort_pairs: null pointer");
+  if (workspace_bytes < sort_ws_bytes(n)) {
+    set_error("ctr_sort_pairs: workspace %zu < %zu", workspace_bytes, sort_ws_bytes(n));
+    return CTR_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const SortWs w = carve(workspace, n);
+  const int passes = (key_bits + 7) / 8;
+  uint32_t* ka = (passes % 2 == 0) ? keys_out : w.keys_tmp;
+  uint32_t* va = (passes % 2 == 0) ? vals_out : w.vals_tmp;
+  uint32_t* kb = (passes % 2 == 0) ? w.keys_tmp : keys_out;
+  uint32_t* vb = (passes % 2 == 0) ? w.vals_tmp : vals_out;
+  hipError_t e = hipMemcpyAsync(ka, keys_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(va, vals_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) { set_error("ctr_sort_pairs: copy failed: %s", hipGetErrorString(e)); return (int)e; }
+  run_passes(ka, va, kb, vb, n, passes, w, st);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}

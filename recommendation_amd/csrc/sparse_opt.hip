@@ -1,0 +1,152 @@
+// Segment-reduce over sorted (key, src) pairs + fused row-wise optimizer, and the dense
+// (flat-buffer) optimizers.  A row of E floats is owned by G = E/4 lanes; the group that
+// sits on the first pair of a run of equal keys walks the run in sorted order (fixed
+// summation order => bitwise reproducible), then updates that table row once.
+#include "common.h"
+
+namespace ctr {
+
+struct Opt {
+  int kind;
+  float lr, b1, b2, eps;
+};
+
+__device__ static inline void opt_apply4(const Opt& o, float4 g, float4* w, float4* s0, float4* s1) {
+  if (o.kind == CTR_OPT_ADAM) {
+    float4 m = *s0, v = *s1, p = *w;
+    m.x = o.b1 * m.x + (1.f - o.b1) * g.x; m.y = o.b1 * m.y + (1.f - o.b1) * g.y;
+    m.z = o.b1 * m.z + (1.f - o.b1) * g.z; m.w = o.b1 * m.w + (1.f - o.b1) * g.w;
+    v.x = o.b2 * v.x + (1.f - o.b2) * g.x * g.x; v.y = o.b2 * v.y + (1.f - o.b2) * g.y * g.y;
+    v.z = o.b2 * v.z + (1.f - o.b2) * g.z * g.z; v.w = o.b2 * v.w + (1.f - o.b2) * g.w * g.w;
+    p.x -= o.lr * m.x / (sqrtf(v.x) + o.eps); p.y -= o.lr * m.y / (sqrtf(v.y) + o.eps);
+    p.z -= o.lr * m.z / (sqrtf(v.z) + o.eps); p.w -= o.lr * m.w / (sqrtf(v.w) + o.eps);
+    *s0 = m; *s1 = v; *w = p;
+  } else if (o.kind == CTR_OPT_ADAGRAD) {
+    float4 a = *s0, p = *w;
+    a.x += g.x * g.x; a.y += g.y * g.y; a.z += g.z * g.z; a.w += g.w * g.w;
+    p.x -= o.lr * g.x / sqrtf(a.x); p.y -= o.lr * g.y / sqrtf(a.y);
+    p.z -= o.lr * g.z / sqrtf(a.z); p.w -= o.lr * g.w / sqrtf(a.w);
+    *s0 = a; *w = p;
+  } else if (o.kind == CTR_OPT_SGD) {
+    float4 p = *w;
+    p.x -= o.lr * g.x; p.y -= o.lr * g.y; p.z -= o.lr * g.z; p.w -= o.lr * g.w;
+    *w = p;
+  } else {
+    *s0 = g;
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void sparse_apply_kernel(
+    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ src, int64_t n_items, int N, int E,
+    int64_t total_rows, const float* __restrict__ dz, int64_t dz_ld, const float* __restrict__ src_scale,
+    float* __restrict__ tables, float* __restrict__ slot0, float* __restrict__ slot1, Opt opt) {
+  const int64_t item = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+  const int g = threadIdx.x % G;
+  if (item >= n_items) return;
+  const uint32_t key = keys[item];
+  if ((int64_t)key >= total_rows) return;
+  if (item > 0 && keys[item - 1] == key) return;  // not the head of its run
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int64_t j = item;
+  do {
+    const uint32_t sj = src[j];
+    const int64_t b = sj / (uint32_t)N;
+    const int64_t n = sj % (uint32_t)N;
+    const float4 v = *reinterpret_cast<const float4*>(dz + b * dz_ld + n * E + g * 4);
+    const float sc = src_scale ? src_scale[sj] : 1.f;
+    acc.x += v.x * sc; acc.y += v.y * sc; acc.z += v.z * sc; acc.w += v.w * sc;
+    ++j;
+  } while (j < n_items && keys[j] == key);
+  const int64_t off = (int64_t)key * E + g * 4;
+  opt_apply4(opt, acc, reinterpret_cast<float4*>(tables + off),
+             slot0 ? reinterpret_cast<float4*>(slot0 + off) : nullptr,
+             slot1 ? reinterpret_cast<float4*>(slot1 + off) : nullptr);
+}
+
+__global__ __launch_bounds__(256) void dense_update_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ s0, float* __restrict__ s1,
+                                                          int64_t n, Opt o) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    if (o.kind == CTR_OPT_ADAM) {
+      const float m = o.b1 * s0[i] + (1.f - o.b1) * gi;
+      const float v = o.b2 * s1[i] + (1.f - o.b2) * gi * gi;
+      s0[i] = m; s1[i] = v;
+      p[i] -= o.lr * m / (sqrtf(v) + o.eps);
+    } else if (o.kind == CTR_OPT_ADAGRAD) {
+      const float a = s0[i] + gi * gi;
+      s0[i] = a;
+      p[i] -= o.lr * gi / sqrtf(a);
+    } else {
+      p[i] -= o.lr * gi;
+    }
+  }
+}
+
+static Opt make_opt(const ctr_opt_t* o) {
+  Opt r;
+  r.kind = o->kind; r.lr = o->lr; r.b1 = o->beta1; r.b2 = o->beta2; r.eps = o->eps;
+  return r;
+}
+
+}  // namespace ctr
+
+using namespace ctr;
+
+extern "C" int ctr_emb_sparse_apply(const uint32_t* keys_sorted, const uint32_t* src_sorted,
+                                    int64_t n_items, int N, int E, int64_t total_rows, const float* dz,
+                                    int64_t dz_ld, const float* src_scale, float* tables, float* slot0,
+                                    float* slot1, const ctr_opt_t* opt, void* stream) {
+  CTR_REQUIRE(opt, "ctr_emb_sparse_apply: opt is null");
+  CTR_REQUIRE(n_items >= 0 && N > 0, "ctr_emb_sparse_apply: bad size");
+  CTR_REQUIRE(E >= 4 && E <= 256 && (E & (E - 1)) == 0, "ctr_emb_sparse_apply: E=%d must be a power of two in [4,256]", E);
+  if (n_items == 0) return CTR_OK;
+  CTR_REQUIRE(keys_sorted && src_sorted && dz, "ctr_emb_sparse_apply: null pointer");
+  CTR_REQUIRE(dz_ld % 4 == 0 && ((uintptr_t)dz % 16) == 0, "ctr_emb_sparse_apply: dz alignment");
+  switch (opt->kind) {
+    case CTR_OPT_GRAD_ONLY: CTR_REQUIRE(slot0, "ctr_emb_sparse_apply: GRAD_ONLY needs slot0"); break;
+    case CTR_OPT_ADAM: CTR_REQUIRE(tables && slot0 && slot1, "ctr_emb_sparse_apply: Adam needs tables, m, v"); break;
+    case CTR_OPT_ADAGRAD: CTR_REQUIRE(tables && slot0, "ctr_emb_sparse_apply: Adagrad needs tables, acc"); break;
+    case CTR_OPT_SGD: CTR_REQUIRE(tables, "ctr_emb_sparse_apply: SGD needs tables"); break;
+    default: CTR_REQUIRE(false, "ctr_emb_sparse_apply: unknown optimizer kind %d", opt->kind);
+  }
+  const Opt o = make_opt(opt);
+  hipStream_t st = (hipStream_t)stream;
+  const int G = E / 4;
+  const dim3 grid((unsigned)cdiv(n_items, 256 / G)), block(256);
+  // GRAD_ONLY writes through slot0 only; give the kernel a non-null table pointer it never uses.
+  float* tab = tables ? tables : slot0;
+#define LAUNCH(GG)                                                                                   \
+  hipLaunchKernelGGL(sparse_apply_kernel<GG>, grid, block, 0, st, keys_sorted, src_sorted, n_items, N, \
+                     E, total_rows, dz, dz_ld, src_scale, tab, slot0, slot1, o)
+  switch (G) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 4: LAUNCH(4); break;
+    case 8: LAUNCH(8); break;
+    case 16: LAUNCH(16); break;
+    case 32: LAUNCH(32); break;
+    case 64: LAUNCH(64); break;
+  }
+#undef LAUNCH
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_dense_update(float* param, const float* grad, float* slot0, float* slot1, int64_t n,
+                                const ctr_opt_t* opt, void* stream) {
+  CTR_REQUIRE(opt && n >= 0, "ctr_dense_update: bad argument");
+  if (n == 0) return CTR_OK;
+  CTR_REQUIRE(param && grad, "ctr_dense_update: null pointer");
+  CTR_REQUIRE(opt->kind == CTR_OPT_ADAM || opt->kind == CTR_OPT_ADAGRAD || opt->kind == CTR_OPT_SGD,
+              "ctr_dense_update: unknown optimizer kind %d", opt->kind);
+  CTR_REQUIRE(opt->kind != CTR_OPT_ADAM || (slot0 && slot1), "ctr_dense_update: Adam needs m and v");
+  CTR_REQUIRE(opt->kind != CTR_OPT_ADAGRAD || slot0, "ctr_dense_update: Adagrad needs the accumulator");
+  const int64_t blocks = cdiv(n, 256) < 8192 ? cdiv(n, 256) : 8192;
+  hipLaunchKernelGGL(dense_update_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param,
+                     grad, slot0, slot1, n, make_opt(opt));
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}

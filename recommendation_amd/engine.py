@@ -1,0 +1,210 @@
+"""Host-side building blocks shared by the model classes: flat dense parameters, the sharded-
+ready embedding tables, the embedding/FM front end in both semantics, and the MLP tower.
+All arithmetic happens in libctrhip kernels (ops.py); this file only owns buffers and order.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import OPT_ADAGRAD, OPT_ADAM, OPT_GRAD_ONLY, OPT_SGD
+
+OPT_KIND = dict(adam=OPT_ADAM, adagrad=OPT_ADAGRAD, sgd=OPT_SGD)
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def truncated_normal(rng, shape, std=0.01):
+    """Host initialiser with the distribution of tf.truncated_normal_initializer(0, std)
+    (DeepFM/DeepFM.py:30): re-sample outside two standard deviations."""
+    x = rng.standard_normal(size=shape)
+    bad = np.abs(x) > 2.0
+    while bad.any():
+        x[bad] = rng.standard_normal(size=int(bad.sum()))
+        bad = np.abs(x) > 2.0
+    return (x * std).astype(np.float32)
+
+
+class DenseParams:
+    """All dense variables of a model in ONE flat fp32 buffer (+ flat grad and optimizer
+    slots), so the optimizer is a single launch and a data-parallel all-reduce is one call."""
+
+    def __init__(self, shapes, device):
+        self.shapes = OrderedDict(shapes)
+        self.offsets = OrderedDict()
+        off = 0
+        for k, s in self.shapes.items():
+            self.offsets[k] = off
+            off += round_up(int(np.prod(s)), 4)          # keep every tensor 16-byte aligned
+        self.size = off
+        self.flat = torch.zeros(max(off, 4), dtype=torch.float32, device=device)
+        self.grad = torch.zeros_like(self.flat)
+        self.slot0 = None
+        self.slot1 = None
+
+    def _view(self, buf, k):
+        s = self.shapes[k]
+        n = int(np.prod(s))
+        return buf[self.offsets[k]:self.offsets[k] + n].view(*s)
+
+    def p(self, k):
+        return self._view(self.flat, k)
+
+    def g(self, k):
+        return self._view(self.grad, k)
+
+    def mat(self, k, buf=None):
+        """2-D [rows, cols] view (vectors become [1, n])."""
+        v = self._view(self.flat if buf is None else buf, k)
+        return v if v.dim() == 2 else v.reshape(1, -1) if v.dim() == 1 else v.reshape(v.shape[0], -1)
+
+    def init_slots(self, kind):
+        if kind == 'adam':
+            self.slot0 = torch.zeros_like(self.flat)
+            self.slot1 = torch.zeros_like(self.flat)
+        elif kind == 'adagrad':
+            self.slot0 = torch.full_like(self.flat, 0.1)   # tf.train.AdagradOptimizer initial accumulator
+            self.slot1 = None
+
+    def apply(self, opt):
+        ops.dense_update(self.flat, self.grad, opt, self.slot0, self.slot1)
+
+
+class EmbeddingTables:
+    """All per-field tables concatenated into one [sum(V), E] buffer with a row-offset array
+    (the layout the gather and the sorted backward index with one 32-bit global row id)."""
+
+    def __init__(self, cate_list, E, device):
+        self.cate_list = [int(v) for v in cate_list]
+        self.F = len(self.cate_list)
+        self.E = int(E)
+        offs = np.zeros(self.F + 1, dtype=np.int64)
+        offs[1:] = np.cumsum(self.cate_list)
+        self.offsets_host = offs
+        self.total_rows = int(offs[-1])
+        self.row_offset = torch.as_tensor(offs, device=device)
+        self.weight = torch.zeros(self.total_rows, self.E, dtype=torch.float32, device=device)
+        self.slot0 = None
+        self.slot1 = None
+        self.grad = None        # dense gradient buffer of the TF-1.x-exact (non-lazy) Adam path
+
+    def table(self, f, buf=None):
+        b = self.weight if buf is None else buf
+        return b[int(self.offsets_host[f]):int(self.offsets_host[f + 1])]
+
+    def init_slots(self, kind, dense_adam):
+        if kind == 'adam':
+            self.slot0 = torch.zeros_like(self.weight)
+            self.slot1 = torch.zeros_like(self.weight)
+            if dense_adam:
+                self.grad = torch.zeros_like(self.weight)
+        elif kind == 'adagrad':
+            self.slot0 = torch.full_like(self.weight, 0.1)
+
+
+class EmbedFront:
+    """Embedding block + FM reductions in either semantics.
+
+    mode 'R': the reference block exactly as written (DeepFM/DeepFM.py:43-53): Z is the dense
+              [B, sum(V), E] tensor whose only non-zero rows are copies of W_f[1].
+    mode 'S': standard per-field lookup Z[b,f,:] = W_f[x[b,f]] (Wide_Deep/Wide_Deep.py:51).
+    cont_embed adds the value-scaled continuous rows of AFM/PNN (AFM/AFM.py:52-57)."""
+
+    def __init__(self, tables, mode, cont_num, cont_embed):
+        self.t = tables
+        self.mode = mode
+        self.C = int(cont_num)
+        self.cont_embed = bool(cont_embed)
+        self.Ncat = tables.total_rows if mode == 'R' else tables.F
+        self.N = self.Ncat + (self.C if cont_embed else 0)
+        self.E = tables.E
+
+    def forward(self, idx, x_cont, *, z_out, cont_tail=False, cont_w=None, first_out=None, s_out=None,
+                second_out=None, drop_first=None, drop_second=None, oor_count=None):
+        t, E = self.t, self.E
+        want_fm = first_out is not None or s_out is not None or second_out is not None
+        if self.mode == 'S':
+            ops.embed_fwd(t.weight, t.row_offset, idx, x_cont, cont_w if self.cont_embed else None, E=E,
+                          z_out=z_out, cont_tail=cont_tail, first_out=first_out, s_out=s_out,
+                          second_out=second_out, drop_first=drop_first, drop_second=drop_second,
+                          oor_count=oor_count)
+            return
+        if z_out is None:
+            raise ValueError('R-mode needs the dense Z buffer')
+        ops.embed_onehot_fwd(t.weight, t.row_offset, idx, x_cont, E=E, z_out=z_out,
+                             cont_tail=cont_tail and not self.cont_embed)
+        if self.cont_embed:
+            empty_idx = idx[:, :0].contiguous()
+            ops.embed_fwd(t.weight, t.row_offset[:1], empty_idx, x_cont, cont_w, E=E,
+                          z_out=z_out[:, self.Ncat * E:], cont_tail=cont_tail)
+        if want_fm:
+            ops.fm_fwd(z_out, N=self.N, E=E, first_out=first_out, s_out=s_out, second_out=second_out,
+                       drop_first=drop_first, drop_second=drop_second)
+
+    def backward_tables(self, idx, dz, keys, src, ws, opt, lazy):
+        """dz: [B, >= N*E] gradient with respect to Z.  Sort (key, src), segment-reduce, update."""
+        t = self.t
+        B, F = idx.shape
+        ops.emb_sort(idx, t.row_offset, N=self.N, total_rows=t.total_rows, rmode=(self.mode == 'R'),
+                     keys_out=keys, src_out=src, ws=ws)
+        if opt.kind == OPT_ADAM and not lazy:
+            t.grad.zero_()
+            ops.emb_sparse_apply(keys, src, B * F, N=self.N, E=self.E, total_rows=t.total_rows, dz=dz,
+                                 opt=ops.make_opt(OPT_GRAD_ONLY), slot0=t.grad)
+            ops.dense_update(t.weight, t.grad, opt, t.slot0, t.slot1)
+        else:
+            ops.emb_sparse_apply(keys, src, B * F, N=self.N, E=self.E, total_rows=t.total_rows, dz=dz,
+                                 opt=opt, tables=t.weight, slot0=t.slot0, slot1=t.slot1)
+
+    def backward_cont_w(self, dz, x_cont, g_cont_w, ws):
+        """d cont_w[c,:] = sum_b dz[b, Ncat + c, :] * x_cont[b,c]."""
+        E = self.E
+        ops.colsum(dz[:, self.Ncat * E:(self.Ncat + self.C) * E], g_cont_w.reshape(-1), w=x_cont, w_group=E, ws=ws)
+
+
+class Tower:
+    """relu(x W_i + b_i) -> dropout chain on the fp32 MFMA GEMM, with the relu/dropout backward
+    fused into the next GEMM's epilogue (DeepFM/DeepFM.py:65-80)."""
+
+    def __init__(self, dense, prefix, n_layers):
+        self.dense = dense
+        self.names = [('%s_w_%d' % (prefix, i), '%s_b_%d' % (prefix, i)) for i in range(n_layers)]
+        self.widths = [dense.shapes[w][1] for w, _ in self.names]
+        self.d_in = dense.shapes[self.names[0][0]][0]
+
+    def forward(self, x, acts, drops, ws):
+        """x: [B, >= d_in]; acts[i]: output buffer of layer i ([B, L_i] views)."""
+        h = x[:, :self.d_in]
+        for i, (wn, bn) in enumerate(self.names):
+            ops.gemm(h, self.dense.p(wn), acts[i], bias=self.dense.p(bn), relu=True, dropout=drops[i], ws=ws)
+            h = acts[i]
+
+    def backward(self, x, acts, g_last, gbufs, rates, dx, ws):
+        """g_last: gradient w.r.t. acts[-1] (post relu+dropout); it is masked in place.
+        gbufs[i]: scratch [B, L_i] for i < n-1.  dx (optional): [B, >= d_in] receives dL/dx."""
+        n = len(self.names)
+        scale = [1.0 / (1.0 - r) if r else 1.0 for r in rates]
+        ops.relu_mask_apply(g_last, acts[n - 1], scale[n - 1])
+        g = g_last
+        for i in range(n - 1, -1, -1):
+            wn, bn = self.names[i]
+            h_in = x[:, :self.d_in] if i == 0 else acts[i - 1]
+            ops.gemm(h_in, g, self.dense.g(wn), trans_a=True, ws=ws)                 # dW = h_in^T g
+            ops.colsum(g, self.dense.g(bn).reshape(-1), ws=ws)                        # db
+            if i > 0:
+                ops.gemm(g, self.dense.p(wn), gbufs[i - 1], trans_b=True, mask_src=acts[i - 1],
+                         mask_scale=scale[i - 1], ws=ws)
+                g = gbufs[i - 1]
+            elif dx is not None:
+                ops.gemm(g, self.dense.p(wn), dx[:, :self.d_in], trans_b=True, ws=ws)
+
+
+def adam_lr_t(lr, t, b1=0.9, b2=0.999):
+    """tf.train.AdamOptimizer's bias-corrected step size for update number t (1-based)."""
+    return lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)

@@ -1,0 +1,298 @@
+"""Common host logic of the six CSV-family model classes (DeepFM, DCN, NFM, PNN, AFM, ESMM).
+
+Mirrors the reference's model-class surface (DeepFM/DeepFM.py:5-131): __init__(args, cate_num,
+cont_num, cate_list), build(), run(session, X_cate, X_cont, y, is_train, step), .saver.
+Subclasses describe their dense variables and implement _forward/_backward with ops.py kernels.
+
+Extra, optional attributes read from `args` (absent in the reference's argparse namespaces):
+  mode        'R' (default): the embedding block exactly as the reference writes it;
+              'S': standard per-field lookup (the only form that exists at Criteo scale)
+  adam_mode   'tf1' : TF-1.x AdamOptimizer on tables (m, v decay for every row; dense pass)
+              'lazy': rows without a gradient are untouched.  Default: 'tf1' in R-mode, 'lazy' in S-mode
+  init_std    stddev of the truncated-normal initialiser (0.01)
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from .engine import OPT_KIND, DenseParams, EmbedFront, EmbeddingTables, adam_lr_t, round_up, truncated_normal
+from ._lib import OPT_ADAM
+
+
+class Saver:
+    """Stand-in for tf.train.Saver (DeepFM/DeepFM.py:25, DeepFM/main.py:74-80,129):
+    save(sess, path) / restore(sess, path).  Variables are stored by their reference names
+    (plus optimizer slots and global_step) in one safetensors file at `path`."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def save(self, sess, path):
+        from safetensors.torch import save_file
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        save_file(self.model._state_dict(), path + '.safetensors')
+        with open(os.path.join(os.path.dirname(os.path.abspath(path)), 'checkpoint'), 'w') as f:
+            f.write('model_checkpoint_path: "%s"\n' % os.path.basename(path))
+        return path
+
+    def restore(self, sess, path):
+        from safetensors.torch import load_file
+        self.model._ensure_initialized(sess)
+        self.model._load_state_dict(load_file(path + '.safetensors'))
+
+
+def get_checkpoint_state(directory):
+    """tf.train.get_checkpoint_state counterpart: latest checkpoint path recorded in
+    `directory`/checkpoint, or None."""
+    p = os.path.join(directory, 'checkpoint')
+    if not os.path.exists(p):
+        return None
+    with open(p) as f:
+        line = f.readline()
+    name = line.split('"')[1]
+    full = os.path.join(directory, name)
+    return full if os.path.exists(full + '.safetensors') else None
+
+
+class CTRModel:
+    MODEL = None
+    OPTIMIZER = 'adam'
+    CONT_EMBED = False        # AFM / PNN append value-scaled continuous rows to Z
+    NEEDS_DENSE_Z = True      # model consumes Z itself (not only its reductions)
+
+    def __init__(self, args, cate_num, cont_num, cate_list):
+        self.args = args
+        self.cate_num = int(cate_num)
+        self.cont_num = int(cont_num)
+        self.embed_size = int(args.embed_size)
+        self.regular_rate = getattr(args, 'regular_rate', 0.0)     # declared, never added to the loss
+        self.learning_rate = float(args.learning_rate)
+        self.decay_steps = int(args.decay_steps)
+        self.decay_rate = float(args.decay_rate)
+        self.cate_list = [int(v) for v in cate_list]
+        self.mode = getattr(args, 'mode', 'R')
+        if self.mode not in ('R', 'S'):
+            raise ValueError("mode must be 'R' or 'S'")
+        self.adam_mode = getattr(args, 'adam_mode', 'tf1' if self.mode == 'R' else 'lazy')
+        self.init_std = float(getattr(args, 'init_std', 0.01))
+        self.global_step = 0
+        self._built = False
+        self._ready = False
+        self._bufs = {}
+
+    # ---- graph definition -----------------------------------------------------------------
+    def build(self):
+        E = self.embed_size
+        self.n_cat_rows = int(np.sum(self.cate_list)) if self.mode == 'R' else self.cate_num
+        self.N = self.n_cat_rows + (self.cont_num if self.CONT_EMBED else 0)
+        shapes = OrderedDict()
+        if self.CONT_EMBED:
+            shapes['embedding/embed_cont_w_%d' % (self.cate_num - 1)] = (self.cont_num, E)
+        self._dense_shapes(shapes)
+        self.dense_shapes = shapes
+        self.saver = Saver(self)
+        self._built = True
+
+    def _dense_shapes(self, shapes):
+        raise NotImplementedError
+
+    def variable_shapes(self):
+        """name -> shape of every trainable variable, reference naming."""
+        out = OrderedDict(('embedding/embed_cate_w_%d' % i, (v, self.embed_size))
+                          for i, v in enumerate(self.cate_list))
+        out.update(self.dense_shapes)
+        return out
+
+    # ---- variables ------------------------------------------------------------------------
+    def initialize(self, session, params=None, seed=0):
+        """Allocate device state and initialise variables (the counterpart of
+        sess.run(tf.global_variables_initializer())).  `params` injects name -> array."""
+        if not self._built:
+            raise RuntimeError('call build() first')
+        dev = session.device
+        self.session = session
+        self.tables = EmbeddingTables(self.cate_list, self.embed_size, dev)
+        self.dense = DenseParams(self.dense_shapes, dev)
+        self.front = EmbedFront(self.tables, self.mode, self.cont_num, self.CONT_EMBED)
+        self.tables.init_slots(self.OPTIMIZER, dense_adam=(self.adam_mode == 'tf1'))
+        self.dense.init_slots(self.OPTIMIZER)
+        self._loss_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._oor = torch.zeros(1, dtype=torch.int32, device=dev)
+        rng = np.random.Generator(np.random.PCG64(seed))
+        init = OrderedDict()
+        for k, s in self.variable_shapes().items():
+            init[k] = truncated_normal(rng, s, self.init_std)
+        if params:
+            for k, v in params.items():
+                if k not in init:
+                    raise KeyError('unknown variable %s' % k)
+                v = np.asarray(v, dtype=np.float32)
+                if tuple(v.shape) != tuple(init[k].shape):
+                    raise ValueError('%s: shape %s != %s' % (k, v.shape, init[k].shape))
+                init[k] = v
+        self.set_params(init)
+        self.global_step = 0
+        self._ready = True
+        self._post_init()
+
+    def _post_init(self):
+        pass
+
+    def _ensure_initialized(self, session):
+        if not self._ready:
+            self.initialize(session)
+
+    def set_params(self, params):
+        for k, v in params.items():
+            t = torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32))
+            if k.startswith('embedding/embed_cate_w_'):
+                self.tables.table(int(k.rsplit('_', 1)[1])).copy_(t)
+            else:
+                self.dense.p(k).copy_(t.reshape(self.dense.shapes[k]))
+
+    def get_params(self):
+        out = OrderedDict()
+        for f in range(self.cate_num):
+            out['embedding/embed_cate_w_%d' % f] = self.tables.table(f).cpu().numpy()
+        for k in self.dense.shapes:
+            out[k] = self.dense.p(k).cpu().numpy()
+        return out
+
+    def get_grads(self):
+        """Dense-variable gradients of the last training step (tables: only with adam_mode 'tf1')."""
+        out = OrderedDict((k, self.dense.g(k).cpu().numpy()) for k in self.dense.shapes)
+        if self.tables.grad is not None:
+            for f in range(self.cate_num):
+                out['embedding/embed_cate_w_%d' % f] = self.tables.table(f, self.tables.grad).cpu().numpy()
+        return out
+
+    def _state_dict(self):
+        sd = OrderedDict((k, torch.as_tensor(v)) for k, v in self.get_params().items())
+        sd['optimization/Variable'] = torch.tensor([self.global_step], dtype=torch.int64)
+        for name, t in (('tables/slot0', self.tables.slot0), ('tables/slot1', self.tables.slot1),
+                        ('dense/slot0', self.dense.slot0), ('dense/slot1', self.dense.slot1)):
+            if t is not None:
+                sd[name] = t.detach().cpu()
+        return sd
+
+    def _load_state_dict(self, sd):
+        names = set(self.variable_shapes())
+        self.set_params({k: v.numpy() for k, v in sd.items() if k in names})
+        self.global_step = int(sd['optimization/Variable'][0])
+        for name, t in (('tables/slot0', self.tables.slot0), ('tables/slot1', self.tables.slot1),
+                        ('dense/slot0', self.dense.slot0), ('dense/slot1', self.dense.slot1)):
+            if t is not None and name in sd:
+                t.copy_(sd[name])
+
+    # ---- step ------------------------------------------------------------------------------
+    def _lr(self):
+        """tf.train.exponential_decay(staircase=True) at the pre-update global_step."""
+        return self.learning_rate * (self.decay_rate ** (self.global_step // self.decay_steps))
+
+    def _optimizer(self):
+        lr = self._lr()
+        if self.OPTIMIZER == 'adam':
+            lr = adam_lr_t(lr, self.global_step + 1)
+        return ops.make_opt(OPT_KIND[self.OPTIMIZER], lr=lr)
+
+    def _upload(self, X_cate, X_cont, y):
+        """Feed conversion of the reference placeholders: int64 -> int32, float64 -> float32."""
+        dev = self.session.device
+        if isinstance(X_cate, torch.Tensor) and X_cate.is_cuda:
+            idx = X_cate.to(torch.int32).contiguous()
+        else:
+            idx = torch.as_tensor(np.ascontiguousarray(np.asarray(X_cate).astype(np.int32))).to(dev)
+        if isinstance(X_cont, torch.Tensor) and X_cont.is_cuda:
+            xc = X_cont.to(torch.float32).contiguous()
+        else:
+            xc = torch.as_tensor(np.ascontiguousarray(np.asarray(X_cont).astype(np.float32))).to(dev)
+        if isinstance(y, torch.Tensor) and y.is_cuda:
+            yy = y.to(torch.float32).contiguous()
+        else:
+            yy = torch.as_tensor(np.ascontiguousarray(np.asarray(y).astype(np.float32))).to(dev)
+        if idx.dim() != 2 or idx.shape[1] != self.cate_num:
+            raise ValueError('X_cate must be [B, %d]' % self.cate_num)
+        if xc.dim() != 2 or xc.shape[1] != self.cont_num or xc.shape[0] != idx.shape[0]:
+            raise ValueError('X_cont must be [B, %d]' % self.cont_num)
+        if yy.dim() != 1 or yy.shape[0] != idx.shape[0]:
+            raise ValueError('y must be [B]')
+        return idx, xc, yy
+
+    def _buffers(self, B):
+        if B not in self._bufs:
+            dev = self.session.device
+            bufs = dict(logit=torch.zeros(B, dtype=torch.float32, device=dev),
+                        y_out=torch.zeros(B, dtype=torch.float32, device=dev),
+                        dlogit=torch.zeros(B, dtype=torch.float32, device=dev),
+                        keys=torch.zeros(B * self.cate_num, dtype=torch.int32, device=dev),
+                        src=torch.zeros(B * self.cate_num, dtype=torch.int32, device=dev))
+            self._alloc(B, bufs, dev)
+            self._bufs[B] = bufs
+        return self._bufs[B]
+
+    def _alloc(self, B, bufs, dev):
+        raise NotImplementedError
+
+    def _drop(self, rate, stream_id, train):
+        if not train:
+            return None
+        return ops.make_dropout(rate, self.session.seed * 1000003 + self.global_step, stream_id)
+
+    def train_step(self, idx, xc, yy):
+        """One fwd + bwd + optimizer step on device tensors; returns the device scalar loss
+        (computed with the pre-update weights, as the reference's fetch does)."""
+        B = idx.shape[0]
+        bufs = self._buffers(B)
+        self._forward(idx, xc, bufs, True)
+        self._loss(bufs, yy, True)
+        self._backward(idx, xc, bufs)
+        self.dense.apply(self._optimizer())
+        self.global_step += 1
+        return self._loss_dev
+
+    def predict_step(self, idx, xc):
+        bufs = self._buffers(idx.shape[0])
+        self._forward(idx, xc, bufs, False)
+        self._loss(bufs, None, False)
+        return bufs['y_out']
+
+    def run(self, session, X_cate, X_cont, y, is_train=False, step=None):
+        self._ensure_initialized(session)
+        idx, xc, yy = self._upload(X_cate, X_cont, y)
+        if idx.shape[0] == 0:
+            raise ValueError('empty batch')
+        if is_train:
+            return np.float32(self.train_step(idx, xc, yy).item())
+        y_out = self.predict_step(idx, xc)
+        # tf.round is round-half-to-even; torch.round too
+        return np.asarray(yy.cpu().numpy(), dtype=np.float32), torch.round(y_out).cpu().numpy()
+
+    def predict_proba(self, session, X_cate, X_cont):
+        self._ensure_initialized(session)
+        idx, xc, _ = self._upload(X_cate, X_cont, np.zeros(len(X_cate), dtype=np.float32))
+        return self.predict_step(idx, xc).cpu().numpy()
+
+    # hooks
+    LOSS_KIND = 0
+
+    def _loss(self, bufs, yy, train):
+        if train:
+            ops.loss_head(self.LOSS_KIND, bufs['logit'], yy, y_out=bufs['y_out'], loss_out=self._loss_dev,
+                          dx=bufs['dlogit'])
+        else:
+            ops.loss_head(self.LOSS_KIND, bufs['logit'], bufs['logit'], y_out=bufs['y_out'])
+
+    def _forward(self, idx, xc, bufs, train):
+        raise NotImplementedError
+
+    def _backward(self, idx, xc, bufs):
+        raise NotImplementedError
+
+    def _tables_backward(self, idx, dz, bufs):
+        self.front.backward_tables(idx, dz, bufs['keys'], bufs['src'], self.session.ws, self._optimizer(),
+                                   lazy=(self.adam_mode == 'lazy'))

@@ -1,0 +1,324 @@
+"""Thin operator layer: torch tensors in, libctrhip calls out.
+
+torch is only the carrier of device memory and of the HIP stream; every operator hands raw
+device pointers to the C ABI.  Shapes, dtypes and devices are validated here, on the host,
+before a kernel is launched.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import Dropout, Epilogue, Opt, check
+
+KEEP_ONE = 1 << 24
+
+
+def lib():
+    return _lib.load()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, dtype=None, name='tensor'):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError('%s must live on the GPU (libctrhip has no CPU path)' % name)
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError('%s: expected %s, got %s' % (name, dtype, t.dtype))
+    return C.c_void_p(t.data_ptr())
+
+
+def _rows(t, name):
+    """(pointer, leading dimension) of a 2-D view whose last dim is contiguous."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError('%s must be 2-D with a contiguous last dimension' % name)
+    return _ptr(t, torch.float32, name), int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), t.shape[1])
+
+
+def make_dropout(rate, seed, stream_id):
+    """Dropout descriptor for tf.layers.dropout(rate) in training mode; None when rate == 0."""
+    if rate is None or rate <= 0.0:
+        return None
+    keep = 1.0 - float(rate)
+    return Dropout(seed=int(seed), stream_id=int(stream_id),
+                   keep_threshold=int(math.floor(keep * KEEP_ONE)), scale=1.0 / keep)
+
+
+def _dp(d):
+    return C.byref(d) if d is not None else None
+
+
+class Workspace:
+    """Grow-only device scratch buffer handed to the kernels that need one."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes):
+        nbytes = int(nbytes)
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
+        return C.c_void_p(self.buf.data_ptr()), self.buf.numel()
+
+
+# ------------------------------------------------------------------ embedding front end
+def embed_fwd(tables, row_offset, idx, x_cont=None, cont_w=None, *, E, z_out=None, cont_tail=False,
+              first_out=None, s_out=None, second_out=None, drop_first=None, drop_second=None,
+              oor_count=None):
+    B, F = idx.shape
+    C_ = 0 if x_cont is None else x_cont.shape[1]
+    if idx.dtype != torch.int32 or not idx.is_contiguous():
+        raise TypeError('idx must be contiguous int32 [B,F]')
+    if row_offset.dtype != torch.int64 or row_offset.numel() != F + 1:
+        raise ValueError('row_offset must be int64 [F+1]')
+    if tables.dim() != 2 or tables.shape[1] != E or not tables.is_contiguous():
+        raise ValueError('tables must be contiguous [rows, E]')
+    if x_cont is not None and (not x_cont.is_contiguous() or x_cont.shape[0] != B):
+        raise ValueError('x_cont must be contiguous [B,C]')
+    if cont_w is not None and (tuple(cont_w.shape) != (C_, E) or not cont_w.is_contiguous()):
+        raise ValueError('cont_w must be contiguous [C,E]')
+    N = F + (C_ if cont_w is not None else 0)
+    zp, zld = (None, 0)
+    if z_out is not None:
+        zp, zld = _rows(z_out, 'z_out')
+        if z_out.shape[0] != B or z_out.shape[1] < N * E + (C_ if cont_tail else 0):
+            raise ValueError('z_out too small')
+    fp, fld = (None, 0) if first_out is None else _rows(first_out, 'first_out')
+    sp, sld = (None, 0) if second_out is None else _rows(second_out, 'second_out')
+    if first_out is not None and (first_out.shape[0] != B or first_out.shape[1] < N):
+        raise ValueError('first_out too small')
+    if second_out is not None and (second_out.shape[0] != B or second_out.shape[1] < E):
+        raise ValueError('second_out too small')
+    if s_out is not None and (tuple(s_out.shape) != (B, E) or not s_out.is_contiguous()):
+        raise ValueError('s_out must be contiguous [B,E]')
+    check(lib().ctr_embed_fwd(_ptr(tables, torch.float32, 'tables'), _ptr(row_offset), _ptr(idx),
+                              _ptr(x_cont, torch.float32, 'x_cont'), _ptr(cont_w, torch.float32, 'cont_w'),
+                              B, F, C_, E, zp, zld, int(bool(cont_tail)), fp, fld,
+                              _ptr(s_out, torch.float32, 's_out'), sp, sld, _dp(drop_first), _dp(drop_second),
+                              _ptr(oor_count, torch.int32, 'oor_count'), _stream()), 'ctr_embed_fwd')
+
+
+def fm_fwd(z, *, N, E, first_out=None, s_out=None, second_out=None, drop_first=None, drop_second=None):
+    B = z.shape[0]
+    zp, zld = _rows(z, 'z')
+    if z.shape[1] < N * E:
+        raise ValueError('z narrower than N*E')
+    fp, fld = (None, 0) if first_out is None else _rows(first_out, 'first_out')
+    sp, sld = (None, 0) if second_out is None else _rows(second_out, 'second_out')
+    if first_out is not None and (first_out.shape[0] != B or first_out.shape[1] < N):
+        raise ValueError('first_out too small')
+    if second_out is not None and (second_out.shape[0] != B or second_out.shape[1] < E):
+        raise ValueError('second_out too small')
+    if s_out is not None and (tuple(s_out.shape) != (B, E) or not s_out.is_contiguous()):
+        raise ValueError('s_out must be contiguous [B,E]')
+    check(lib().ctr_fm_fwd(zp, zld, B, N, E, fp, fld, _ptr(s_out, torch.float32), sp, sld, _dp(drop_first),
+                           _dp(drop_second), _stream()), 'ctr_fm_fwd')
+
+
+def relu_mask_apply(g, act, scale=1.0):
+    rows, cols = g.shape
+    gp, gld = _rows(g, 'g')
+    ap, ald = _rows(act, 'act')
+    if act.shape[0] != rows or act.shape[1] < cols:
+        raise ValueError('relu_mask_apply shape mismatch')
+    check(lib().ctr_relu_mask_apply(gp, gld, ap, ald, rows, cols, float(scale), _stream()), 'ctr_relu_mask_apply')
+
+
+def embed_onehot_fwd(tables, row_offset, idx, x_cont, *, E, z_out, cont_tail=False, pos_out=None):
+    B, F = idx.shape
+    C_ = 0 if x_cont is None else x_cont.shape[1]
+    if idx.dtype != torch.int32 or not idx.is_contiguous():
+        raise TypeError('idx must be contiguous int32 [B,F]')
+    zp, zld = _rows(z_out, 'z_out')
+    if pos_out is not None and (pos_out.dtype != torch.int32 or tuple(pos_out.shape) != (B, F)):
+        raise ValueError('pos_out must be int32 [B,F]')
+    check(lib().ctr_embed_onehot_fwd(_ptr(tables, torch.float32), _ptr(row_offset, torch.int64), _ptr(idx),
+                                     _ptr(x_cont, torch.float32), B, F, C_, E, zp, zld,
+                                     int(bool(cont_tail)), _ptr(pos_out), _stream()), 'ctr_embed_onehot_fwd')
+
+
+def embed_bwd_dz(dz, *, B, N, E, gz=None, g_first=None, g_second=None, s=None, z=None,
+                 drop_first=None, drop_second=None):
+    dzp, dzld = _rows(dz, 'dz')
+    gzp, gzld = (None, 0) if gz is None else _rows(gz, 'gz')
+    g1p, g1ld = (None, 0) if g_first is None else _rows(g_first, 'g_first')
+    g2p, g2ld = (None, 0) if g_second is None else _rows(g_second, 'g_second')
+    zp, zld = (None, 0) if z is None else _rows(z, 'z')
+    for t, w, nm in ((dz, N * E, 'dz'), (gz, N * E, 'gz'), (g_first, N, 'g_first'), (g_second, E, 'g_second'),
+                     (z, N * E, 'z')):
+        if t is not None and (t.shape[0] != B or t.shape[1] < w):
+            raise ValueError('%s too small' % nm)
+    check(lib().ctr_embed_bwd_dz(gzp, gzld, g1p, g1ld, g2p, g2ld, _ptr(s, torch.float32), zp, zld, B, N, E,
+                                 _dp(drop_first), _dp(drop_second), dzp, dzld, _stream()), 'ctr_embed_bwd_dz')
+
+
+# ------------------------------------------------------------------ sort + sparse update
+def emb_sort(idx, row_offset, *, N, total_rows, rmode, keys_out, src_out, ws):
+    B, F = idx.shape
+    n = B * F
+    if keys_out.numel() < n or src_out.numel() < n:
+        raise ValueError('sort outputs too small')
+    wp, wn = ws.get(lib().ctr_emb_sort_workspace_bytes(n))
+    check(lib().ctr_emb_sort(_ptr(idx, torch.int32), _ptr(row_offset, torch.int64), B, F, N, int(total_rows),
+                             int(bool(rmode)), _ptr(keys_out), _ptr(src_out), wp, wn, _stream()), 'ctr_emb_sort')
+
+
+def sort_pairs(keys, vals, key_bits, ws):
+    n = keys.numel()
+    ko = torch.empty_like(keys)
+    vo = torch.empty_like(vals)
+    wp, wn = ws.get(lib().ctr_emb_sort_workspace_bytes(n))
+    check(lib().ctr_sort_pairs(_ptr(keys), _ptr(vals), n, int(key_bits), _ptr(ko), _ptr(vo), wp, wn, _stream()),
+          'ctr_sort_pairs')
+    return ko, vo
+
+
+def make_opt(kind, lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    return Opt(kind=int(kind), lr=float(lr), beta1=float(beta1), beta2=float(beta2), eps=float(eps))
+
+
+def emb_sparse_apply(keys, src, n_items, *, N, E, total_rows, dz, opt, tables=None, slot0=None, slot1=None,
+                     src_scale=None):
+    dzp, dzld = _rows(dz, 'dz')
+    for t, nm in ((tables, 'tables'), (slot0, 'slot0'), (slot1, 'slot1')):
+        if t is not None and (t.numel() < total_rows * E or not t.is_contiguous()):
+            raise ValueError('%s must be contiguous [total_rows, E]' % nm)
+    if dz.shape[1] < N * E:
+        raise ValueError('dz narrower than N*E')
+    check(lib().ctr_emb_sparse_apply(_ptr(keys), _ptr(src), int(n_items), N, E, int(total_rows), dzp, dzld,
+                                     _ptr(src_scale, torch.float32), _ptr(tables, torch.float32),
+                                     _ptr(slot0, torch.float32), _ptr(slot1, torch.float32), C.byref(opt),
+                                     _stream()), 'ctr_emb_sparse_apply')
+
+
+# ------------------------------------------------------------------ dense pieces
+def gemm(A, B_, Cout, *, trans_a=False, trans_b=False, bias=None, relu=False, accumulate=False, dropout=None,
+         mask_src=None, mask_scale=1.0, ws=None):
+    """Cout[M,N] = epilogue(op(A) @ op(B_)); all three are 2-D views with contiguous last dim."""
+    M, N = Cout.shape
+    ap, lda = _rows(A, 'A')
+    bp, ldb = _rows(B_, 'B')
+    cp, ldc = _rows(Cout, 'C')
+    K = A.shape[0] if trans_a else A.shape[1]
+    am = A.shape[1] if trans_a else A.shape[0]
+    bk, bn = (B_.shape[1], B_.shape[0]) if trans_b else (B_.shape[0], B_.shape[1])
+    if am != M or bk != K or bn != N:
+        raise ValueError('gemm shape mismatch: op(A)=%dx%d op(B)=%dx%d C=%dx%d' % (am, K, bk, bn, M, N))
+    if bias is not None and bias.numel() != N:
+        raise ValueError('bias must have N elements')
+    mp, mld = (None, 0)
+    if mask_src is not None:
+        mp, mld = _rows(mask_src, 'mask_src')
+        if mask_src.shape[0] != M or mask_src.shape[1] < N:
+            raise ValueError('mask_src shape mismatch')
+    epi = Epilogue(bias=None if bias is None else bias.data_ptr(), relu=int(relu), accumulate=int(accumulate),
+                   dropout=C.pointer(dropout) if dropout is not None else None,
+                   mask_src=None if mask_src is None else mask_src.data_ptr(), mask_ld=mld,
+                   mask_scale=float(mask_scale))
+    need = lib().ctr_gemm_f32_workspace_bytes(M, N, K)
+    wp, wn = (None, 0)
+    if need:
+        wp, wn = ws.get(need)
+    check(lib().ctr_gemm_f32(int(trans_a), int(trans_b), M, N, K, ap, lda, bp, ldb, cp, ldc, C.byref(epi), wp, wn,
+                             _stream()), 'ctr_gemm_f32')
+
+
+def colsum(X, out, *, w=None, w_group=1, accumulate=False, ws):
+    B, K = X.shape
+    xp, ld = _rows(X, 'X')
+    wp_, wld = (None, 0) if w is None else _rows(w, 'w')
+    if out.numel() < K:
+        raise ValueError('colsum output too small')
+    if w is not None and (w.shape[0] != B or w.shape[1] * w_group < K):
+        raise ValueError('colsum weight shape mismatch')
+    wsp, wsn = ws.get(lib().ctr_colsum_workspace_bytes(B, K))
+    check(lib().ctr_colsum(xp, ld, wp_, wld, int(w_group), B, K, _ptr(out, torch.float32), int(accumulate), wsp, wsn,
+                           _stream()), 'ctr_colsum')
+
+
+def rowdot_fwd(X, w, bias, out):
+    B, K = X.shape
+    xp, ld = _rows(X, 'X')
+    if w.numel() != K or out.numel() < B:
+        raise ValueError('rowdot shape mismatch')
+    check(lib().ctr_rowdot_fwd(xp, ld, _ptr(w, torch.float32), _ptr(bias, torch.float32), B, K,
+                               _ptr(out, torch.float32), _stream()), 'ctr_rowdot_fwd')
+
+
+def rowdot_bwd_x(g, w, dX, accumulate=False):
+    B, K = dX.shape
+    dp, ld = _rows(dX, 'dX')
+    if w.numel() != K or g.numel() < B:
+        raise ValueError('rowdot_bwd shape mismatch')
+    check(lib().ctr_rowdot_bwd_x(_ptr(g, torch.float32), _ptr(w, torch.float32), B, K, dp, ld, int(accumulate),
+                                 _stream()), 'ctr_rowdot_bwd_x')
+
+
+def loss_head(kind, x, y, *, y_out=None, loss_out=None, dx=None):
+    B = x.numel()
+    if y.numel() != B:
+        raise ValueError('loss_head: label count mismatch')
+    check(lib().ctr_loss_head(int(kind), _ptr(x, torch.float32), _ptr(y, torch.float32), B,
+                              _ptr(y_out, torch.float32), _ptr(loss_out, torch.float32), _ptr(dx, torch.float32),
+                              _stream()), 'ctr_loss_head')
+
+
+def dense_update(param, grad, opt, slot0=None, slot1=None):
+    n = param.numel()
+    if grad.numel() != n or (slot0 is not None and slot0.numel() != n) or (slot1 is not None and slot1.numel() != n):
+        raise ValueError('dense_update size mismatch')
+    check(lib().ctr_dense_update(_ptr(param, torch.float32), _ptr(grad, torch.float32), _ptr(slot0, torch.float32),
+                                 _ptr(slot1, torch.float32), n, C.byref(opt), _stream()), 'ctr_dense_update')
+
+
+def cross_fwd(x0, w, b, xL, aux, ws):
+    B, D = xL.shape
+    L = w.shape[0]
+    xp, xld = _rows(x0, 'x0')
+    op, old = _rows(xL, 'xL')
+    if x0.shape[0] != B or x0.shape[1] < D or tuple(w.shape) != (L, D) or tuple(b.shape) != (L, D):
+        raise ValueError('cross_fwd shape mismatch')
+    if aux is not None and aux.numel() < B * 2 * L:
+        raise ValueError('cross aux too small')
+    wp, wn = ws.get(lib().ctr_cross_fwd_workspace_bytes(D, L))
+    check(lib().ctr_cross_fwd(xp, xld, _ptr(w, torch.float32), _ptr(b, torch.float32), B, D, L, op, old,
+                              _ptr(aux, torch.float32), wp, wn, _stream()), 'ctr_cross_fwd')
+
+
+def cross_bwd(x0, w, b, aux, g, dx0, dw, db, ws, accumulate=False):
+    B, D = g.shape
+    L = w.shape[0]
+    xp, xld = _rows(x0, 'x0')
+    gp, gld = _rows(g, 'g')
+    dp, dld = _rows(dx0, 'dx0')
+    if dx0.shape[0] != B or dx0.shape[1] < D or dw.numel() != L * D or db.numel() != L * D:
+        raise ValueError('cross_bwd shape mismatch')
+    wp, wn = ws.get(lib().ctr_cross_bwd_workspace_bytes(B, D, L))
+    check(lib().ctr_cross_bwd(xp, xld, _ptr(w, torch.float32), _ptr(b, torch.float32), _ptr(aux, torch.float32),
+                              gp, gld, B, D, L, dp, dld, int(accumulate), _ptr(dw, torch.float32),
+                              _ptr(db, torch.float32), wp, wn, _stream()), 'ctr_cross_bwd')
+
+
+def copy2d(src, dst, accumulate=False):
+    rows, cols = src.shape
+    sp, sld = _rows(src, 'src')
+    dp, dld = _rows(dst, 'dst')
+    if dst.shape[0] != rows or dst.shape[1] < cols:
+        raise ValueError('copy2d shape mismatch')
+    check(lib().ctr_copy2d(sp, sld, dp, dld, rows, cols, int(accumulate), _stream()), 'ctr_copy2d')
+
+
+def dropout_apply(x, drop):
+    if drop is None:
+        return
+    rows, cols = x.shape
+    xp, ld = _rows(x, 'x')
+    check(lib().ctr_dropout_apply(xp, ld, rows, cols, C.byref(drop), _stream()), 'ctr_dropout_apply')

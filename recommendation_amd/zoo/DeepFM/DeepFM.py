@@ -1,0 +1,73 @@
+"""DeepFM on the HIP hot path; same class surface as the reference's DeepFM/DeepFM.py:5-131."""
+import torch
+
+from recommendation_amd import ops
+from recommendation_amd.engine import Tower, round_up
+from recommendation_amd.model_base import CTRModel
+from recommendation_amd._lib import LOSS_SIGMOID_LOGLOSS
+
+
+class DeepFM(CTRModel):
+    MODEL = 'DeepFM'
+    OPTIMIZER = 'adam'                      # DeepFM/DeepFM.py:32
+    LOSS_KIND = LOSS_SIGMOID_LOGLOSS        # DeepFM/DeepFM.py:88-91
+
+    def __init__(self, args, cate_num, cont_num, cate_list):
+        super().__init__(args, cate_num, cont_num, cate_list)
+        self.deep_layers = [int(v) for v in args.deep_layers]
+        self.dropout_fm = float(args.dropout_fm)
+        self.dropout_deep = float(args.dropout_deep)
+
+    def _dense_shapes(self, sh):
+        n = len(self.deep_layers)
+        self.total_size = self.N * self.embed_size + self.cont_num        # DeepFM/DeepFM.py:18
+        d = self.total_size
+        for i, L in enumerate(self.deep_layers):
+            sh['deep_part/deep_w_%d' % i] = (d, L)
+            sh['deep_part/deep_b_%d' % i] = (1, L)
+            d = L
+        self.concat_width = self.N + self.embed_size + self.deep_layers[-1]
+        sh['output_unit/output_w_%d' % (n - 1)] = (self.concat_width, 1)   # DeepFM/DeepFM.py:84 (leaked loop index)
+        sh['output_unit/output_b_%d' % (n - 1)] = (1,)
+
+    def _post_init(self):
+        self.tower = Tower(self.dense, 'deep_part/deep', len(self.deep_layers))
+
+    def _alloc(self, B, bufs, dev):
+        N, E, Ls = self.N, self.embed_size, self.deep_layers
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        bufs['x0'] = z(B, round_up(self.total_size, 4))
+        bufs['dx0'] = z(B, round_up(self.total_size, 4))
+        bufs['concat'] = z(B, self.concat_width)
+        bufs['dconcat'] = z(B, self.concat_width)
+        bufs['s'] = z(B, E)
+        bufs['acts'] = [z(B, L) for L in Ls[:-1]] + [bufs['concat'][:, N + E:]]
+        bufs['gbufs'] = [z(B, L) for L in Ls[:-1]]
+
+    def _forward(self, idx, xc, bufs, train):
+        N, E, n = self.N, self.embed_size, len(self.deep_layers)
+        concat = bufs['concat']
+        self.front.forward(idx, xc, z_out=bufs['x0'], cont_tail=True, first_out=concat[:, :N], s_out=bufs['s'],
+                           second_out=concat[:, N:N + E], drop_first=self._drop(self.dropout_fm, 1, train),
+                           drop_second=self._drop(self.dropout_fm, 2, train))
+        drops = [self._drop(self.dropout_deep, 10 + i, train) for i in range(n)]
+        self.tower.forward(bufs['x0'], bufs['acts'], drops, self.session.ws)
+        ops.rowdot_fwd(concat, self.dense.p('output_unit/output_w_%d' % (n - 1)).reshape(-1),
+                       self.dense.p('output_unit/output_b_%d' % (n - 1)), bufs['logit'])
+
+    def _backward(self, idx, xc, bufs):
+        N, E, n = self.N, self.embed_size, len(self.deep_layers)
+        B = idx.shape[0]
+        ws = self.session.ws
+        concat, dconcat, dl = bufs['concat'], bufs['dconcat'], bufs['dlogit']
+        wn, bn = 'output_unit/output_w_%d' % (n - 1), 'output_unit/output_b_%d' % (n - 1)
+        ops.rowdot_bwd_x(dl, self.dense.p(wn).reshape(-1), dconcat)
+        ops.colsum(concat, self.dense.g(wn).reshape(-1), w=dl.view(B, 1), w_group=self.concat_width, ws=ws)
+        ops.colsum(dl.view(B, 1), self.dense.g(bn), ws=ws)
+        self.tower.backward(bufs['x0'], bufs['acts'], dconcat[:, N + E:], bufs['gbufs'],
+                            [self.dropout_deep] * n, bufs['dx0'], ws)
+        ops.embed_bwd_dz(bufs['dx0'], B=B, N=N, E=E, gz=bufs['dx0'], g_first=dconcat[:, :N],
+                         g_second=dconcat[:, N:N + E], s=bufs['s'], z=bufs['x0'],
+                         drop_first=self._drop(self.dropout_fm, 1, True),
+                         drop_second=self._drop(self.dropout_fm, 2, True))
+        self._tables_backward(idx, bufs['dx0'], bufs)

@@ -1,0 +1,95 @@
+"""DeepFM on the HIP path vs the CPU oracle: forward, loss, gradients and optimizer steps.
+Tolerance: fp32 forward/gradients within 1e-5 relative (max-norm), the bar BASELINE.json states."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctr_oracle as O
+from tests.helpers import no_dropout, rel_err, tiny_batch, tiny_cfg
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _build(sess, model_name, cfg, P):
+    import recommendation_amd as ra
+    ra.enable_zoo_imports()
+    import importlib
+    mod = importlib.import_module('%s.%s' % (model_name, model_name))
+    m = getattr(mod, model_name)(cfg, cfg.cate_num, cfg.cont_num, cfg.cate_list)
+    m.build()
+    m.initialize(sess, params=P)
+    return m
+
+
+@pytest.mark.parametrize('mode', ['R', 'S'])
+def test_deepfm_forward_grads_steps(sess, mode):
+    cfg = no_dropout(tiny_cfg('DeepFM', mode))
+    cfg.adam_mode = 'tf1'
+    P = O.init_params('DeepFM', cfg, seed=3, std=0.3)
+    Xc, Xf, y = tiny_batch(cfg, B=8)
+    orc = O.OracleModel('DeepFM', cfg, P, dtype=torch.float64)
+    m = _build(sess, 'DeepFM', cfg, P)
+    # forward
+    p_gpu = m.predict_proba(sess, Xc, Xf)
+    p_ref = orc.forward(Xc, Xf).y_out.numpy()
+    assert rel_err(p_gpu, p_ref) < TOL
+    # loss + grads (dense vars and tables) at identical weights
+    loss_ref, g_ref, _ = orc.loss_and_grads(Xc, Xf, y)
+    loss_gpu = m.run(sess, Xc, Xf, y, True)
+    assert abs(float(loss_gpu) - float(loss_ref)) < TOL * max(1.0, abs(float(loss_ref)))
+    g_gpu = m.get_grads()
+    for k, v in g_gpu.items():
+        assert rel_err(v, g_ref[k].numpy()) < 5 * TOL, k
+    # three optimizer steps: weights track the oracle
+    orc.run(Xc, Xf, y, True)
+    for _ in range(2):
+        l_o = orc.run(Xc, Xf, y, True)
+        l_g = m.run(sess, Xc, Xf, y, True)
+        assert abs(float(l_o) - float(l_g)) < 1e-5
+    P_gpu = m.get_params()
+    for k, v in P_gpu.items():
+        assert rel_err(v, orc.P[k].numpy()) < 1e-4, k
+    # eval path: (actual, round(y_out))
+    a, pr = m.run(sess, Xc, Xf, y, False)
+    a_o, pr_o = orc.run(Xc, Xf, y, False)
+    assert np.array_equal(a, a_o) and np.array_equal(pr, pr_o)
+
+
+def test_deepfm_smode_lazy_adam_matches_dense_on_touched_rows(sess):
+    cfg = no_dropout(tiny_cfg('DeepFM', 'S'))
+    P = O.init_params('DeepFM', cfg, seed=4, std=0.3)
+    Xc, Xf, y = tiny_batch(cfg, B=8, oor=False)
+    cfg.adam_mode = 'lazy'
+    m1 = _build(sess, 'DeepFM', cfg, P)
+    cfg2 = no_dropout(tiny_cfg('DeepFM', 'S'))
+    cfg2.adam_mode = 'tf1'
+    m2 = _build(sess, 'DeepFM', cfg2, P)
+    # same batch every step => every touched row is touched at every step => lazy == dense
+    for _ in range(3):
+        m1.run(sess, Xc, Xf, y, True)
+        m2.run(sess, Xc, Xf, y, True)
+    for (k, a), b in zip(m1.get_params().items(), m2.get_params().values()):
+        assert np.array_equal(a, b), k
+
+
+def test_deepfm_dropout_masks_match_hash(sess):
+    """Training-mode dropout uses the shared counter hash: feed the oracle the same masks."""
+    cfg = tiny_cfg('DeepFM', 'S')
+    cfg.adam_mode = 'tf1'
+    P = O.init_params('DeepFM', cfg, seed=5, std=0.3)
+    Xc, Xf, y = tiny_batch(cfg, B=16, seed=2)
+    m = _build(sess, 'DeepFM', cfg, P)
+    B, N, E = 16, cfg.cate_num, cfg.embed_size
+    seed = sess.seed * 1000003 + 0
+    masks = {'fm_first': O.keep_mask(seed, 1, B * N, 1 - cfg.dropout_fm).reshape(B, N),
+             'fm_second': O.keep_mask(seed, 2, B * E, 1 - cfg.dropout_fm).reshape(B, E)}
+    for i, L in enumerate(cfg.deep_layers):
+        masks['deep_%d' % i] = O.keep_mask(seed, 10 + i, B * L, 1 - cfg.dropout_deep).reshape(B, L)
+    masks = {k: torch.as_tensor(v) for k, v in masks.items()}
+    orc = O.OracleModel('DeepFM', cfg, P, dtype=torch.float64)
+    loss_ref, g_ref, _ = orc.loss_and_grads(Xc, Xf, y, masks)
+    loss_gpu = m.run(sess, Xc, Xf, y, True)
+    assert abs(float(loss_gpu) - float(loss_ref)) < 1e-5
+    for k, v in m.get_grads().items():
+        assert rel_err(v, g_ref[k].numpy()) < 5e-5, k
