@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Headline benchmark: DeepFM training step on Criteo-Kaggle-shape synthetic data.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (embedding gather + FM + tower forward, loss, backward,
+sorted segment-reduce + sparse Adam, dense Adam) over one batch that already sits in HBM.
+Rank 0 prints ONE JSON line (see README/DESIGN for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA (exact fp32) dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=65536, help='per-GPU batch')
+    ap.add_argument('--embed', type=int, default=16)
+    ap.add_argument('--alpha', type=float, default=1.05, help='Zipf exponent of the ids (0 = uniform)')
+    ap.add_argument('--model', default='DeepFM', choices=['DeepFM', 'DCN'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timers', action='store_true')
+    return ap.parse_args()
+
+
+def build_model(args, sess, cards, rank, world):
+    import recommendation_amd as ra
+    ra.enable_zoo_imports()
+    if args.model == 'DeepFM':
+        from DeepFM import DeepFM as mod
+        margs = SimpleNamespace(embed_size=args.embed, deep_layers=[256, 128, 64, 32], regular_rate=0.1,
+                                dropout_fm=0.5, dropout_deep=0.2, learning_rate=0.001, decay_steps=10000,
+                                decay_rate=0.99, mode='S', adam_mode='lazy', init_std=0.01)
+        cls = mod.DeepFM
+    else:
+        from DCN import DCN as mod
+        margs = SimpleNamespace(embed_size=args.embed, deep_layers=[1024, 1024, 1024], cross_layer_num=6,
+                                regular_rate=0.1, dropout=0.2, learning_rate=0.001, decay_steps=10000,
+                                decay_rate=0.99, mode='S', adam_mode='lazy', init_std=0.01)
+        cls = mod.DCN
+    if world > 1:
+        margs.world_size, margs.rank = world, rank
+    m = cls(margs, len(cards), 13, cards)
+    m.build()
+    m.initialize(sess, seed=1234)
+    return m
+
+
+def cpu_baseline(args, cards):
+    """The oracle (CPU restatement of the reference graph; TensorFlow is unavailable) timed on
+    the host's cores on a bounded sample of the same workload."""
+    from oracle import ctr_oracle as O
+    from recommendation_amd.synthetic import scaled
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    div = 64
+    small = scaled(cards, div)
+    B = 4096
+    cfg = O.default_cfg('DeepFM', embed_size=args.embed, mode='S')
+    cfg.cate_num, cfg.cont_num, cfg.cate_list = len(small), 13, small
+    rng = np.random.default_rng(0)
+    P = O.init_params('DeepFM', cfg, seed=0)
+    m = O.OracleModel('DeepFM', cfg, P, dtype=torch.float32)
+    Xc = np.stack([rng.integers(0, v, B) for v in small], 1)
+    Xf = rng.standard_normal((B, 13)).astype(np.float32)
+    y = rng.integers(0, 2, B)
+    m.run(Xc, Xf, y, True)
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 50):
+        m.run(Xc, Xf, y, True)
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=B * n / dt, unit='samples/s', cores=threads, kind='port',
+                sample='CPU restatement of the reference graph (TensorFlow unavailable): DeepFM S-mode, '
+                       'torch-CPU fp32, B=%d, %d steps, table rows scaled 1/%d (sum V=%d), TF1 dense Adam'
+                       % (B, n, div, int(np.sum(small))))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
+                             '--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...'
+                             % (args.gpus, args.gpus))
+        raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
+    import recommendation_amd as ra
+    from recommendation_amd import ops
+    from recommendation_amd.synthetic import CRITEO_KAGGLE, make_batches
+
+    torch.cuda.set_device(local_rank)
+    dev = 'cuda:%d' % local_rank
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device(dev))
+    sess = ra.Session(dev, seed=11 + rank)
+    cards = CRITEO_KAGGLE
+    model = build_model(args, sess, cards, rank, world)
+    B = args.batch
+    batches = make_batches(cards, 13, B, 8, args.alpha, 20240601 + rank, dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        model.train_step(*batches[i % len(batches)])
+    timer = None
+    if not args.no_kernel_timers:
+        timer = ops.KernelTimer()
+        ops.set_timer(timer)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        model.train_step(*batches[i % len(batches)])
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.set_timer(None)
+    loss = float(model._loss_dev.item())
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    value = world * B * args.steps / dt
+    out = dict(metric='train samples/sec (node) DeepFM+DCN Criteo-shape; % HBM roofline on emb kernels',
+               value=value, unit='samples/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling='weak', vs_baseline=None,
+               dtype='f32', data='synthetic',
+               config=dict(workload='%s Criteo-Kaggle shape: 13 dense + 26 sparse fields, sum(V)=%d rows, '
+                                    'embed dim %d, per-GPU batch %d, Zipf(%.2f) ids, fwd+bwd+Adam (sparse rows: '
+                                    'row-wise Adam on touched rows), dropout at the reference rates'
+                                    % (args.model, int(np.sum(cards)), args.embed, B, args.alpha),
+                           global_batch=world * B, parallelism='dp%d' % world if world > 1 else 'single'),
+               final_loss=loss)
+    if timer is not None:
+        ks = timer.summary()
+        F, E = len(cards), args.embed
+        # algorithmic bytes per sample: ids + row read + row write (embedding gather forward)
+        emb_bytes = F * (4 + E * 4 + E * 4) * B
+        k = ks.get('embed_fwd')
+        roof_emb = None
+        if k:
+            ach = emb_bytes / (k['avg_us'] * 1e-6) / 1e9
+            roof_emb = dict(kernel='embed_fwd_kernel (gather + FM first/second order + concat)', bound='hbm',
+                            achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
+                            traffic=None, avg_us=k['avg_us'], bytes_per_launch=emb_bytes)
+        dom_name = max(ks, key=lambda n: ks[n]['total_ms'])
+        dom = ks[dom_name]
+        if dom_name.startswith('gemm_'):
+            M, N, K = [int(v) for v in dom_name.split('_')[1].split('x')]
+            ach = 2.0 * M * N * K / (dom['avg_us'] * 1e-6) / 1e12
+            roof = dict(kernel=dom_name, bound='mfma', achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=None, avg_us=dom['avg_us'])
+        elif dom_name == 'embed_fwd' and roof_emb:
+            roof = roof_emb
+        else:
+            roof = dict(kernel=dom_name, bound='hbm', achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None,
+                        traffic=None, avg_us=dom['avg_us'])
+        out['roofline'] = roof
+        out['roofline_emb'] = roof_emb
+        out['kernel_ms_per_step'] = {n: round(v['total_ms'] / args.steps, 4) for n, v in
+                                     sorted(ks.items(), key=lambda kv: -kv[1]['total_ms'])}
+    if not args.no_cpu_baseline and world == 1:
+        out['cpu_baseline'] = cpu_baseline(args, cards)
+    elif world == 1:
+        out['cpu_baseline'] = None
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

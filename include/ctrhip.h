@@ -144,12 +144,15 @@ typedef struct {
  * reproducible) of scale_j * dz[b_j*dz_ld + n_j*E : +E] with src_j = b_j*N + n_j and
  * scale_j = src_scale[src_j] (1 when src_scale == NULL), then apply `opt` to row `key`
  * of tables (slot0/slot1 = Adam m/v, slot0 = Adagrad accumulator) or, for
- * CTR_OPT_GRAD_ONLY, store g into slot0[key,:].  Keys >= total_rows are skipped. */
+ * CTR_OPT_GRAD_ONLY, store g into slot0[key,:].  Keys >= total_rows are skipped.
+ * Long runs (hot rows) are cut into 64-pair pieces summed by separate lane groups and
+ * combined in piece order, so the time does not depend on the hottest row. */
+size_t ctr_emb_sparse_apply_workspace_bytes(int64_t n_items, int E);
 int ctr_emb_sparse_apply(const uint32_t* keys_sorted, const uint32_t* src_sorted, int64_t n_items,
                          int N, int E, int64_t total_rows,
                          const float* dz, int64_t dz_ld, const float* src_scale,
                          float* tables, float* slot0, float* slot1,
-                         const ctr_opt_t* opt, void* stream);
+                         const ctr_opt_t* opt, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Dense tower pieces.
@@ -207,15 +210,17 @@ int ctr_rowdot_bwd_x(const float* g, const float* w, int B, int K,
  *   CTR_LOSS_SCE_LOGIT         y_out = sigmoid(x);  loss = sce(labels=y, logits=x)
  *   CTR_LOSS_PROB_SCE          y_out = x (already a probability); loss = sce(labels=y, logits=x)
  * loss_out[0] = mean over B (fixed-order reduction); dx[b] = d loss / d x[b].
- * y_out, dx, loss_out optional.
+ * y_out, dx, loss_out optional; y may be NULL when only y_out is wanted (inference).
  * ---------------------------------------------------------------------------------- */
 #define CTR_LOSS_SIGMOID_LOGLOSS 0
 #define CTR_LOSS_IDENTITY_LOGLOSS 1
 #define CTR_LOSS_SIGMOID_SCE_PROB 2
 #define CTR_LOSS_SCE_LOGIT 3
 #define CTR_LOSS_PROB_SCE 4
+size_t ctr_loss_head_workspace_bytes(int B);
 int ctr_loss_head(int kind, const float* x, const float* y, int B,
-                  float* y_out, float* loss_out, float* dx, void* stream);
+                  float* y_out, float* loss_out, float* dx,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Dense optimizers over one flat parameter buffer (multi-tensor in one launch).

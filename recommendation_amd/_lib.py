@@ -53,14 +53,16 @@ SIGNATURES = {
     'ctr_emb_sort_workspace_bytes': (sz, [i64]),
     'ctr_emb_sort': (i, [vp, vp, i, i, i, i64, i, vp, vp, vp, sz, vp]),
     'ctr_sort_pairs': (i, [vp, vp, i64, i, vp, vp, vp, sz, vp]),
-    'ctr_emb_sparse_apply': (i, [vp, vp, i64, i, i, i64, vp, i64, vp, vp, vp, vp, C.POINTER(Opt), vp]),
+    'ctr_emb_sparse_apply_workspace_bytes': (sz, [i64, i]),
+    'ctr_emb_sparse_apply': (i, [vp, vp, i64, i, i, i64, vp, i64, vp, vp, vp, vp, C.POINTER(Opt), vp, sz, vp]),
     'ctr_gemm_f32_workspace_bytes': (sz, [i, i, i]),
     'ctr_gemm_f32': (i, [i, i, i, i, i, vp, i64, vp, i64, vp, i64, C.POINTER(Epilogue), vp, sz, vp]),
     'ctr_colsum_workspace_bytes': (sz, [i, i]),
     'ctr_colsum': (i, [vp, i64, vp, i64, i, i, i, vp, i, vp, sz, vp]),
     'ctr_rowdot_fwd': (i, [vp, i64, vp, vp, i, i, vp, vp]),
     'ctr_rowdot_bwd_x': (i, [vp, vp, i, i, vp, i64, i, vp]),
-    'ctr_loss_head': (i, [i, vp, vp, i, vp, vp, vp, vp]),
+    'ctr_loss_head_workspace_bytes': (sz, [i]),
+    'ctr_loss_head': (i, [i, vp, vp, i, vp, vp, vp, vp, sz, vp]),
     'ctr_dense_update': (i, [vp, vp, vp, vp, i64, C.POINTER(Opt), vp]),
     'ctr_cross_fwd_workspace_bytes': (sz, [i, i]),
     'ctr_cross_fwd': (i, [vp, i64, vp, vp, i, i, i, vp, i64, vp, vp, sz, vp]),

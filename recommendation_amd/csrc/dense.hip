@@ -5,7 +5,7 @@
 
 namespace ctr {
 
-constexpr int CS_ROWS = 256;  // rows per partial chunk
+constexpr int CS_ROWS = 512;  // rows per partial chunk
 
 // grid (ceil(K/64), nchunks); block (64, 4)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int64_t ld,
@@ -31,13 +31,21 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   if (ty == 0 && j < K) part[(int64_t)blockIdx.y * K + j] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
+// block (64, 4): row phase ty sums chunks ty, ty+4, ...; the four phases are added in a fixed order
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nchunks, int K,
                                                           float* __restrict__ out, int accumulate) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= K) return;
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + tx;
   float acc = 0.f;
-  for (int c = 0; c < nchunks; ++c) acc += part[(int64_t)c * K + j];
-  out[j] = accumulate ? out[j] + acc : acc;
+  if (j < K)
+    for (int c = ty; c < nchunks; c += 4) acc += part[(int64_t)c * K + j];
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && j < K) {
+    const float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    out[j] = accumulate ? out[j] + v : v;
+  }
 }
 
 __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict__ X, int64_t ld,
@@ -70,19 +78,20 @@ __global__ __launch_bounds__(256) void rowdot_bwd_x_kernel(const float* __restri
 __device__ static inline float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ static inline float sce_(float x, float z) { return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x))); }
 
-// One 1024-thread block; fixed-order tree reduction of the per-thread partial sums.
-__global__ __launch_bounds__(1024) void loss_head_kernel(int kind, const float* __restrict__ x,
-                                                        const float* __restrict__ y, int B,
-                                                        float* __restrict__ y_out,
-                                                        float* __restrict__ loss_out,
-                                                        float* __restrict__ dx) {
-  __shared__ float red[1024];
+// Pass 1: 256 samples per block -> y_out, dx and one partial loss sum per block.
+// Pass 2: one block adds the partials in a fixed order.
+__global__ __launch_bounds__(256) void loss_head_kernel(int kind, const float* __restrict__ x,
+                                                       const float* __restrict__ y, int B,
+                                                       float* __restrict__ y_out, float* __restrict__ dx,
+                                                       float* __restrict__ part) {
+  __shared__ float red[256];
   const float invB = 1.f / (float)B;
   const float eps = 1e-7f;
-  float acc = 0.f;
-  for (int b = threadIdx.x; b < B; b += 1024) {
-    const float xv = x[b], yv = y[b];
-    float p, l, d;
+  float l = 0.f;
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b < B) {
+    const float xv = x[b], yv = y ? y[b] : 0.f;
+    float p, d;
     if (kind == CTR_LOSS_SIGMOID_LOGLOSS || kind == CTR_LOSS_IDENTITY_LOGLOSS) {
       p = kind == CTR_LOSS_SIGMOID_LOGLOSS ? sigmoidf_(xv) : xv;
       l = -yv * logf(p + eps) - (1.f - yv) * logf(1.f - p + eps);
@@ -103,15 +112,29 @@ __global__ __launch_bounds__(1024) void loss_head_kernel(int kind, const float* 
     }
     if (y_out) y_out[b] = p;
     if (dx) dx[b] = d * invB;
-    acc += l;
   }
-  red[threadIdx.x] = acc;
+  if (!part) return;
+  red[threadIdx.x] = l;
   __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
+  for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0 && loss_out) loss_out[0] = red[0] * invB;
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict__ part, int n, int B,
+                                                        float* __restrict__ loss_out) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_out[0] = red[0] / (float)B;
 }
 
 __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ src, int64_t src_ld,
@@ -161,7 +184,7 @@ static unsigned grid_for(int64_t total) {
 static int cs_chunks(int B) {
   int64_t n = cdiv(B, CS_ROWS);
   if (n < 1) n = 1;
-  if (n > 512) n = 512;
+  if (n > 128) n = 128;
   return (int)n;
 }
 
@@ -190,7 +213,7 @@ extern "C" int ctr_colsum(const float* X, int64_t ld, const float* w, int64_t w_
   float* part = (float*)workspace;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(K, 64), nchunks), dim3(256), 0, st, X, ld, w,
                      w_ld, w_group, B, K, rows_per_chunk, part);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(K, 256)), dim3(256), 0, st, part, nchunks, K,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(K, 64)), dim3(256), 0, st, part, nchunks, K,
                      out, accumulate);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
@@ -218,12 +241,25 @@ extern "C" int ctr_rowdot_bwd_x(const float* g, const float* w, int B, int K, fl
   return CTR_OK;
 }
 
+extern "C" size_t ctr_loss_head_workspace_bytes(int B) { return (size_t)cdiv(B > 0 ? B : 1, 256) * sizeof(float); }
+
 extern "C" int ctr_loss_head(int kind, const float* x, const float* y, int B, float* y_out, float* loss_out,
-                             float* dx, void* stream) {
+                             float* dx, void* workspace, size_t workspace_bytes, void* stream) {
   CTR_REQUIRE(kind >= 0 && kind <= CTR_LOSS_PROB_SCE, "ctr_loss_head: unknown kind %d", kind);
-  CTR_REQUIRE(B > 0 && x && y, "ctr_loss_head: bad argument");
-  hipLaunchKernelGGL(loss_head_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, kind, x, y, B, y_out,
-                     loss_out, dx);
+  CTR_REQUIRE(B > 0 && x, "ctr_loss_head: bad argument");
+  CTR_REQUIRE(y || (!loss_out && !dx), "ctr_loss_head: labels are required for loss / gradient");
+  const int nb = (int)cdiv(B, 256);
+  float* part = nullptr;
+  if (loss_out) {
+    if (!workspace || workspace_bytes < ctr_loss_head_workspace_bytes(B)) {
+      set_error("ctr_loss_head: workspace %zu < %zu", workspace_bytes, ctr_loss_head_workspace_bytes(B));
+      return CTR_EWORKSPACE;
+    }
+    part = (float*)workspace;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(loss_head_kernel, dim3(nb), dim3(256), 0, st, kind, x, y, B, y_out, dx, part);
+  if (loss_out) hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, part, nb, B, loss_out);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }

@@ -51,37 +51,60 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(
   counts[(int64_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
 }
 
-// Exclusive scan of `len` uint32 counters by one 1024-thread block.
-__global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t* __restrict__ counts, int64_t len) {
-  __shared__ uint32_t part[1024];
-  const int t = threadIdx.x;
-  const int64_t per = (len + 1023) / 1024;
-  const int64_t lo = (int64_t)t * per;
-  const int64_t hi = lo + per < len ? lo + per : len;
-  uint32_t sum = 0;
-  for (int64_t i = lo; i < hi; ++i) sum += counts[i];
-  part[t] = sum;
-  __syncthreads();
-  // Hillis-Steele inclusive scan over the 1024 partials
-  for (int o = 1; o < 1024; o <<= 1) {
-    uint32_t v = t >= o ? part[t - o] : 0u;
+// Block d turns row d of counts[digit][tile] into its exclusive prefix over the tiles and
+// stores the row total in totals[d]; the scatter kernel adds the prefix over the digits itself.
+__global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ counts, int nblocks,
+                                                        uint32_t* __restrict__ totals) {
+  __shared__ uint32_t wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* row = counts + (int64_t)blockIdx.x * nblocks;
+  uint32_t carry = 0;
+  for (int base = 0; base < nblocks; base += 256) {
+    const int i = base + threadIdx.x;
+    const uint32_t c = i < nblocks ? row[i] : 0u;
+    uint32_t incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    part[t] += v;
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) woff += wsum[w];
+      tot += wsum[w];
+    }
+    if (i < nblocks) row[i] = carry + woff + incl - c;
+    carry += tot;
     __syncthreads();
   }
-  uint32_t run = part[t] - sum;  // exclusive prefix of this thread's range
-  for (int64_t i = lo; i < hi; ++i) {
-    const uint32_t c = counts[i];
-    counts[i] = run;
-    run += c;
-  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t n, int shift,
-    int nblocks, const uint32_t* __restrict__ scanned, uint32_t* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out) {
+    int nblocks, const uint32_t* __restrict__ scanned, const uint32_t* __restrict__ totals,
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
   __shared__ uint32_t whist[SORT_WAVES][256];
+  __shared__ uint32_t dbase[256];
+  {  // exclusive prefix of the digit totals (256 values, one per thread)
+    const uint32_t tv = totals[threadIdx.x];
+    uint32_t incl = tv;
+    const int ln = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = __shfl_up(incl, o);
+      if (ln >= o) incl += v;
+    }
+    dbase[threadIdx.x] = incl;          // inclusive within the wave for now
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += dbase[w * 64 + 63];
+    __syncthreads();
+    dbase[threadIdx.x] = woff + incl - tv;
+  }
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < SORT_WAVES * 256; i += SORT_THREADS) (&whist[0][0])[i] = 0;
@@ -118,7 +141,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
   __syncthreads();
   {  // per digit: exclusive prefix over the waves + this tile's global base
     const int d = threadIdx.x;
-    uint32_t run = scanned[(int64_t)d * nblocks + blockIdx.x];
+    uint32_t run = dbase[d] + scanned[(int64_t)d * nblocks + blockIdx.x];
 #pragma unroll
     for (int w = 0; w < SORT_WAVES; ++w) {
       const uint32_t c = whist[w][d];
@@ -146,13 +169,13 @@ static int bits_for(uint64_t max_value) {
 }
 
 struct SortWs {
-  uint32_t *keys_tmp, *vals_tmp, *counts;
+  uint32_t *keys_tmp, *vals_tmp, *counts, *totals;
   int nblocks;
 };
 
 static size_t sort_ws_bytes(int64_t n) {
   const int64_t nblocks = cdiv(n > 0 ? n : 1, SORT_TILE);
-  return align_up((size_t)n * 4, 256) * 2 + align_up((size_t)nblocks * 256 * 4, 256);
+  return align_up((size_t)n * 4, 256) * 2 + align_up((size_t)nblocks * 256 * 4, 256) + 1024;
 }
 
 static SortWs carve(void* ws, int64_t n) {
@@ -161,7 +184,8 @@ static SortWs carve(void* ws, int64_t n) {
   w.nblocks = (int)cdiv(n > 0 ? n : 1, SORT_TILE);
   w.keys_tmp = (uint32_t*)p; p += align_up((size_t)n * 4, 256);
   w.vals_tmp = (uint32_t*)p; p += align_up((size_t)n * 4, 256);
-  w.counts = (uint32_t*)p;
+  w.counts = (uint32_t*)p; p += align_up((size_t)w.nblocks * 256 * 4, 256);
+  w.totals = (uint32_t*)p;
   return w;
 }
 
@@ -173,9 +197,9 @@ static int run_passes(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, in
     const int shift = 8 * p;
     hipLaunchKernelGGL(radix_hist_kernel, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, n, shift,
                        w.nblocks, w.counts);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, (int64_t)w.nblocks * 256);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(256), 0, st, w.counts, w.nblocks, w.totals);
     hipLaunchKernelGGL(radix_scatter_kernel, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, va, n,
-                       shift, w.nblocks, w.counts, kb, vb);
+                       shift, w.nblocks, w.counts, w.totals, kb, vb);
     uint32_t* t;
     t = ka; ka = kb; kb = t;
     t = va; va = vb; vb = t;

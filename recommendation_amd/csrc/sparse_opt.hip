@@ -36,19 +36,34 @@ __device__ static inline void opt_apply4(const Opt& o, float4 g, float4* w, floa
   }
 }
 
+// Runs of equal keys are cut at every multiple of SEG positions of the sorted array, so no
+// lane group ever walks more than SEG pairs (a Zipf-hot row can own tens of thousands).
+//   pass 1: one lane group per piece start (key change or position % SEG == 0) sums its piece.
+//           A run that fits inside one SEG block is finished here.  Otherwise the piece that
+//           holds the run's head goes to part_head[block] (+ head_key[block] = key) and every
+//           later piece, which starts exactly at a block boundary, goes to part[block].
+//   pass 2: one wave per block with a recorded head adds part_head + the continuation pieces in
+//           block order (R pieces per step in fixed lane slots, then a fixed-order shuffle tree)
+//           and applies the optimizer.  No atomics: bitwise reproducible.
+constexpr int SEG = 64;
+constexpr uint32_t NO_KEY = 0xFFFFFFFFu;
+
 template <int G>
 __global__ __launch_bounds__(256) void sparse_apply_kernel(
     const uint32_t* __restrict__ keys, const uint32_t* __restrict__ src, int64_t n_items, int N, int E,
     int64_t total_rows, const float* __restrict__ dz, int64_t dz_ld, const float* __restrict__ src_scale,
-    float* __restrict__ tables, float* __restrict__ slot0, float* __restrict__ slot1, Opt opt) {
+    float* __restrict__ tables, float* __restrict__ slot0, float* __restrict__ slot1, Opt opt,
+    float* __restrict__ part, float* __restrict__ part_head, uint32_t* __restrict__ head_key) {
   const int64_t item = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
   const int g = threadIdx.x % G;
   if (item >= n_items) return;
   const uint32_t key = keys[item];
   if ((int64_t)key >= total_rows) return;
-  if (item > 0 && keys[item - 1] == key) return;  // not the head of its run
+  const bool run_head = item == 0 || keys[item - 1] != key;
+  if (!run_head && (item % SEG) != 0) return;  // not the start of a piece
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int64_t j = item;
+  bool more;
   do {
     const uint32_t sj = src[j];
     const int64_t b = sj / (uint32_t)N;
@@ -57,11 +72,59 @@ __global__ __launch_bounds__(256) void sparse_apply_kernel(
     const float sc = src_scale ? src_scale[sj] : 1.f;
     acc.x += v.x * sc; acc.y += v.y * sc; acc.z += v.z * sc; acc.w += v.w * sc;
     ++j;
-  } while (j < n_items && keys[j] == key);
-  const int64_t off = (int64_t)key * E + g * 4;
-  opt_apply4(opt, acc, reinterpret_cast<float4*>(tables + off),
-             slot0 ? reinterpret_cast<float4*>(slot0 + off) : nullptr,
-             slot1 ? reinterpret_cast<float4*>(slot1 + off) : nullptr);
+    more = j < n_items && keys[j] == key;
+  } while (more && (j % SEG) != 0);
+  const int64_t blk = item / SEG;
+  if (run_head && !more) {
+    const int64_t off = (int64_t)key * E + g * 4;
+    opt_apply4(opt, acc, reinterpret_cast<float4*>(tables + off),
+               slot0 ? reinterpret_cast<float4*>(slot0 + off) : nullptr,
+               slot1 ? reinterpret_cast<float4*>(slot1 + off) : nullptr);
+  } else if (run_head) {
+    *reinterpret_cast<float4*>(part_head + blk * E + g * 4) = acc;
+    if (g == 0) head_key[blk] = key;
+  } else {
+    *reinterpret_cast<float4*>(part + blk * E + g * 4) = acc;
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void sparse_apply_tail_kernel(
+    const uint32_t* __restrict__ keys, int64_t n_items, int64_t n_blocks, int E,
+    float* __restrict__ tables, float* __restrict__ slot0, float* __restrict__ slot1, Opt opt,
+    const float* __restrict__ part, const float* __restrict__ part_head,
+    const uint32_t* __restrict__ head_key) {
+  constexpr int R = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blk >= n_blocks) return;
+  const uint32_t key = head_key[blk];
+  if (key == NO_KEY) return;
+  const int g = lane % G, r = lane / G;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r == 0) acc = *reinterpret_cast<const float4*>(part_head + blk * E + g * 4);
+  // continuation pieces sit in blocks blk+1, blk+2, ... while the block's first key is `key`
+  for (int64_t k0 = blk + 1; k0 < n_blocks; k0 += R) {
+    const int64_t k = k0 + r;
+    const bool ok = k < n_blocks && keys[k * SEG] == key;
+    if (ok) {
+      const float4 v = *reinterpret_cast<const float4*>(part + k * E + g * 4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    // the run ends inside this step as soon as one slot misses (wave-uniform exit)
+    if (__ballot(ok) != __ballot(1)) break;
+  }
+#pragma unroll
+  for (int o = G; o < 64; o <<= 1) {
+    acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o);
+    acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
+  }
+  if (r == 0) {
+    const int64_t off = (int64_t)key * E + g * 4;
+    opt_apply4(opt, acc, reinterpret_cast<float4*>(tables + off),
+               slot0 ? reinterpret_cast<float4*>(slot0 + off) : nullptr,
+               slot1 ? reinterpret_cast<float4*>(slot1 + off) : nullptr);
+  }
 }
 
 __global__ __launch_bounds__(256) void dense_update_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -95,10 +158,20 @@ static Opt make_opt(const ctr_opt_t* o) {
 
 using namespace ctr;
 
+static size_t apply_ws_bytes(int64_t n_items, int E) {
+  const int64_t nb = cdiv(n_items > 0 ? n_items : 1, SEG);
+  return 2 * align_up((size_t)nb * E * sizeof(float), 256) + align_up((size_t)nb * sizeof(uint32_t), 256);
+}
+
+extern "C" size_t ctr_emb_sparse_apply_workspace_bytes(int64_t n_items, int E) {
+  return apply_ws_bytes(n_items, E);
+}
+
 extern "C" int ctr_emb_sparse_apply(const uint32_t* keys_sorted, const uint32_t* src_sorted,
                                     int64_t n_items, int N, int E, int64_t total_rows, const float* dz,
                                     int64_t dz_ld, const float* src_scale, float* tables, float* slot0,
-                                    float* slot1, const ctr_opt_t* opt, void* stream) {
+                                    float* slot1, const ctr_opt_t* opt, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
   CTR_REQUIRE(opt, "ctr_emb_sparse_apply: opt is null");
   CTR_REQUIRE(n_items >= 0 && N > 0, "ctr_emb_sparse_apply: bad size");
   CTR_REQUIRE(E >= 4 && E <= 256 && (E & (E - 1)) == 0, "ctr_emb_sparse_apply: E=%d must be a power of two in [4,256]", E);
@@ -112,15 +185,29 @@ extern "C" int ctr_emb_sparse_apply(const uint32_t* keys_sorted, const uint32_t*
     case CTR_OPT_SGD: CTR_REQUIRE(tables, "ctr_emb_sparse_apply: SGD needs tables"); break;
     default: CTR_REQUIRE(false, "ctr_emb_sparse_apply: unknown optimizer kind %d", opt->kind);
   }
+  if (!workspace || workspace_bytes < apply_ws_bytes(n_items, E)) {
+    set_error("ctr_emb_sparse_apply: workspace %zu < %zu", workspace_bytes, apply_ws_bytes(n_items, E));
+    return CTR_EWORKSPACE;
+  }
   const Opt o = make_opt(opt);
   hipStream_t st = (hipStream_t)stream;
   const int G = E / 4;
+  const int64_t nb = cdiv(n_items, SEG);
+  char* wsp = (char*)workspace;
+  float* part = (float*)wsp; wsp += align_up((size_t)nb * E * sizeof(float), 256);
+  float* part_head = (float*)wsp; wsp += align_up((size_t)nb * E * sizeof(float), 256);
+  uint32_t* head_key = (uint32_t*)wsp;
+  hipError_t me = hipMemsetAsync(head_key, 0xFF, (size_t)nb * sizeof(uint32_t), st);
+  if (me != hipSuccess) { set_error("ctr_emb_sparse_apply: memset failed: %s", hipGetErrorString(me)); return (int)me; }
   const dim3 grid((unsigned)cdiv(n_items, 256 / G)), block(256);
+  const dim3 grid2((unsigned)cdiv(nb, 4));
   // GRAD_ONLY writes through slot0 only; give the kernel a non-null table pointer it never uses.
   float* tab = tables ? tables : slot0;
 #define LAUNCH(GG)                                                                                   \
   hipLaunchKernelGGL(sparse_apply_kernel<GG>, grid, block, 0, st, keys_sorted, src_sorted, n_items, N, \
-                     E, total_rows, dz, dz_ld, src_scale, tab, slot0, slot1, o)
+                     E, total_rows, dz, dz_ld, src_scale, tab, slot0, slot1, o, part, part_head, head_key); \
+  hipLaunchKernelGGL(sparse_apply_tail_kernel<GG>, grid2, block, 0, st, keys_sorted, n_items, nb, E, tab, \
+                     slot0, slot1, o, part, part_head, head_key)
   switch (G) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;

@@ -156,11 +156,11 @@ class EmbedFront:
         if opt.kind == OPT_ADAM and not lazy:
             t.grad.zero_()
             ops.emb_sparse_apply(keys, src, B * F, N=self.N, E=self.E, total_rows=t.total_rows, dz=dz,
-                                 opt=ops.make_opt(OPT_GRAD_ONLY), slot0=t.grad)
+                                 opt=ops.make_opt(OPT_GRAD_ONLY), slot0=t.grad, ws=ws)
             ops.dense_update(t.weight, t.grad, opt, t.slot0, t.slot1)
         else:
             ops.emb_sparse_apply(keys, src, B * F, N=self.N, E=self.E, total_rows=t.total_rows, dz=dz,
-                                 opt=opt, tables=t.weight, slot0=t.slot0, slot1=t.slot1)
+                                 opt=opt, tables=t.weight, slot0=t.slot0, slot1=t.slot1, ws=ws)
 
     def backward_cont_w(self, dz, x_cont, g_cont_w, ws):
         """d cont_w[c,:] = sum_b dz[b, Ncat + c, :] * x_cont[b,c]."""

@@ -283,9 +283,9 @@ class CTRModel:
     def _loss(self, bufs, yy, train):
         if train:
             ops.loss_head(self.LOSS_KIND, bufs['logit'], yy, y_out=bufs['y_out'], loss_out=self._loss_dev,
-                          dx=bufs['dlogit'])
+                          dx=bufs['dlogit'], ws=self.session.ws)
         else:
-            ops.loss_head(self.LOSS_KIND, bufs['logit'], bufs['logit'], y_out=bufs['y_out'])
+            ops.loss_head(self.LOSS_KIND, bufs['logit'], None, y_out=bufs['y_out'])
 
     def _forward(self, idx, xc, bufs, train):
         raise NotImplementedError

@@ -21,6 +21,54 @@ def lib():
     return _lib.load()
 
 
+class KernelTimer:
+    """Optional HIP-event timer around every operator call (events are recorded on the stream
+    the kernels run on).  Used by bench.py to attribute the timed region to kernels."""
+
+    def __init__(self):
+        self.records = []          # (name, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b in self.records:
+            ms = a.elapsed_time(b)
+            tot, cnt = out.get(name, (0.0, 0))
+            out[name] = (tot + ms, cnt + 1)
+        return {k: dict(total_ms=v[0], calls=v[1], avg_us=1e3 * v[0] / v[1]) for k, v in out.items()}
+
+
+_TIMER = None
+
+
+def set_timer(timer):
+    global _TIMER
+    _TIMER = timer
+
+
+def _timed(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrap(*a, **k):
+        if _TIMER is None:
+            return fn(*a, **k)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        name = fn.__name__
+        if name == 'gemm':                      # one bucket per GEMM shape
+            A, Cout = a[0], a[2]
+            ta = bool(k.get('trans_a', False))
+            name = 'gemm_%dx%dx%d_%s%s' % (Cout.shape[0], Cout.shape[1], A.shape[0] if ta else A.shape[1],
+                                            'T' if ta else 'N', 'T' if k.get('trans_b', False) else 'N')
+        _TIMER.records.append((name, e0, e1))
+        return r
+    return wrap
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -70,6 +118,7 @@ class Workspace:
 
 
 # ------------------------------------------------------------------ embedding front end
+@_timed
 def embed_fwd(tables, row_offset, idx, x_cont=None, cont_w=None, *, E, z_out=None, cont_tail=False,
               first_out=None, s_out=None, second_out=None, drop_first=None, drop_second=None,
               oor_count=None):
@@ -106,6 +155,7 @@ def embed_fwd(tables, row_offset, idx, x_cont=None, cont_w=None, *, E, z_out=Non
                               _ptr(oor_count, torch.int32, 'oor_count'), _stream()), 'ctr_embed_fwd')
 
 
+@_timed
 def fm_fwd(z, *, N, E, first_out=None, s_out=None, second_out=None, drop_first=None, drop_second=None):
     B = z.shape[0]
     zp, zld = _rows(z, 'z')
@@ -123,6 +173,7 @@ def fm_fwd(z, *, N, E, first_out=None, s_out=None, second_out=None, drop_first=N
                            _dp(drop_second), _stream()), 'ctr_fm_fwd')
 
 
+@_timed
 def relu_mask_apply(g, act, scale=1.0):
     rows, cols = g.shape
     gp, gld = _rows(g, 'g')
@@ -132,6 +183,7 @@ def relu_mask_apply(g, act, scale=1.0):
     check(lib().ctr_relu_mask_apply(gp, gld, ap, ald, rows, cols, float(scale), _stream()), 'ctr_relu_mask_apply')
 
 
+@_timed
 def embed_onehot_fwd(tables, row_offset, idx, x_cont, *, E, z_out, cont_tail=False, pos_out=None):
     B, F = idx.shape
     C_ = 0 if x_cont is None else x_cont.shape[1]
@@ -145,6 +197,7 @@ def embed_onehot_fwd(tables, row_offset, idx, x_cont, *, E, z_out, cont_tail=Fal
                                      int(bool(cont_tail)), _ptr(pos_out), _stream()), 'ctr_embed_onehot_fwd')
 
 
+@_timed
 def embed_bwd_dz(dz, *, B, N, E, gz=None, g_first=None, g_second=None, s=None, z=None,
                  drop_first=None, drop_second=None):
     dzp, dzld = _rows(dz, 'dz')
@@ -161,6 +214,7 @@ def embed_bwd_dz(dz, *, B, N, E, gz=None, g_first=None, g_second=None, s=None, z
 
 
 # ------------------------------------------------------------------ sort + sparse update
+@_timed
 def emb_sort(idx, row_offset, *, N, total_rows, rmode, keys_out, src_out, ws):
     B, F = idx.shape
     n = B * F
@@ -171,6 +225,7 @@ def emb_sort(idx, row_offset, *, N, total_rows, rmode, keys_out, src_out, ws):
                              int(bool(rmode)), _ptr(keys_out), _ptr(src_out), wp, wn, _stream()), 'ctr_emb_sort')
 
 
+@_timed
 def sort_pairs(keys, vals, key_bits, ws):
     n = keys.numel()
     ko = torch.empty_like(keys)
@@ -185,7 +240,8 @@ def make_opt(kind, lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
     return Opt(kind=int(kind), lr=float(lr), beta1=float(beta1), beta2=float(beta2), eps=float(eps))
 
 
-def emb_sparse_apply(keys, src, n_items, *, N, E, total_rows, dz, opt, tables=None, slot0=None, slot1=None,
+@_timed
+def emb_sparse_apply(keys, src, n_items, *, N, E, total_rows, dz, opt, ws, tables=None, slot0=None, slot1=None,
                      src_scale=None):
     dzp, dzld = _rows(dz, 'dz')
     for t, nm in ((tables, 'tables'), (slot0, 'slot0'), (slot1, 'slot1')):
@@ -193,13 +249,15 @@ def emb_sparse_apply(keys, src, n_items, *, N, E, total_rows, dz, opt, tables=No
             raise ValueError('%s must be contiguous [total_rows, E]' % nm)
     if dz.shape[1] < N * E:
         raise ValueError('dz narrower than N*E')
+    wp, wn = ws.get(lib().ctr_emb_sparse_apply_workspace_bytes(int(n_items), E))
     check(lib().ctr_emb_sparse_apply(_ptr(keys), _ptr(src), int(n_items), N, E, int(total_rows), dzp, dzld,
                                      _ptr(src_scale, torch.float32), _ptr(tables, torch.float32),
                                      _ptr(slot0, torch.float32), _ptr(slot1, torch.float32), C.byref(opt),
-                                     _stream()), 'ctr_emb_sparse_apply')
+                                     wp, wn, _stream()), 'ctr_emb_sparse_apply')
 
 
 # ------------------------------------------------------------------ dense pieces
+@_timed
 def gemm(A, B_, Cout, *, trans_a=False, trans_b=False, bias=None, relu=False, accumulate=False, dropout=None,
          mask_src=None, mask_scale=1.0, ws=None):
     """Cout[M,N] = epilogue(op(A) @ op(B_)); all three are 2-D views with contiguous last dim."""
@@ -231,6 +289,7 @@ def gemm(A, B_, Cout, *, trans_a=False, trans_b=False, bias=None, relu=False, ac
                              _stream()), 'ctr_gemm_f32')
 
 
+@_timed
 def colsum(X, out, *, w=None, w_group=1, accumulate=False, ws):
     B, K = X.shape
     xp, ld = _rows(X, 'X')
@@ -244,6 +303,7 @@ def colsum(X, out, *, w=None, w_group=1, accumulate=False, ws):
                            _stream()), 'ctr_colsum')
 
 
+@_timed
 def rowdot_fwd(X, w, bias, out):
     B, K = X.shape
     xp, ld = _rows(X, 'X')
@@ -253,6 +313,7 @@ def rowdot_fwd(X, w, bias, out):
                                _ptr(out, torch.float32), _stream()), 'ctr_rowdot_fwd')
 
 
+@_timed
 def rowdot_bwd_x(g, w, dX, accumulate=False):
     B, K = dX.shape
     dp, ld = _rows(dX, 'dX')
@@ -262,15 +323,20 @@ def rowdot_bwd_x(g, w, dX, accumulate=False):
                                  _stream()), 'ctr_rowdot_bwd_x')
 
 
-def loss_head(kind, x, y, *, y_out=None, loss_out=None, dx=None):
+@_timed
+def loss_head(kind, x, y, *, y_out=None, loss_out=None, dx=None, ws=None):
     B = x.numel()
-    if y.numel() != B:
+    if y is not None and y.numel() != B:
         raise ValueError('loss_head: label count mismatch')
+    wp, wn = (None, 0)
+    if loss_out is not None:
+        wp, wn = ws.get(lib().ctr_loss_head_workspace_bytes(B))
     check(lib().ctr_loss_head(int(kind), _ptr(x, torch.float32), _ptr(y, torch.float32), B,
                               _ptr(y_out, torch.float32), _ptr(loss_out, torch.float32), _ptr(dx, torch.float32),
-                              _stream()), 'ctr_loss_head')
+                              wp, wn, _stream()), 'ctr_loss_head')
 
 
+@_timed
 def dense_update(param, grad, opt, slot0=None, slot1=None):
     n = param.numel()
     if grad.numel() != n or (slot0 is not None and slot0.numel() != n) or (slot1 is not None and slot1.numel() != n):
@@ -279,6 +345,7 @@ def dense_update(param, grad, opt, slot0=None, slot1=None):
                                  _ptr(slot1, torch.float32), n, C.byref(opt), _stream()), 'ctr_dense_update')
 
 
+@_timed
 def cross_fwd(x0, w, b, xL, aux, ws):
     B, D = xL.shape
     L = w.shape[0]
@@ -293,6 +360,7 @@ def cross_fwd(x0, w, b, xL, aux, ws):
                               _ptr(aux, torch.float32), wp, wn, _stream()), 'ctr_cross_fwd')
 
 
+@_timed
 def cross_bwd(x0, w, b, aux, g, dx0, dw, db, ws, accumulate=False):
     B, D = g.shape
     L = w.shape[0]
@@ -307,6 +375,7 @@ def cross_bwd(x0, w, b, aux, g, dx0, dw, db, ws, accumulate=False):
                               _ptr(db, torch.float32), wp, wn, _stream()), 'ctr_cross_bwd')
 
 
+@_timed
 def copy2d(src, dst, accumulate=False):
     rows, cols = src.shape
     sp, sld = _rows(src, 'src')
@@ -316,6 +385,7 @@ def copy2d(src, dst, accumulate=False):
     check(lib().ctr_copy2d(sp, sld, dp, dld, rows, cols, int(accumulate), _stream()), 'ctr_copy2d')
 
 
+@_timed
 def dropout_apply(x, drop):
     if drop is None:
         return

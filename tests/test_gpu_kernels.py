@@ -1,0 +1,340 @@
+"""Kernel-level parity through the C ABI: every libctrhip operator against numpy/torch-CPU
+restatements on seeded inputs.  Index handling and row copies must be bit-exact; fp32
+reductions within 1e-5 relative (max-norm) of a float64 reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctr_oracle as O
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+@pytest.fixture(scope='module')
+def ops_ws(sess):
+    from recommendation_amd import ops
+    return ops, sess.ws
+
+
+@pytest.mark.parametrize('n,bits', [(1, 3), (63, 8), (64, 9), (4097, 17), (200000, 26), (70001, 32), (300000, 2)])
+def test_sort_pairs_stable_exact(ops_ws, n, bits):
+    ops, ws = ops_ws
+    rng = np.random.default_rng(n + bits)
+    keys = rng.integers(0, 2 ** bits, n, dtype=np.uint64).astype(np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    ko, vo = ops.sort_pairs(dev(keys.view(np.int32)), dev(vals.view(np.int32)), bits, ws)
+    order = np.argsort(keys, kind='stable')
+    assert np.array_equal(ko.cpu().numpy().view(np.uint32), keys[order])
+    assert np.array_equal(vo.cpu().numpy().view(np.uint32), vals[order])
+
+
+def _tables(rng, cards, E):
+    offs = np.zeros(len(cards) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(cards)
+    W = rng.standard_normal((int(offs[-1]), E)).astype(np.float32)
+    return W, offs
+
+
+@pytest.mark.parametrize('E', [4, 8, 16, 64, 128])
+def test_embed_fwd_smode_bit_exact_rows_and_fm(ops_ws, E):
+    ops, ws = ops_ws
+    rng = np.random.default_rng(E)
+    cards = [3, 50, 7, 1000, 2, 33]
+    F, C, B = len(cards), 5, 257
+    W, offs = _tables(rng, cards, E)
+    idx = np.stack([rng.integers(0, v, B) for v in cards], 1).astype(np.int32)
+    idx[0, 0] = -1
+    idx[1, 3] = 1000          # == V: out of range
+    idx[2, 5] = 2 ** 31 - 1
+    xc = rng.standard_normal((B, C)).astype(np.float32)
+    Wc = rng.standard_normal((C, E)).astype(np.float32)
+    N = F + C
+    ld = (N * E + C + 3) // 4 * 4
+    z = torch.full((B, ld), 7.0, device=DEV)
+    first = torch.zeros(B, N, device=DEV)
+    s = torch.zeros(B, E, device=DEV)
+    second = torch.zeros(B, E + 3, device=DEV)
+    oor = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.embed_fwd(dev(W), dev(offs), dev(idx), dev(xc), dev(Wc), E=E, z_out=z, cont_tail=True, first_out=first,
+                  s_out=s, second_out=second[:, 3:], oor_count=oor)
+    # reference
+    Z = np.zeros((B, N, E), dtype=np.float32)
+    for f in range(F):
+        ok = (idx[:, f] >= 0) & (idx[:, f] < cards[f])
+        Z[ok, f] = W[offs[f] + idx[ok, f]]
+    Z[:, F:] = Wc[None] * xc[:, :, None]
+    zz = z.cpu().numpy()
+    assert np.array_equal(zz[:, :N * E].reshape(B, N, E), Z)          # copies / one multiply: bit-exact
+    assert np.array_equal(zz[:, N * E:N * E + C], xc)
+    assert int(oor.item()) == 3
+    Z64 = Z.astype(np.float64)
+    assert rel_err(first.cpu().numpy(), Z64.sum(2)) < 1e-5
+    assert rel_err(s.cpu().numpy(), Z64.sum(1)) < 1e-5
+    assert rel_err(second[:, 3:].cpu().numpy(), 0.5 * (Z64.sum(1) ** 2 - (Z64 ** 2).sum(1))) < 1e-5
+
+
+def test_embed_onehot_rmode_bit_exact(ops_ws):
+    ops, ws = ops_ws
+    rng = np.random.default_rng(1)
+    cards, E, B, C = [3, 5, 4, 9], 8, 33, 2
+    W, offs = _tables(rng, cards, E)
+    idx = np.stack([rng.integers(0, v, B) for v in cards], 1).astype(np.int32)
+    idx[0, 0], idx[1, 1] = 3, -2
+    xc = rng.standard_normal((B, C)).astype(np.float32)
+    SV = int(offs[-1])
+    ld = (SV * E + C + 3) // 4 * 4
+    z = torch.full((B, ld), 3.0, device=DEV)
+    pos = torch.zeros(B, len(cards), dtype=torch.int32, device=DEV)
+    ops.embed_onehot_fwd(dev(W), dev(offs), dev(idx), dev(xc), E=E, z_out=z, cont_tail=True, pos_out=pos)
+    tabs = [torch.as_tensor(W[offs[f]:offs[f + 1]]) for f in range(len(cards))]
+    Zref = O.embed_block_rmode_literal(tabs, torch.as_tensor(idx.astype(np.int64))).numpy()
+    zz = z.cpu().numpy()
+    assert np.array_equal(zz[:, :SV * E].reshape(B, SV, E), Zref)
+    assert np.array_equal(zz[:, SV * E:SV * E + C], xc)
+    pref = np.where((idx >= 0) & (idx < np.array(cards)[None]), offs[:-1][None] + idx, -1)
+    assert np.array_equal(pos.cpu().numpy(), pref)
+
+
+@pytest.mark.parametrize('skew', [False, True])
+@pytest.mark.parametrize('E', [4, 16, 64])
+def test_sort_segment_reduce_matches_scatter_add(ops_ws, E, skew):
+    """emb_sort + sparse_apply(GRAD_ONLY) == np.add.at, including hot rows with long runs."""
+    ops, ws = ops_ws
+    rng = np.random.default_rng(E + skew)
+    cards = [2, 3, 4000, 17, 100000]
+    F, B = len(cards), 6000
+    offs = np.zeros(F + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(cards)
+    total = int(offs[-1])
+    if skew:
+        idx = np.stack([np.minimum((rng.pareto(0.6, B)).astype(np.int64), v - 1) for v in cards], 1)
+    else:
+        idx = np.stack([rng.integers(0, v, B) for v in cards], 1)
+    idx = idx.astype(np.int32)
+    idx[5, 2] = -1
+    idx[6, 4] = cards[4]
+    ld = F * E + 4
+    dz = rng.standard_normal((B, ld)).astype(np.float32)
+    keys = torch.zeros(B * F, dtype=torch.int32, device=DEV)
+    src = torch.zeros(B * F, dtype=torch.int32, device=DEV)
+    d_idx, d_offs, d_dz = dev(idx), dev(offs), dev(dz)
+    outs = []
+    for _ in range(2):
+        grad = torch.zeros(total, E, device=DEV)
+        ops.emb_sort(d_idx, d_offs, N=F, total_rows=total, rmode=False, keys_out=keys, src_out=src, ws=ws)
+        ops.emb_sparse_apply(keys, src, B * F, N=F, E=E, total_rows=total, dz=d_dz,
+                             opt=ops.make_opt(0), slot0=grad, ws=ws)
+        outs.append(grad.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])                       # bitwise reproducible
+    ref = np.zeros((total, E), dtype=np.float64)
+    g = dz[:, :F * E].reshape(B, F, E).astype(np.float64)
+    for f in range(F):
+        ok = (idx[:, f] >= 0) & (idx[:, f] < cards[f])
+        np.add.at(ref, offs[f] + idx[ok, f], g[ok, f])
+    assert rel_err(outs[0], ref) < 1e-5
+    # sorted keys really are sorted and complete
+    k = keys.cpu().numpy().view(np.uint32)
+    assert np.all(np.diff(k.astype(np.int64)) >= 0)
+    assert int((k == total).sum()) == 2
+
+
+@pytest.mark.parametrize('kind', ['adam', 'adagrad', 'sgd'])
+def test_sparse_optimizers_match_tf1_formulas(ops_ws, kind):
+    ops, ws = ops_ws
+    rng = np.random.default_rng(3)
+    cards, E, B = [50, 7], 8, 300
+    F = 2
+    offs = np.array([0, 50, 57], dtype=np.int64)
+    total = 57
+    idx = np.stack([rng.integers(0, v, B) for v in cards], 1).astype(np.int32)
+    dz = rng.standard_normal((B, F * E)).astype(np.float32)
+    W = rng.standard_normal((total, E)).astype(np.float32)
+    m0 = np.abs(rng.standard_normal((total, E))).astype(np.float32) * 0.1
+    v0 = np.abs(rng.standard_normal((total, E))).astype(np.float32) * 0.1 + 0.1
+    g = np.zeros((total, E), dtype=np.float64)
+    for f in range(F):
+        np.add.at(g, offs[f] + idx[:, f], dz[:, f * E:(f + 1) * E].astype(np.float64))
+    touched = np.zeros(total, dtype=bool)
+    for f in range(F):
+        touched[offs[f] + idx[:, f]] = True
+    keys = torch.zeros(B * F, dtype=torch.int32, device=DEV)
+    src = torch.zeros(B * F, dtype=torch.int32, device=DEV)
+    ops.emb_sort(dev(idx), dev(offs), N=F, total_rows=total, rmode=False, keys_out=keys, src_out=src, ws=ws)
+    dW, dm, dv = dev(W), dev(m0), dev(v0)
+    lr, b1, b2, eps = 0.01, 0.9, 0.999, 1e-8
+    code = dict(adam=1, adagrad=2, sgd=3)[kind]
+    ops.emb_sparse_apply(keys, src, B * F, N=F, E=E, total_rows=total, dz=dev(dz),
+                         opt=ops.make_opt(code, lr=lr, beta1=b1, beta2=b2, eps=eps), tables=dW,
+                         slot0=dm if kind != 'sgd' else None, slot1=dv if kind == 'adam' else None, ws=ws)
+    W64, m64, v64 = W.astype(np.float64), m0.astype(np.float64), v0.astype(np.float64)
+    if kind == 'adam':
+        m1 = b1 * m64 + (1 - b1) * g
+        v1 = b2 * v64 + (1 - b2) * g * g
+        Wn = W64 - lr * m1 / (np.sqrt(v1) + eps)
+    elif kind == 'adagrad':
+        m1 = m64 + g * g
+        Wn = W64 - lr * g / np.sqrt(m1)
+    else:
+        Wn = W64 - lr * g
+    out = dW.cpu().numpy()
+    assert rel_err(out[touched], Wn[touched]) < 1e-5
+    assert np.array_equal(out[~touched], W[~touched])             # untouched rows are not written
+
+
+GEMM_SHAPES = [(1, 1, 1), (5, 3, 2), (130, 70, 33), (257, 129, 19), (64, 1, 300), (429, 256, 5000),
+               (1000, 429, 256), (33, 250, 4096)]
+
+
+@pytest.mark.parametrize('ta', [False, True])
+@pytest.mark.parametrize('tb', [False, True])
+@pytest.mark.parametrize('shape', GEMM_SHAPES)
+def test_gemm_f32_all_layouts(ops_ws, shape, ta, tb):
+    ops, ws = ops_ws
+    M, N, K = shape
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bm = rng.standard_normal((K, N)).astype(np.float32)
+    # odd leading dimensions on purpose (scalar load path) and aligned ones (vector path)
+    pad = 0 if (M + N + K) % 2 else 3
+    As = np.zeros(((K, M + pad) if ta else (M, K + pad)), dtype=np.float32)
+    Bs = np.zeros(((N, K + pad) if tb else (K, N + pad)), dtype=np.float32)
+    if ta:
+        As[:, :M] = A.T
+    else:
+        As[:, :K] = A
+    if tb:
+        Bs[:, :K] = Bm.T
+    else:
+        Bs[:, :N] = Bm
+    dA, dB = dev(As), dev(Bs)
+    vA = dA[:, :M] if ta else dA[:, :K]
+    vB = dB[:, :K] if tb else dB[:, :N]
+    Cbuf = torch.full((M, N + 5), -1.0, device=DEV)
+    ops.gemm(vA, vB, Cbuf[:, :N], trans_a=ta, trans_b=tb, ws=ws)
+    ref = A.astype(np.float64) @ Bm.astype(np.float64)
+    out = Cbuf.cpu().numpy()
+    assert rel_err(out[:, :N], ref) < 1e-5
+    assert np.all(out[:, N:] == -1.0)                              # nothing written outside the view
+
+
+def test_gemm_epilogues(ops_ws):
+    ops, ws = ops_ws
+    rng = np.random.default_rng(5)
+    M, N, K = 300, 70, 45
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bm = rng.standard_normal((K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ Bm + bias
+    # bias + relu
+    C = torch.zeros(M, N, device=DEV)
+    ops.gemm(dev(A), dev(Bm), C, bias=dev(bias), relu=True, ws=ws)
+    assert rel_err(C.cpu().numpy(), np.maximum(ref, 0)) < 1e-5
+    # bias + relu + dropout through the shared hash
+    drop = ops.make_dropout(0.3, seed=99, stream_id=4)
+    ops.gemm(dev(A), dev(Bm), C, bias=dev(bias), relu=True, dropout=drop, ws=ws)
+    keep = O.keep_mask(99, 4, M * N, 0.7).reshape(M, N)
+    assert rel_err(C.cpu().numpy(), np.maximum(ref, 0) * keep / 0.7) < 1e-5
+    # accumulate
+    C = dev(C0)
+    ops.gemm(dev(A), dev(Bm), C, accumulate=True, ws=ws)
+    assert rel_err(C.cpu().numpy(), C0 + A.astype(np.float64) @ Bm) < 1e-5
+    # relu/dropout-backward mask
+    act = rng.standard_normal((M, N)).astype(np.float32)
+    C = torch.zeros(M, N, device=DEV)
+    ops.gemm(dev(A), dev(Bm), C, mask_src=dev(act), mask_scale=1.25, ws=ws)
+    assert rel_err(C.cpu().numpy(), np.where(act > 0, (A.astype(np.float64) @ Bm) * 1.25, 0)) < 1e-5
+
+
+def test_colsum_rowdot_loss(ops_ws):
+    ops, ws = ops_ws
+    rng = np.random.default_rng(6)
+    B, K, E = 5000, 37, 4
+    X = rng.standard_normal((B, K + 3)).astype(np.float32)
+    w = rng.standard_normal((B, 10)).astype(np.float32)
+    out = torch.zeros(K, device=DEV)
+    ops.colsum(dev(X)[:, :K], out, ws=ws)
+    assert rel_err(out.cpu().numpy(), X[:, :K].astype(np.float64).sum(0)) < 1e-5
+    ops.colsum(dev(X)[:, :K], out, w=dev(w), w_group=E, ws=ws)
+    ref = (X[:, :K].astype(np.float64) * np.repeat(w, E, axis=1)[:, :K]).sum(0)
+    assert rel_err(out.cpu().numpy(), ref) < 1e-5
+    wv = rng.standard_normal(K).astype(np.float32)
+    bias = np.array([0.3], dtype=np.float32)
+    o = torch.zeros(B, device=DEV)
+    ops.rowdot_fwd(dev(X)[:, :K], dev(wv), dev(bias), o)
+    assert rel_err(o.cpu().numpy(), X[:, :K].astype(np.float64) @ wv + 0.3) < 1e-5
+    # loss heads vs torch (float64) incl. gradients
+    x = rng.standard_normal(B).astype(np.float32)
+    y = rng.integers(0, 2, B).astype(np.float32)
+    for kind in range(5):
+        xx = x if kind not in (1, 4) else (1 / (1 + np.exp(-x))).astype(np.float32)   # probabilities where needed
+        t = torch.tensor(xx, dtype=torch.float64, requires_grad=True)
+        yy = torch.tensor(y, dtype=torch.float64)
+        if kind == 0:
+            p = torch.sigmoid(t); loss = O.log_loss(yy, p)
+        elif kind == 1:
+            p = t; loss = O.log_loss(yy, p)
+        elif kind == 2:
+            p = torch.sigmoid(t); loss = O.sigmoid_ce_with_logits(yy, p).mean()
+        elif kind == 3:
+            p = torch.sigmoid(t); loss = O.sigmoid_ce_with_logits(yy, t).mean()
+        else:
+            p = t; loss = O.sigmoid_ce_with_logits(yy, t).mean()
+        loss.backward()
+        yo, lo, dx = torch.zeros(B, device=DEV), torch.zeros(1, device=DEV), torch.zeros(B, device=DEV)
+        ops.loss_head(kind, dev(xx), dev(y), y_out=yo, loss_out=lo, dx=dx, ws=ws)
+        assert rel_err(yo.cpu().numpy(), p.detach().numpy()) < 1e-5, kind
+        assert abs(float(lo.item()) - float(loss.item())) < 1e-5, kind
+        assert rel_err(dx.cpu().numpy(), t.grad.numpy()) < 2e-5, kind
+
+
+@pytest.mark.parametrize('D,L', [(50, 3), (429, 3), (1677, 6), (300, 1), (2100, 8)])
+def test_cross_network_fwd_bwd(ops_ws, D, L):
+    ops, ws = ops_ws
+    rng = np.random.default_rng(D + L)
+    B = 37
+    x0 = (rng.standard_normal((B, D)) * 0.5).astype(np.float32)
+    w = (rng.standard_normal((L, D)) * 0.05).astype(np.float32)
+    b = (rng.standard_normal((L, D)) * 0.05).astype(np.float32)
+    g = rng.standard_normal((B, D)).astype(np.float32)
+    ld = (D + 3) // 4 * 4
+    x0p = np.zeros((B, ld), dtype=np.float32); x0p[:, :D] = x0
+    d_x0 = dev(x0p)
+    xL = torch.zeros(B, D, device=DEV)
+    aux = torch.zeros(B, 2 * L, device=DEV)
+    ops.cross_fwd(d_x0, dev(w), dev(b), xL, aux, ws)
+    tx = torch.tensor(x0, dtype=torch.float64, requires_grad=True)
+    tw = [torch.tensor(w[l].reshape(D, 1), dtype=torch.float64, requires_grad=True) for l in range(L)]
+    tb = [torch.tensor(b[l].reshape(D, 1), dtype=torch.float64, requires_grad=True) for l in range(L)]
+    ref = O.dcn_cross(tx, tw, tb)
+    assert rel_err(xL.cpu().numpy(), ref.detach().numpy()) < 1e-5
+    ref.backward(torch.tensor(g, dtype=torch.float64))
+    dx0 = torch.zeros(B, ld, device=DEV)
+    dw, db = torch.zeros(L, D, device=DEV), torch.zeros(L, D, device=DEV)
+    ops.cross_bwd(d_x0, dev(w), dev(b), aux, dev(g), dx0, dw, db, ws)
+    assert rel_err(dx0.cpu().numpy()[:, :D], tx.grad.numpy()) < 1e-5
+    assert rel_err(dw.cpu().numpy(), np.stack([t.grad.numpy().reshape(-1) for t in tw])) < 1e-5
+    assert rel_err(db.cpu().numpy(), np.stack([t.grad.numpy().reshape(-1) for t in tb])) < 1e-5
+
+
+def test_bad_arguments_are_rejected(ops_ws):
+    ops, ws = ops_ws
+    from recommendation_amd._lib import CtrError
+    W = torch.zeros(10, 12, device=DEV)
+    idx = torch.zeros(4, 1, dtype=torch.int32, device=DEV)
+    offs = dev(np.array([0, 10], dtype=np.int64))
+    with pytest.raises(CtrError):       # E = 12 is not a power of two
+        ops.embed_fwd(W, offs, idx, E=12, z_out=torch.zeros(4, 12, device=DEV))
+    with pytest.raises(ValueError):     # GEMM inner dimensions disagree
+        ops.gemm(torch.zeros(4, 5, device=DEV), torch.zeros(6, 3, device=DEV), torch.zeros(4, 3, device=DEV), ws=ws)
+    with pytest.raises(ValueError):     # CPU tensors are refused: there is no CPU path
+        ops.gemm(torch.zeros(4, 5), torch.zeros(5, 3), torch.zeros(4, 3), ws=ws)
