@@ -222,6 +222,13 @@ int ctr_loss_head(int kind, const float* x, const float* y, int B,
                   float* y_out, float* loss_out, float* dx,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ESMM head (ESMM/ESMM.py:95-98): y_out = sigmoid(ctr) * sigmoid(cvr);
+ * loss = mean sigmoid_cross_entropy_with_logits(labels=y, logits=y_out) (y_out is already a
+ * probability; reproduced as written).  dctr/dcvr = d loss / d logits.  Workspace as ctr_loss_head. */
+int ctr_esmm_head(const float* ctr_logit, const float* cvr_logit, const float* y, int B,
+                  float* y_out, float* loss_out, float* dctr, float* dcvr,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Dense optimizers over one flat parameter buffer (multi-tensor in one launch).
  * Replaces: tf.train.AdamOptimizer / AdagradOptimizer / GradientDescentOptimizer apply
@@ -233,17 +240,17 @@ int ctr_dense_update(float* param, const float* grad, float* slot0, float* slot1
 /* ------------------------------------------------------------------------------------
  * DCN cross network, all layers fused (DCN/DCN.py:56-65 without the [B,D,D] product):
  *   x_{l+1} = x0 * (x_l . w_l) + b_l + x_l,   l = 0..L-1,   1 <= L <= 8,  D <= 8192
- * w, b: [L, D] contiguous.  Every x_l lies in span{x0, prefix sums of b}, so the kernels
+ * w, b, dw, db: L rows of D values, row stride wld (>= D).  Every x_l lies in span{x0, prefix sums of b}, so the kernels
  * carry only per-sample scalars: aux_out[b, 0..L) = x0 . w_l and aux_out[b, L..2L) = c_{l+1}
  * with x_l = x0*c_l + sum_{l'<l} b_l'.  aux_out ([B, 2L]) is what the backward needs.
  * Backward: given g = dLoss/dx_L, produces dx0 (+= when accumulate), dw[L,D], db[L,D].
  * ---------------------------------------------------------------------------------- */
 size_t ctr_cross_fwd_workspace_bytes(int D, int L);
-int ctr_cross_fwd(const float* x0, int64_t x0_ld, const float* w, const float* b,
+int ctr_cross_fwd(const float* x0, int64_t x0_ld, const float* w, const float* b, int64_t wld,
                   int B, int D, int L, float* xL, int64_t xL_ld, float* aux_out,
                   void* workspace, size_t workspace_bytes, void* stream);
 size_t ctr_cross_bwd_workspace_bytes(int B, int D, int L);
-int ctr_cross_bwd(const float* x0, int64_t x0_ld, const float* w, const float* b,
+int ctr_cross_bwd(const float* x0, int64_t x0_ld, const float* w, const float* b, int64_t wld,
                   const float* aux, const float* g, int64_t g_ld,
                   int B, int D, int L,
                   float* dx0, int64_t dx0_ld, int accumulate, float* dw, float* db,

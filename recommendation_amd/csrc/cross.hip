@@ -14,7 +14,7 @@ constexpr int LMAX = 8;
 
 // Bl[l][j] for l = 0..L (prefix sums of b) and q[l] = Bl_l . w_l.  One block.
 __global__ __launch_bounds__(256) void cross_prep_kernel(const float* __restrict__ w, const float* __restrict__ b,
-                                                        int D, int L, float* __restrict__ Bl,
+                                                        int64_t wld, int D, int L, float* __restrict__ Bl,
                                                         float* __restrict__ q) {
   __shared__ float red[256];
   float qacc[LMAX];
@@ -25,8 +25,8 @@ __global__ __launch_bounds__(256) void cross_prep_kernel(const float* __restrict
     for (int l = 0; l <= L; ++l) {
       Bl[(int64_t)l * D + j] = run;
       if (l < L) {
-        qacc[l] += run * w[(int64_t)l * D + j];
-        run += b[(int64_t)l * D + j];
+        qacc[l] += run * w[(int64_t)l * wld + j];
+        run += b[(int64_t)l * wld + j];
       }
     }
   }
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void cross_prep_kernel(const float* __restrict
 
 template <int NPL>
 __global__ __launch_bounds__(256) void cross_fwd_kernel(const float* __restrict__ x0, int64_t x0_ld,
-                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ w, int64_t wld,
                                                        const float* __restrict__ Bl,
                                                        const float* __restrict__ q, int B, int D, int L,
                                                        float* __restrict__ xL, int64_t xL_ld,
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void cross_fwd_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
       const int j = lane + 64 * i;
-      if (j < D) p += x[i] * w[(int64_t)l * D + j];
+      if (j < D) p += x[i] * w[(int64_t)l * wld + j];
     }
     p = wave_sum(p);
     const float s = c * p + q[l];
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void cross_fwd_kernel(const float* __restrict_
 
 template <int NPL>
 __global__ __launch_bounds__(256) void cross_bwd_kernel(const float* __restrict__ x0, int64_t x0_ld,
-                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ w, int64_t wld,
                                                        const float* __restrict__ aux,
                                                        const float* __restrict__ g, int64_t g_ld, int B, int D,
                                                        int L, float* __restrict__ dx0, int64_t dx0_ld,
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void cross_bwd_kernel(const float* __restrict_
       float v = gv[i] * cL;
 #pragma unroll
       for (int l = 0; l < LMAX; ++l)
-        if (l < L) v += dp[l] * w[(int64_t)l * D + j];
+        if (l < L) v += dp[l] * w[(int64_t)l * wld + j];
       float* d = dx0 + b * dx0_ld + j;
       *d = accumulate ? *d + v : v;
     }
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void cross_bwd_sdq_kernel(const float* __restr
 }
 
 __global__ __launch_bounds__(256) void cross_bwd_final_kernel(const float* __restrict__ part, int nchunks,
-                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ w, int64_t wld,
                                                              const float* __restrict__ Bl,
                                                              const float* __restrict__ sdq, int D, int L,
                                                              float* __restrict__ dw, float* __restrict__ db) {
@@ -200,11 +200,11 @@ __global__ __launch_bounds__(256) void cross_bwd_final_kernel(const float* __res
   // dBl_L = colsum(g); dBl_l = sdq_l * w_l (l < L); db_l' = sum_{l > l'} dBl_l
   float run = gsum;
   for (int l = L - 1; l >= 0; --l) {
-    db[(int64_t)l * D + j] = run;
-    run += sdq[l] * w[(int64_t)l * D + j];
+    db[(int64_t)l * wld + j] = run;
+    run += sdq[l] * w[(int64_t)l * wld + j];
     float acc = 0.f;
     for (int c = 0; c < nchunks; ++c) acc += part[((int64_t)c * (L + 1) + l) * D + j];
-    dw[(int64_t)l * D + j] = acc + sdq[l] * Bl[(int64_t)l * D + j];
+    dw[(int64_t)l * wld + j] = acc + sdq[l] * Bl[(int64_t)l * D + j];
   }
 }
 
@@ -240,13 +240,14 @@ extern "C" size_t ctr_cross_bwd_workspace_bytes(int B, int D, int L) {
     else hipLaunchKernelGGL(KERNEL<128>, grid, block, 0, st, __VA_ARGS__);                       \
   } while (0)
 
-extern "C" int ctr_cross_fwd(const float* x0, int64_t x0_ld, const float* w, const float* b, int B, int D,
-                             int L, float* xL, int64_t xL_ld, float* aux_out, void* workspace,
+extern "C" int ctr_cross_fwd(const float* x0, int64_t x0_ld, const float* w, const float* b, int64_t wld,
+                             int B, int D, int L, float* xL, int64_t xL_ld, float* aux_out, void* workspace,
                              size_t workspace_bytes, void* stream) {
   CTR_REQUIRE(B >= 0 && D > 0 && L >= 1 && L <= LMAX, "ctr_cross_fwd: need 1 <= L <= %d", LMAX);
   CTR_REQUIRE(D <= 8192, "ctr_cross_fwd: D=%d exceeds the register-resident limit 8192", D);
   if (B == 0) return CTR_OK;
   CTR_REQUIRE(x0 && w && b && xL && workspace, "ctr_cross_fwd: null pointer");
+  CTR_REQUIRE(wld >= D, "ctr_cross_fwd: wld < D");
   if (workspace_bytes < ctr_cross_fwd_workspace_bytes(D, L)) {
     set_error("ctr_cross_fwd: workspace %zu < %zu", workspace_bytes, ctr_cross_fwd_workspace_bytes(D, L));
     return CTR_EWORKSPACE;
@@ -254,19 +255,20 @@ extern "C" int ctr_cross_fwd(const float* x0, int64_t x0_ld, const float* w, con
   hipStream_t st = (hipStream_t)stream;
   float* Bl = (float*)workspace;
   float* q = Bl + (size_t)(L + 1) * D;
-  hipLaunchKernelGGL(cross_prep_kernel, dim3(1), dim3(256), 0, st, w, b, D, L, Bl, q);
-  CROSS_DISPATCH(cross_fwd_kernel, x0, x0_ld, w, Bl, q, B, D, L, xL, xL_ld, aux_out);
+  hipLaunchKernelGGL(cross_prep_kernel, dim3(1), dim3(256), 0, st, w, b, wld, D, L, Bl, q);
+  CROSS_DISPATCH(cross_fwd_kernel, x0, x0_ld, w, wld, Bl, q, B, D, L, xL, xL_ld, aux_out);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
 
-extern "C" int ctr_cross_bwd(const float* x0, int64_t x0_ld, const float* w, const float* b,
+extern "C" int ctr_cross_bwd(const float* x0, int64_t x0_ld, const float* w, const float* b, int64_t wld,
                              const float* aux, const float* g, int64_t g_ld, int B, int D, int L,
                              float* dx0, int64_t dx0_ld, int accumulate, float* dw, float* db,
                              void* workspace, size_t workspace_bytes, void* stream) {
   CTR_REQUIRE(B > 0 && D > 0 && L >= 1 && L <= LMAX, "ctr_cross_bwd: need B > 0 and 1 <= L <= %d", LMAX);
   CTR_REQUIRE(D <= 8192, "ctr_cross_bwd: D=%d exceeds the register-resident limit 8192", D);
   CTR_REQUIRE(x0 && w && b && aux && g && dx0 && dw && db && workspace, "ctr_cross_bwd: null pointer");
+  CTR_REQUIRE(wld >= D, "ctr_cross_bwd: wld < D");
   if (workspace_bytes < ctr_cross_bwd_workspace_bytes(B, D, L)) {
     set_error("ctr_cross_bwd: workspace %zu < %zu", workspace_bytes, ctr_cross_bwd_workspace_bytes(B, D, L));
     return CTR_EWORKSPACE;
@@ -279,13 +281,13 @@ extern "C" int ctr_cross_bwd(const float* x0, int64_t x0_ld, const float* w, con
   float* part = sdq + 64;
   const int nchunks = cross_chunks(B);
   const int rows_per_chunk = (int)cdiv(B, nchunks);
-  hipLaunchKernelGGL(cross_prep_kernel, dim3(1), dim3(256), 0, st, w, b, D, L, Bl, q);
-  CROSS_DISPATCH(cross_bwd_kernel, x0, x0_ld, w, aux, g, g_ld, B, D, L, dx0, dx0_ld, accumulate, dpq);
+  hipLaunchKernelGGL(cross_prep_kernel, dim3(1), dim3(256), 0, st, w, b, wld, D, L, Bl, q);
+  CROSS_DISPATCH(cross_bwd_kernel, x0, x0_ld, w, wld, aux, g, g_ld, B, D, L, dx0, dx0_ld, accumulate, dpq);
   hipLaunchKernelGGL(cross_bwd_partial_kernel, dim3((unsigned)cdiv(D, 64), nchunks), dim3(256), 0, st, x0,
                      x0_ld, g, g_ld, dpq, B, D, L, rows_per_chunk, part);
   hipLaunchKernelGGL(cross_bwd_sdq_kernel, dim3(1), dim3(256), 0, st, dpq, B, L, sdq);
   hipLaunchKernelGGL(cross_bwd_final_kernel, dim3((unsigned)cdiv(D, 256)), dim3(256), 0, st, part, nchunks, w,
-                     Bl, sdq, D, L, dw, db);
+                     wld, Bl, sdq, D, L, dw, db);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }

@@ -123,6 +123,37 @@ __global__ __launch_bounds__(256) void loss_head_kernel(int kind, const float* _
   if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 
+// ESMM head (ESMM/ESMM.py:95-98): y_out = sigmoid(a) * sigmoid(c); loss = sce(labels=y, logits=y_out)
+__global__ __launch_bounds__(256) void esmm_head_kernel(const float* __restrict__ a, const float* __restrict__ c,
+                                                       const float* __restrict__ y, int B,
+                                                       float* __restrict__ y_out, float* __restrict__ da,
+                                                       float* __restrict__ dc, float* __restrict__ part) {
+  __shared__ float red[256];
+  const float invB = 1.f / (float)B;
+  float l = 0.f;
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b < B) {
+    const float sa = sigmoidf_(a[b]), sc = sigmoidf_(c[b]);
+    const float p = sa * sc;
+    if (y_out) y_out[b] = p;
+    if (y) {
+      const float yv = y[b];
+      l = sce_(p, yv);
+      const float d = (sigmoidf_(p) - yv) * invB;
+      if (da) da[b] = d * p * (1.f - sa);
+      if (dc) dc[b] = d * p * (1.f - sc);
+    }
+  }
+  if (!part) return;
+  red[threadIdx.x] = l;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
 __global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict__ part, int n, int B,
                                                         float* __restrict__ loss_out) {
   __shared__ float red[256];
@@ -294,6 +325,28 @@ extern "C" int ctr_relu_mask_apply(float* g, int64_t g_ld, const float* act, int
   CTR_REQUIRE(g && act, "ctr_relu_mask_apply: null pointer");
   hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_for((int64_t)rows * cols)), dim3(256), 0, (hipStream_t)stream,
                      g, g_ld, act, act_ld, rows, cols, scale);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_esmm_head(const float* ctr_logit, const float* cvr_logit, const float* y, int B, float* y_out,
+                             float* loss_out, float* dctr, float* dcvr, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  CTR_REQUIRE(B > 0 && ctr_logit && cvr_logit, "ctr_esmm_head: bad argument");
+  CTR_REQUIRE(y || (!loss_out && !dctr && !dcvr), "ctr_esmm_head: labels are required for loss / gradient");
+  const int nb = (int)cdiv(B, 256);
+  float* part = nullptr;
+  if (loss_out) {
+    if (!workspace || workspace_bytes < ctr_loss_head_workspace_bytes(B)) {
+      set_error("ctr_esmm_head: workspace %zu < %zu", workspace_bytes, ctr_loss_head_workspace_bytes(B));
+      return CTR_EWORKSPACE;
+    }
+    part = (float*)workspace;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(esmm_head_kernel, dim3(nb), dim3(256), 0, st, ctr_logit, cvr_logit, y, B, y_out, dctr, dcvr,
+                     part);
+  if (loss_out) hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, part, nb, B, loss_out);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }

@@ -64,6 +64,18 @@ class DenseParams:
         v = self._view(self.flat if buf is None else buf, k)
         return v if v.dim() == 2 else v.reshape(1, -1) if v.dim() == 1 else v.reshape(v.shape[0], -1)
 
+    def stacked(self, names, buf=None):
+        """[len(names), n] view over consecutively registered, equally sized variables
+        (row stride = the 4-float-padded size)."""
+        b = self.flat if buf is None else buf
+        n = int(np.prod(self.shapes[names[0]]))
+        stride = round_up(n, 4)
+        off0 = self.offsets[names[0]]
+        for i, k in enumerate(names):
+            if self.offsets[k] != off0 + i * stride or int(np.prod(self.shapes[k])) != n:
+                raise ValueError('variables are not stacked: %s' % (names,))
+        return b[off0:off0 + len(names) * stride].view(len(names), stride)[:, :n]
+
     def init_slots(self, kind):
         if kind == 'adam':
             self.slot0 = torch.zeros_like(self.flat)
@@ -185,9 +197,10 @@ class Tower:
             ops.gemm(h, self.dense.p(wn), acts[i], bias=self.dense.p(bn), relu=True, dropout=drops[i], ws=ws)
             h = acts[i]
 
-    def backward(self, x, acts, g_last, gbufs, rates, dx, ws):
+    def backward(self, x, acts, g_last, gbufs, rates, dx, ws, accumulate_dx=False):
         """g_last: gradient w.r.t. acts[-1] (post relu+dropout); it is masked in place.
-        gbufs[i]: scratch [B, L_i] for i < n-1.  dx (optional): [B, >= d_in] receives dL/dx."""
+        gbufs[i]: scratch [B, L_i] for i < n-1.  dx (optional): [B, >= d_in] receives dL/dx
+        (added to its content when accumulate_dx)."""
         n = len(self.names)
         scale = [1.0 / (1.0 - r) if r else 1.0 for r in rates]
         ops.relu_mask_apply(g_last, acts[n - 1], scale[n - 1])
@@ -202,7 +215,7 @@ class Tower:
                          mask_scale=scale[i - 1], ws=ws)
                 g = gbufs[i - 1]
             elif dx is not None:
-                ops.gemm(g, self.dense.p(wn), dx[:, :self.d_in], trans_b=True, ws=ws)
+                ops.gemm(g, self.dense.p(wn), dx[:, :self.d_in], trans_b=True, accumulate=accumulate_dx, ws=ws)
 
 
 def adam_lr_t(lr, t, b1=0.9, b2=0.999):

@@ -337,6 +337,20 @@ def loss_head(kind, x, y, *, y_out=None, loss_out=None, dx=None, ws=None):
 
 
 @_timed
+def esmm_head(ctr_logit, cvr_logit, y, *, y_out=None, loss_out=None, dctr=None, dcvr=None, ws=None):
+    B = ctr_logit.numel()
+    if cvr_logit.numel() != B or (y is not None and y.numel() != B):
+        raise ValueError('esmm_head size mismatch')
+    wp, wn = (None, 0)
+    if loss_out is not None:
+        wp, wn = ws.get(lib().ctr_loss_head_workspace_bytes(B))
+    f32 = torch.float32
+    check(lib().ctr_esmm_head(_ptr(ctr_logit, f32), _ptr(cvr_logit, f32), _ptr(y, f32), B, _ptr(y_out, f32),
+                              _ptr(loss_out, f32), _ptr(dctr, f32), _ptr(dcvr, f32), wp, wn, _stream()),
+          'ctr_esmm_head')
+
+
+@_timed
 def dense_update(param, grad, opt, slot0=None, slot1=None):
     n = param.numel()
     if grad.numel() != n or (slot0 is not None and slot0.numel() != n) or (slot1 is not None and slot1.numel() != n):
@@ -347,16 +361,19 @@ def dense_update(param, grad, opt, slot0=None, slot1=None):
 
 @_timed
 def cross_fwd(x0, w, b, xL, aux, ws):
+    """w, b: [L, >= D] views (row stride = wld)."""
     B, D = xL.shape
     L = w.shape[0]
     xp, xld = _rows(x0, 'x0')
     op, old = _rows(xL, 'xL')
-    if x0.shape[0] != B or x0.shape[1] < D or tuple(w.shape) != (L, D) or tuple(b.shape) != (L, D):
+    wp_, wld = _rows(w, 'w')
+    bp_, bld = _rows(b, 'b')
+    if x0.shape[0] != B or x0.shape[1] < D or w.shape[1] < D or tuple(b.shape) != tuple(w.shape) or bld != wld:
         raise ValueError('cross_fwd shape mismatch')
     if aux is not None and aux.numel() < B * 2 * L:
         raise ValueError('cross aux too small')
     wp, wn = ws.get(lib().ctr_cross_fwd_workspace_bytes(D, L))
-    check(lib().ctr_cross_fwd(xp, xld, _ptr(w, torch.float32), _ptr(b, torch.float32), B, D, L, op, old,
+    check(lib().ctr_cross_fwd(xp, xld, wp_, bp_, wld, B, D, L, op, old,
                               _ptr(aux, torch.float32), wp, wn, _stream()), 'ctr_cross_fwd')
 
 
@@ -367,12 +384,16 @@ def cross_bwd(x0, w, b, aux, g, dx0, dw, db, ws, accumulate=False):
     xp, xld = _rows(x0, 'x0')
     gp, gld = _rows(g, 'g')
     dp, dld = _rows(dx0, 'dx0')
-    if dx0.shape[0] != B or dx0.shape[1] < D or dw.numel() != L * D or db.numel() != L * D:
+    wp_, wld = _rows(w, 'w')
+    bp_, bld = _rows(b, 'b')
+    dwp, dwld = _rows(dw, 'dw')
+    dbp, dbld = _rows(db, 'db')
+    if dx0.shape[0] != B or dx0.shape[1] < D or not (wld == bld == dwld == dbld) or dw.shape[0] != L:
         raise ValueError('cross_bwd shape mismatch')
     wp, wn = ws.get(lib().ctr_cross_bwd_workspace_bytes(B, D, L))
-    check(lib().ctr_cross_bwd(xp, xld, _ptr(w, torch.float32), _ptr(b, torch.float32), _ptr(aux, torch.float32),
-                              gp, gld, B, D, L, dp, dld, int(accumulate), _ptr(dw, torch.float32),
-                              _ptr(db, torch.float32), wp, wn, _stream()), 'ctr_cross_bwd')
+    check(lib().ctr_cross_bwd(xp, xld, wp_, bp_, wld, _ptr(aux, torch.float32),
+                              gp, gld, B, D, L, dp, dld, int(accumulate), dwp, dbp, wp, wn, _stream()),
+          'ctr_cross_bwd')
 
 
 @_timed

@@ -1,0 +1,76 @@
+"""Deep & Cross on the HIP hot path; same class surface as the reference's DCN/DCN.py:5-132."""
+import torch
+
+from recommendation_amd import ops
+from recommendation_amd.engine import Tower, round_up
+from recommendation_amd.model_base import CTRModel
+from recommendation_amd._lib import LOSS_SIGMOID_LOGLOSS
+
+
+class DCN(CTRModel):
+    MODEL = 'DCN'
+    OPTIMIZER = 'adam'                      # DCN/DCN.py:33
+    LOSS_KIND = LOSS_SIGMOID_LOGLOSS        # DCN/DCN.py:89-92
+
+    def __init__(self, args, cate_num, cont_num, cate_list):
+        super().__init__(args, cate_num, cont_num, cate_list)
+        self.cross_layer_num = int(args.cross_layer_num)
+        self.deep_layers = [int(v) for v in args.deep_layers]
+        self.dropout = float(args.dropout)
+
+    def _dense_shapes(self, sh):
+        n = len(self.deep_layers)
+        self.total_size = D = self.N * self.embed_size + self.cont_num     # DCN/DCN.py:19
+        for l in range(self.cross_layer_num):
+            sh['cross_part/cross_w_%d' % l] = (D, 1)
+        for l in range(self.cross_layer_num):
+            sh['cross_part/cross_b_%d' % l] = (D, 1)
+        d = D
+        for i, L in enumerate(self.deep_layers):
+            sh['deep_part/deep_w_%d' % i] = (d, L)
+            sh['deep_part/deep_b_%d' % i] = (1, L)
+            d = L
+        self.stack_width = D + self.deep_layers[-1]
+        sh['stack_layer/stack_w_%d' % (n - 1)] = (self.stack_width, 1)     # DCN/DCN.py:85 (leaked loop index)
+        sh['stack_layer/stack_b_%d' % (n - 1)] = (1,)
+
+    def _post_init(self):
+        self.tower = Tower(self.dense, 'deep_part/deep', len(self.deep_layers))
+        self._wn = ['cross_part/cross_w_%d' % l for l in range(self.cross_layer_num)]
+        self._bn = ['cross_part/cross_b_%d' % l for l in range(self.cross_layer_num)]
+
+    def _alloc(self, B, bufs, dev):
+        D, Ls = self.total_size, self.deep_layers
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        bufs['x0'] = z(B, round_up(D, 4))
+        bufs['dx0'] = z(B, round_up(D, 4))
+        bufs['stack'] = z(B, self.stack_width)
+        bufs['dstack'] = z(B, self.stack_width)
+        bufs['aux'] = z(B, 2 * self.cross_layer_num)
+        bufs['acts'] = [z(B, L) for L in Ls[:-1]] + [bufs['stack'][:, D:]]
+        bufs['gbufs'] = [z(B, L) for L in Ls[:-1]]
+
+    def _forward(self, idx, xc, bufs, train):
+        D, n, ws = self.total_size, len(self.deep_layers), self.session.ws
+        self.front.forward(idx, xc, z_out=bufs['x0'], cont_tail=True)
+        ops.cross_fwd(bufs['x0'], self.dense.stacked(self._wn), self.dense.stacked(self._bn),
+                      bufs['stack'][:, :D], bufs['aux'], ws)
+        drops = [self._drop(self.dropout, 10 + i, train) for i in range(n)]
+        self.tower.forward(bufs['x0'], bufs['acts'], drops, ws)
+        ops.rowdot_fwd(bufs['stack'], self.dense.p('stack_layer/stack_w_%d' % (n - 1)).reshape(-1),
+                       self.dense.p('stack_layer/stack_b_%d' % (n - 1)), bufs['logit'])
+
+    def _backward(self, idx, xc, bufs):
+        D, n, ws = self.total_size, len(self.deep_layers), self.session.ws
+        B = idx.shape[0]
+        stack, dstack, dl = bufs['stack'], bufs['dstack'], bufs['dlogit']
+        wn, bn = 'stack_layer/stack_w_%d' % (n - 1), 'stack_layer/stack_b_%d' % (n - 1)
+        ops.rowdot_bwd_x(dl, self.dense.p(wn).reshape(-1), dstack)
+        ops.colsum(stack, self.dense.g(wn).reshape(-1), w=dl.view(B, 1), w_group=self.stack_width, ws=ws)
+        ops.colsum(dl.view(B, 1), self.dense.g(bn), ws=ws)
+        self.tower.backward(bufs['x0'], bufs['acts'], dstack[:, D:], bufs['gbufs'], [self.dropout] * n,
+                            bufs['dx0'], ws)
+        ops.cross_bwd(bufs['x0'], self.dense.stacked(self._wn), self.dense.stacked(self._bn), bufs['aux'],
+                      dstack[:, :D], bufs['dx0'], self.dense.stacked(self._wn, self.dense.grad),
+                      self.dense.stacked(self._bn, self.dense.grad), ws, accumulate=True)
+        self._tables_backward(idx, bufs['dx0'], bufs)

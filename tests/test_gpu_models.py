@@ -1,4 +1,5 @@
-"""DeepFM on the HIP path vs the CPU oracle: forward, loss, gradients and optimizer steps.
+"""Model classes on the HIP path vs the CPU oracle: forward, loss, gradients and optimizer steps,
+in the reference-exact (R) and the standard-lookup (S) semantics.
 Tolerance: fp32 forward/gradients within 1e-5 relative (max-norm), the bar BASELINE.json states."""
 import numpy as np
 import pytest
@@ -22,14 +23,18 @@ def _build(sess, model_name, cfg, P):
     return m
 
 
+MODELS = ['DeepFM', 'DCN', 'NFM', 'ESMM']
+
+
 @pytest.mark.parametrize('mode', ['R', 'S'])
-def test_deepfm_forward_grads_steps(sess, mode):
-    cfg = no_dropout(tiny_cfg('DeepFM', mode))
+@pytest.mark.parametrize('name', MODELS)
+def test_forward_grads_steps(sess, name, mode):
+    cfg = no_dropout(tiny_cfg(name, mode))
     cfg.adam_mode = 'tf1'
-    P = O.init_params('DeepFM', cfg, seed=3, std=0.3)
+    P = O.init_params(name, cfg, seed=3, std=0.3)
     Xc, Xf, y = tiny_batch(cfg, B=8)
-    orc = O.OracleModel('DeepFM', cfg, P, dtype=torch.float64)
-    m = _build(sess, 'DeepFM', cfg, P)
+    orc = O.OracleModel(name, cfg, P, dtype=torch.float64)
+    m = _build(sess, name, cfg, P)
     # forward
     p_gpu = m.predict_proba(sess, Xc, Xf)
     p_ref = orc.forward(Xc, Xf).y_out.numpy()
