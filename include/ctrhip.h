@@ -95,12 +95,14 @@ int ctr_embed_onehot_fwd(const float* tables, const int64_t* row_offset, const i
 
 /* Backward of the front end with respect to Z (gradient of DeepFM/DeepFM.py:55-66):
  *   dZ[b,n,e] = gz[b,n,e] + g_first[b,n]*keep_first + g_second[b,e]*keep_second*(s[b,e] - Z[b,n,e])
+ *               + g_sum[b,e]
  * Every g* term is optional.  z (the forward's Z, leading dimension z_ld) is needed only
- * with g_second.  dz may alias gz (in-place).  N is the number of rows of Z per sample. */
+ * with g_second; g_sum ([B,E] contiguous) is a gradient with respect to s = sum_n Z (PNN outer
+ * product, PNN/PNN.py:83).  dz may alias gz (in-place).  N = rows of Z per sample. */
 int ctr_embed_bwd_dz(const float* gz, int64_t gz_ld,
                      const float* g_first, int64_t g_first_ld,
                      const float* g_second, int64_t g_second_ld,
-                     const float* s, const float* z, int64_t z_ld,
+                     const float* s, const float* z, int64_t z_ld, const float* g_sum,
                      int B, int N, int E,
                      const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second,
                      float* dz, int64_t dz_ld, void* stream);
@@ -255,6 +257,42 @@ int ctr_cross_bwd(const float* x0, int64_t x0_ld, const float* w, const float* b
                   int B, int D, int L,
                   float* dx0, int64_t dx0_ld, int accumulate, float* dw, float* db,
                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * PNN product layer pieces (PNN/PNN.py:61-96).  lz and the outer-product contraction are plain
+ * GEMMs (ctr_gemm_f32); these are the parts that are not.
+ *   inner: u[b,p,e] = sum_n Z[b,n,e]*w[p,n];  usq_out[b,p] = sum_e u^2.  The reference's
+ *          lp[p] = ||u_p||_F over the WHOLE batch is sqrt(column sum of usq) (ctr_colsum + ctr_vec_op).
+ *   inner backward: du[b,p,e] = coef * u[b,p,e] with coef = coef[p] (coef_ld == 0) or
+ *          coef[b*coef_ld + p];  dz += du . w;  dw_out[p,n] = sum_{b,e} du * Z.
+ *   outer: ss_out[b, e*E+f] = s[b,e]*s[b,f];  ds_out[b,e] = sum_f (dss[b,e,f]+dss[b,f,e])*s[b,f].
+ * E must be a power of two in [4,64]; P*N <= 4096.
+ * ---------------------------------------------------------------------------------- */
+int ctr_pnn_inner_fwd(const float* z, int64_t z_ld, const float* w, int B, int N, int E, int P,
+                      float* usq_out, void* stream);
+size_t ctr_pnn_inner_bwd_workspace_bytes(int B, int N, int P);
+int ctr_pnn_inner_bwd(const float* z, int64_t z_ld, const float* w, const float* coef, int64_t coef_ld,
+                      int B, int N, int E, int P, float* dz, int64_t dz_ld, float* dw_out,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int ctr_outer_fwd(const float* s, int B, int E, float* ss_out, void* stream);
+int ctr_outer_bwd(const float* dss, const float* s, int B, int E, float* ds_out, void* stream);
+/* x[r,c] = dropout(relu?(x[r,c] + bias1[c] + bias2[c])) in place (PNN/PNN.py:95-96). */
+int ctr_bias_act(float* x, int64_t ld, int rows, int cols, const float* bias1, const float* bias2,
+                 int relu, const ctr_dropout_t* drop, void* stream);
+/* kind 0: out = sqrt(a);  kind 1: out = b != 0 ? a/b : 0   (n-element vectors) */
+int ctr_vec_op(int kind, const float* a, const float* b, float* out, int n, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * AFM pair layer with the reference's attention (AFM/AFM.py:60-85): the softmax is taken over
+ * a size-1 axis, so all attention weights are exactly 1 and the attention variables receive
+ * zero gradient;  x[b,e] = sum_{i<j} m_ij * Z[b,i,e]*Z[b,j,e]  with m_ij the dropout multiplier
+ * of pair k = lexicographic index of (i,j) (dropout element b*P + k, P = N(N-1)/2).
+ * Backward: dz[b,i,e] = dx[b,e] * sum_{j != i} m_ij * Z[b,j,e].
+ * ---------------------------------------------------------------------------------- */
+int ctr_afm_pair_fwd(const float* z, int64_t z_ld, int B, int N, int E,
+                     const ctr_dropout_t* pair_drop, float* x_out, void* stream);
+int ctr_afm_pair_bwd(const float* z, int64_t z_ld, const float* dx, int B, int N, int E,
+                     const ctr_dropout_t* pair_drop, float* dz, int64_t dz_ld, void* stream);
 
 /* g[r,c] = act[r,c] > 0 ? g[r,c]*scale : 0 — gradient of relu followed by dropout through a
  * layer whose stored output is `act` (DeepFM/DeepFM.py:71-72). */

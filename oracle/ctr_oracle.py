@@ -249,6 +249,9 @@ def pnn_forward(P, cfg, X_cate, X_cont, masks=None, literal=False):
         if literal:
             lp = torch.cat([torch.linalg.norm((Z * w[i].view(1, -1, 1)).sum(1)).view(1, 1)
                             for i in range(cfg.product_size)], dim=1)   # [1,Pn] batch-global norm
+        elif getattr(cfg, 'inner_mode', 'batch_global') == 'per_sample':
+            u = torch.einsum('bne,pn->bpe', Z, w)          # canonical IPNN option (not the reference's)
+            lp = torch.sqrt((u * u).sum(dim=2))
         else:
             u = torch.einsum('bne,pn->pbe', Z, w)
             lp = torch.sqrt((u * u).sum(dim=(1, 2))).view(1, -1)

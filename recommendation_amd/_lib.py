@@ -49,7 +49,7 @@ SIGNATURES = {
     'ctr_fm_fwd': (i, [vp, i64, i, i, i, vp, i64, vp, vp, i64, DP, DP, vp]),
     'ctr_relu_mask_apply': (i, [vp, i64, vp, i64, i, i, f, vp]),
     'ctr_embed_onehot_fwd': (i, [vp, vp, vp, vp, i, i, i, i, vp, i64, i, vp, vp]),
-    'ctr_embed_bwd_dz': (i, [vp, i64, vp, i64, vp, i64, vp, vp, i64, i, i, i, DP, DP, vp, i64, vp]),
+    'ctr_embed_bwd_dz': (i, [vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i, i, i, DP, DP, vp, i64, vp]),
     'ctr_emb_sort_workspace_bytes': (sz, [i64]),
     'ctr_emb_sort': (i, [vp, vp, i, i, i, i64, i, vp, vp, vp, sz, vp]),
     'ctr_sort_pairs': (i, [vp, vp, i64, i, vp, vp, vp, sz, vp]),
@@ -69,6 +69,15 @@ SIGNATURES = {
     'ctr_cross_fwd': (i, [vp, i64, vp, vp, i64, i, i, i, vp, i64, vp, vp, sz, vp]),
     'ctr_cross_bwd_workspace_bytes': (sz, [i, i, i]),
     'ctr_cross_bwd': (i, [vp, i64, vp, vp, i64, vp, vp, i64, i, i, i, vp, i64, i, vp, vp, vp, sz, vp]),
+    'ctr_pnn_inner_fwd': (i, [vp, i64, vp, i, i, i, i, vp, vp]),
+    'ctr_pnn_inner_bwd_workspace_bytes': (sz, [i, i, i]),
+    'ctr_pnn_inner_bwd': (i, [vp, i64, vp, vp, i64, i, i, i, i, vp, i64, vp, vp, sz, vp]),
+    'ctr_outer_fwd': (i, [vp, i, i, vp, vp]),
+    'ctr_outer_bwd': (i, [vp, vp, i, i, vp, vp]),
+    'ctr_bias_act': (i, [vp, i64, i, i, vp, vp, i, DP, vp]),
+    'ctr_vec_op': (i, [i, vp, vp, vp, i, vp]),
+    'ctr_afm_pair_fwd': (i, [vp, i64, i, i, i, DP, vp, vp]),
+    'ctr_afm_pair_bwd': (i, [vp, i64, vp, i, i, i, DP, vp, i64, vp]),
     'ctr_copy2d': (i, [vp, i64, vp, i64, i, i, i, vp]),
     'ctr_dropout_apply': (i, [vp, i64, i, i, DP, vp]),
 }

@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256) void embed_onehot_fwd_kernel(
 __global__ __launch_bounds__(256) void embed_bwd_dz_kernel(
     const float* gz, int64_t gz_ld, const float* __restrict__ g_first, int64_t g_first_ld,
     const float* __restrict__ g_second, int64_t g_second_ld, const float* __restrict__ s,
-    const float* __restrict__ z, int64_t z_ld, int B, int N, int E, Drop d_first, Drop d_second,
-    float* dz, int64_t dz_ld) {
+    const float* __restrict__ z, int64_t z_ld, const float* __restrict__ g_sum, int B, int N, int E,
+    Drop d_first, Drop d_second, float* dz, int64_t dz_ld) {
   const int G = E / 4;
   const int64_t total = (int64_t)B * N * G;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total;
@@ -144,6 +144,10 @@ __global__ __launch_bounds__(256) void embed_bwd_dz_kernel(
       a.y += g2[1] * drop_mul(d_second, base + 1) * (ss.y - zz.y);
       a.z += g2[2] * drop_mul(d_second, base + 2) * (ss.z - zz.z);
       a.w += g2[3] * drop_mul(d_second, base + 3) * (ss.w - zz.w);
+    }
+    if (g_sum) {
+      const float4 gs = *reinterpret_cast<const float4*>(g_sum + b * E + g * 4);
+      a.x += gs.x; a.y += gs.y; a.z += gs.z; a.w += gs.w;
     }
     *reinterpret_cast<float4*>(dz + b * dz_ld + (int64_t)n * E + g * 4) = a;
   }
@@ -240,19 +244,20 @@ extern "C" int ctr_embed_onehot_fwd(const float* tables, const int64_t* row_offs
 
 extern "C" int ctr_embed_bwd_dz(const float* gz, int64_t gz_ld, const float* g_first,
                                 int64_t g_first_ld, const float* g_second, int64_t g_second_ld,
-                                const float* s, const float* z, int64_t z_ld, int B, int N, int E,
-                                const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second,
-                                float* dz, int64_t dz_ld, void* stream) {
+                                const float* s, const float* z, int64_t z_ld, const float* g_sum, int B,
+                                int N, int E, const ctr_dropout_t* drop_first,
+                                const ctr_dropout_t* drop_second, float* dz, int64_t dz_ld, void* stream) {
   CTR_REQUIRE(B >= 0 && N >= 0 && E >= 4 && E % 4 == 0, "ctr_embed_bwd_dz: bad size");
   CTR_REQUIRE(dz && dz_ld % 4 == 0 && ((uintptr_t)dz % 16) == 0, "ctr_embed_bwd_dz: dz alignment");
   CTR_REQUIRE(!gz || (gz_ld % 4 == 0 && ((uintptr_t)gz % 16) == 0), "ctr_embed_bwd_dz: gz alignment");
   CTR_REQUIRE(!g_second || (s && z && z_ld % 4 == 0 && ((uintptr_t)z % 16) == 0 && ((uintptr_t)s % 16) == 0),
               "ctr_embed_bwd_dz: g_second needs s and z (16-byte aligned)");
+  CTR_REQUIRE(!g_sum || ((uintptr_t)g_sum % 16) == 0, "ctr_embed_bwd_dz: g_sum alignment");
   const int64_t total = (int64_t)B * N * (E / 4);
   if (total == 0) return CTR_OK;
   const int64_t blocks = cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096;
   hipLaunchKernelGGL(embed_bwd_dz_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gz,
-                     gz_ld, g_first, g_first_ld, g_second, g_second_ld, s, z, z_ld, B, N, E,
+                     gz_ld, g_first, g_first_ld, g_second, g_second_ld, s, z, z_ld, g_sum, B, N, E,
                      make_drop(drop_first), make_drop(drop_second), dz, dz_ld);
   CTR_LAUNCH_CHECK();
   return CTR_OK;

@@ -198,7 +198,7 @@ def embed_onehot_fwd(tables, row_offset, idx, x_cont, *, E, z_out, cont_tail=Fal
 
 
 @_timed
-def embed_bwd_dz(dz, *, B, N, E, gz=None, g_first=None, g_second=None, s=None, z=None,
+def embed_bwd_dz(dz, *, B, N, E, gz=None, g_first=None, g_second=None, s=None, z=None, g_sum=None,
                  drop_first=None, drop_second=None):
     dzp, dzld = _rows(dz, 'dz')
     gzp, gzld = (None, 0) if gz is None else _rows(gz, 'gz')
@@ -209,7 +209,10 @@ def embed_bwd_dz(dz, *, B, N, E, gz=None, g_first=None, g_second=None, s=None, z
                      (z, N * E, 'z')):
         if t is not None and (t.shape[0] != B or t.shape[1] < w):
             raise ValueError('%s too small' % nm)
-    check(lib().ctr_embed_bwd_dz(gzp, gzld, g1p, g1ld, g2p, g2ld, _ptr(s, torch.float32), zp, zld, B, N, E,
+    if g_sum is not None and (tuple(g_sum.shape) != (B, E) or not g_sum.is_contiguous()):
+        raise ValueError('g_sum must be contiguous [B,E]')
+    check(lib().ctr_embed_bwd_dz(gzp, gzld, g1p, g1ld, g2p, g2ld, _ptr(s, torch.float32), zp, zld,
+                                 _ptr(g_sum, torch.float32), B, N, E,
                                  _dp(drop_first), _dp(drop_second), dzp, dzld, _stream()), 'ctr_embed_bwd_dz')
 
 
@@ -413,3 +416,89 @@ def dropout_apply(x, drop):
     rows, cols = x.shape
     xp, ld = _rows(x, 'x')
     check(lib().ctr_dropout_apply(xp, ld, rows, cols, C.byref(drop), _stream()), 'ctr_dropout_apply')
+
+
+# ------------------------------------------------------------------ PNN / AFM interaction pieces
+@_timed
+def pnn_inner_fwd(z, w, usq, *, N, E):
+    B = z.shape[0]
+    P = w.shape[0]
+    zp, zld = _rows(z, 'z')
+    if tuple(w.shape) != (P, N) or not w.is_contiguous() or tuple(usq.shape) != (B, P) or not usq.is_contiguous():
+        raise ValueError('pnn_inner_fwd shape mismatch')
+    check(lib().ctr_pnn_inner_fwd(zp, zld, _ptr(w, torch.float32), B, N, E, P, _ptr(usq, torch.float32), _stream()),
+          'ctr_pnn_inner_fwd')
+
+
+@_timed
+def pnn_inner_bwd(z, w, coef, dz, dw, *, N, E, ws):
+    B = z.shape[0]
+    P = w.shape[0]
+    zp, zld = _rows(z, 'z')
+    dp, dld = _rows(dz, 'dz')
+    coef_ld = 0 if coef.dim() == 1 else int(coef.stride(0))
+    if coef.dim() == 2 and (coef.shape[0] != B or coef.shape[1] < P):
+        raise ValueError('coef must be [P] or [B,P]')
+    if dw.numel() != P * N or not dw.is_contiguous():
+        raise ValueError('dw must be contiguous [P,N]')
+    wp, wn = ws.get(lib().ctr_pnn_inner_bwd_workspace_bytes(B, N, P))
+    check(lib().ctr_pnn_inner_bwd(zp, zld, _ptr(w, torch.float32), _ptr(coef, torch.float32), coef_ld, B, N, E, P,
+                                  dp, dld, _ptr(dw, torch.float32), wp, wn, _stream()), 'ctr_pnn_inner_bwd')
+
+
+@_timed
+def outer_fwd(s, ss):
+    B, E = s.shape
+    if tuple(ss.shape) != (B, E * E) or not ss.is_contiguous() or not s.is_contiguous():
+        raise ValueError('outer_fwd shape mismatch')
+    check(lib().ctr_outer_fwd(_ptr(s, torch.float32), B, E, _ptr(ss, torch.float32), _stream()), 'ctr_outer_fwd')
+
+
+@_timed
+def outer_bwd(dss, s, ds):
+    B, E = s.shape
+    if tuple(dss.shape) != (B, E * E) or not dss.is_contiguous() or tuple(ds.shape) != (B, E) or not ds.is_contiguous():
+        raise ValueError('outer_bwd shape mismatch')
+    check(lib().ctr_outer_bwd(_ptr(dss, torch.float32), _ptr(s, torch.float32), B, E, _ptr(ds, torch.float32),
+                              _stream()), 'ctr_outer_bwd')
+
+
+@_timed
+def bias_act(x, bias1=None, bias2=None, relu=False, dropout=None):
+    rows, cols = x.shape
+    xp, ld = _rows(x, 'x')
+    for b in (bias1, bias2):
+        if b is not None and b.numel() != cols:
+            raise ValueError('bias must have one value per column')
+    check(lib().ctr_bias_act(xp, ld, rows, cols, _ptr(bias1, torch.float32), _ptr(bias2, torch.float32), int(relu),
+                             _dp(dropout), _stream()), 'ctr_bias_act')
+
+
+@_timed
+def vec_op(kind, a, b, out):
+    n = out.numel()
+    if a.numel() != n or (b is not None and b.numel() != n):
+        raise ValueError('vec_op size mismatch')
+    check(lib().ctr_vec_op(int(kind), _ptr(a, torch.float32), _ptr(b, torch.float32), _ptr(out, torch.float32), n,
+                           _stream()), 'ctr_vec_op')
+
+
+@_timed
+def afm_pair_fwd(z, x_out, *, N, E, pair_drop=None):
+    B = z.shape[0]
+    zp, zld = _rows(z, 'z')
+    if tuple(x_out.shape) != (B, E) or not x_out.is_contiguous() or z.shape[1] < N * E:
+        raise ValueError('afm_pair_fwd shape mismatch')
+    check(lib().ctr_afm_pair_fwd(zp, zld, B, N, E, _dp(pair_drop), _ptr(x_out, torch.float32), _stream()),
+          'ctr_afm_pair_fwd')
+
+
+@_timed
+def afm_pair_bwd(z, dx, dz, *, N, E, pair_drop=None):
+    B = z.shape[0]
+    zp, zld = _rows(z, 'z')
+    dp, dld = _rows(dz, 'dz')
+    if tuple(dx.shape) != (B, E) or not dx.is_contiguous() or dz.shape[1] < N * E:
+        raise ValueError('afm_pair_bwd shape mismatch')
+    check(lib().ctr_afm_pair_bwd(zp, zld, _ptr(dx, torch.float32), B, N, E, _dp(pair_drop), dp, dld, _stream()),
+          'ctr_afm_pair_bwd')

@@ -23,16 +23,25 @@ def _build(sess, model_name, cfg, P):
     return m
 
 
-MODELS = ['DeepFM', 'DCN', 'NFM', 'ESMM']
+MODELS = ['DeepFM', 'DCN', 'NFM', 'ESMM', 'PNN', 'PNN_outer', 'PNN_persample', 'AFM']
 
 
 @pytest.mark.parametrize('mode', ['R', 'S'])
 @pytest.mark.parametrize('name', MODELS)
 def test_forward_grads_steps(sess, name, mode):
+    variant, name = name, name.split('_')[0]
     cfg = no_dropout(tiny_cfg(name, mode))
+    if variant == 'PNN_outer':
+        cfg.inner_product = False
+    if variant == 'PNN_persample':
+        cfg.inner_mode = 'per_sample'            # option beyond the reference (per-sample norm)
     cfg.adam_mode = 'tf1'
+    # AFM feeds log_loss an unbounded y_out (AFM/AFM.py:85-88); small weights keep 0 < y_out < 1
     P = O.init_params(name, cfg, seed=3, std=0.3)
     Xc, Xf, y = tiny_batch(cfg, B=8)
+    if name == 'AFM':
+        Xf = np.abs(Xf) * 0.5
+        P = {k: np.abs(v) for k, v in P.items()}
     orc = O.OracleModel(name, cfg, P, dtype=torch.float64)
     m = _build(sess, name, cfg, P)
     # forward
@@ -96,5 +105,28 @@ def test_deepfm_dropout_masks_match_hash(sess):
     loss_ref, g_ref, _ = orc.loss_and_grads(Xc, Xf, y, masks)
     loss_gpu = m.run(sess, Xc, Xf, y, True)
     assert abs(float(loss_gpu) - float(loss_ref)) < 1e-5
+    for k, v in m.get_grads().items():
+        assert rel_err(v, g_ref[k].numpy()) < 5e-5, k
+
+
+def test_afm_pair_and_output_dropout_match_hash(sess):
+    """AFM in training mode: per-pair dropout on the (constant 1) attention weights and dropout on
+    the pooled vector, both through the shared counter hash (AFM/AFM.py:80,84)."""
+    cfg = tiny_cfg('AFM', 'S')
+    cfg.dropout = 0.4
+    P = {k: np.abs(v) for k, v in O.init_params('AFM', cfg, seed=6, std=0.1).items()}
+    Xc, Xf, y = tiny_batch(cfg, B=16, seed=3, oor=False)
+    Xf = np.abs(Xf) * 0.3
+    m = _build(sess, 'AFM', cfg, P)
+    B, N, E = 16, cfg.cate_num + cfg.cont_num, cfg.embed_size
+    npairs = N * (N - 1) // 2
+    seed = sess.seed * 1000003 + 0
+    masks = {'att': torch.as_tensor(O.keep_mask(seed, 4, B * npairs, 0.6).reshape(B, npairs, 1)),
+             'out': torch.as_tensor(O.keep_mask(seed, 5, B * E, 0.6).reshape(B, E))}
+    orc = O.OracleModel('AFM', cfg, P, dtype=torch.float64)
+    loss_ref, g_ref, out = orc.loss_and_grads(Xc, Xf, y, masks)
+    assert torch.isfinite(loss_ref)
+    loss_gpu = m.run(sess, Xc, Xf, y, True)
+    assert abs(float(loss_gpu) - float(loss_ref)) < 1e-5 * max(1.0, abs(float(loss_ref)))
     for k, v in m.get_grads().items():
         assert rel_err(v, g_ref[k].numpy()) < 5e-5, k
