@@ -211,7 +211,8 @@ int ctr_rowdot_bwd_x(const float* g, const float* w, int B, int K,
  *   CTR_LOSS_SIGMOID_SCE_PROB  y_out = sigmoid(x);  loss = sce(labels=y, logits=y_out)
  *   CTR_LOSS_SCE_LOGIT         y_out = sigmoid(x);  loss = sce(labels=y, logits=x)
  *   CTR_LOSS_PROB_SCE          y_out = x (already a probability); loss = sce(labels=y, logits=x)
- * loss_out[0] = mean over B (fixed-order reduction); dx[b] = d loss / d x[b].
+ * loss_out[0] = mean over B (fixed-order reduction); dx[b] = grad_scale * d loss / d x[b]
+ * (grad_scale = 1, or 1/world_size when B is one rank's share of a data-parallel batch).
  * y_out, dx, loss_out optional; y may be NULL when only y_out is wanted (inference).
  * ---------------------------------------------------------------------------------- */
 #define CTR_LOSS_SIGMOID_LOGLOSS 0
@@ -220,14 +221,14 @@ int ctr_rowdot_bwd_x(const float* g, const float* w, int B, int K,
 #define CTR_LOSS_SCE_LOGIT 3
 #define CTR_LOSS_PROB_SCE 4
 size_t ctr_loss_head_workspace_bytes(int B);
-int ctr_loss_head(int kind, const float* x, const float* y, int B,
+int ctr_loss_head(int kind, const float* x, const float* y, int B, float grad_scale,
                   float* y_out, float* loss_out, float* dx,
                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* ESMM head (ESMM/ESMM.py:95-98): y_out = sigmoid(ctr) * sigmoid(cvr);
  * loss = mean sigmoid_cross_entropy_with_logits(labels=y, logits=y_out) (y_out is already a
  * probability; reproduced as written).  dctr/dcvr = d loss / d logits.  Workspace as ctr_loss_head. */
-int ctr_esmm_head(const float* ctr_logit, const float* cvr_logit, const float* y, int B,
+int ctr_esmm_head(const float* ctr_logit, const float* cvr_logit, const float* y, int B, float grad_scale,
                   float* y_out, float* loss_out, float* dctr, float* dcvr,
                   void* workspace, size_t workspace_bytes, void* stream);
 

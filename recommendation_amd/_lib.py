@@ -62,8 +62,8 @@ SIGNATURES = {
     'ctr_rowdot_fwd': (i, [vp, i64, vp, vp, i, i, vp, vp]),
     'ctr_rowdot_bwd_x': (i, [vp, vp, i, i, vp, i64, i, vp]),
     'ctr_loss_head_workspace_bytes': (sz, [i]),
-    'ctr_loss_head': (i, [i, vp, vp, i, vp, vp, vp, vp, sz, vp]),
-    'ctr_esmm_head': (i, [vp, vp, vp, i, vp, vp, vp, vp, vp, sz, vp]),
+    'ctr_loss_head': (i, [i, vp, vp, i, f, vp, vp, vp, vp, sz, vp]),
+    'ctr_esmm_head': (i, [vp, vp, vp, i, f, vp, vp, vp, vp, vp, sz, vp]),
     'ctr_dense_update': (i, [vp, vp, vp, vp, i64, C.POINTER(Opt), vp]),
     'ctr_cross_fwd_workspace_bytes': (sz, [i, i]),
     'ctr_cross_fwd': (i, [vp, i64, vp, vp, i64, i, i, i, vp, i64, vp, vp, sz, vp]),

@@ -81,11 +81,11 @@ __device__ static inline float sce_(float x, float z) { return fmaxf(x, 0.f) - x
 // Pass 1: 256 samples per block -> y_out, dx and one partial loss sum per block.
 // Pass 2: one block adds the partials in a fixed order.
 __global__ __launch_bounds__(256) void loss_head_kernel(int kind, const float* __restrict__ x,
-                                                       const float* __restrict__ y, int B,
+                                                       const float* __restrict__ y, int B, float grad_scale,
                                                        float* __restrict__ y_out, float* __restrict__ dx,
                                                        float* __restrict__ part) {
   __shared__ float red[256];
-  const float invB = 1.f / (float)B;
+  const float invB = grad_scale / (float)B;
   const float eps = 1e-7f;
   float l = 0.f;
   const int b = blockIdx.x * 256 + threadIdx.x;
@@ -125,11 +125,11 @@ __global__ __launch_bounds__(256) void loss_head_kernel(int kind, const float* _
 
 // ESMM head (ESMM/ESMM.py:95-98): y_out = sigmoid(a) * sigmoid(c); loss = sce(labels=y, logits=y_out)
 __global__ __launch_bounds__(256) void esmm_head_kernel(const float* __restrict__ a, const float* __restrict__ c,
-                                                       const float* __restrict__ y, int B,
+                                                       const float* __restrict__ y, int B, float grad_scale,
                                                        float* __restrict__ y_out, float* __restrict__ da,
                                                        float* __restrict__ dc, float* __restrict__ part) {
   __shared__ float red[256];
-  const float invB = 1.f / (float)B;
+  const float invB = grad_scale / (float)B;
   float l = 0.f;
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b < B) {
@@ -274,8 +274,8 @@ extern "C" int ctr_rowdot_bwd_x(const float* g, const float* w, int B, int K, fl
 
 extern "C" size_t ctr_loss_head_workspace_bytes(int B) { return (size_t)cdiv(B > 0 ? B : 1, 256) * sizeof(float); }
 
-extern "C" int ctr_loss_head(int kind, const float* x, const float* y, int B, float* y_out, float* loss_out,
-                             float* dx, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int ctr_loss_head(int kind, const float* x, const float* y, int B, float grad_scale, float* y_out,
+                             float* loss_out, float* dx, void* workspace, size_t workspace_bytes, void* stream) {
   CTR_REQUIRE(kind >= 0 && kind <= CTR_LOSS_PROB_SCE, "ctr_loss_head: unknown kind %d", kind);
   CTR_REQUIRE(B > 0 && x, "ctr_loss_head: bad argument");
   CTR_REQUIRE(y || (!loss_out && !dx), "ctr_loss_head: labels are required for loss / gradient");
@@ -289,7 +289,7 @@ extern "C" int ctr_loss_head(int kind, const float* x, const float* y, int B, fl
     part = (float*)workspace;
   }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(loss_head_kernel, dim3(nb), dim3(256), 0, st, kind, x, y, B, y_out, dx, part);
+  hipLaunchKernelGGL(loss_head_kernel, dim3(nb), dim3(256), 0, st, kind, x, y, B, grad_scale, y_out, dx, part);
   if (loss_out) hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, part, nb, B, loss_out);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
@@ -329,9 +329,9 @@ extern "C" int ctr_relu_mask_apply(float* g, int64_t g_ld, const float* act, int
   return CTR_OK;
 }
 
-extern "C" int ctr_esmm_head(const float* ctr_logit, const float* cvr_logit, const float* y, int B, float* y_out,
-                             float* loss_out, float* dctr, float* dcvr, void* workspace, size_t workspace_bytes,
-                             void* stream) {
+extern "C" int ctr_esmm_head(const float* ctr_logit, const float* cvr_logit, const float* y, int B,
+                             float grad_scale, float* y_out, float* loss_out, float* dctr, float* dcvr,
+                             void* workspace, size_t workspace_bytes, void* stream) {
   CTR_REQUIRE(B > 0 && ctr_logit && cvr_logit, "ctr_esmm_head: bad argument");
   CTR_REQUIRE(y || (!loss_out && !dctr && !dcvr), "ctr_esmm_head: labels are required for loss / gradient");
   const int nb = (int)cdiv(B, 256);
@@ -344,8 +344,8 @@ extern "C" int ctr_esmm_head(const float* ctr_logit, const float* cvr_logit, con
     part = (float*)workspace;
   }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(esmm_head_kernel, dim3(nb), dim3(256), 0, st, ctr_logit, cvr_logit, y, B, y_out, dctr, dcvr,
-                     part);
+  hipLaunchKernelGGL(esmm_head_kernel, dim3(nb), dim3(256), 0, st, ctr_logit, cvr_logit, y, B, grad_scale, y_out,
+                     dctr, dcvr, part);
   if (loss_out) hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, part, nb, B, loss_out);
   CTR_LAUNCH_CHECK();
   return CTR_OK;

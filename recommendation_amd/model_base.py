@@ -80,6 +80,12 @@ class CTRModel:
             raise ValueError("mode must be 'R' or 'S'")
         self.adam_mode = getattr(args, 'adam_mode', 'tf1' if self.mode == 'R' else 'lazy')
         self.init_std = float(getattr(args, 'init_std', 0.01))
+        # multi-GPU: world_size/rank (+ optional comm object); tables are then sharded table-wise
+        self.world = int(getattr(args, 'world_size', 1))
+        self.rank = int(getattr(args, 'rank', 0))
+        self.comm = getattr(args, 'comm', None)
+        if self.world > 1 and self.mode != 'S':
+            raise ValueError("multi-GPU runs use mode 'S' (the dense R-mode block exists only at parity sizes)")
         self.global_step = 0
         self._built = False
         self._ready = False
@@ -116,9 +122,18 @@ class CTRModel:
             raise RuntimeError('call build() first')
         dev = session.device
         self.session = session
-        self.tables = EmbeddingTables(self.cate_list, self.embed_size, dev)
         self.dense = DenseParams(self.dense_shapes, dev)
-        self.front = EmbedFront(self.tables, self.mode, self.cont_num, self.CONT_EMBED)
+        if self.world > 1:
+            from .distributed import ShardedFront, TorchComm
+            if self.comm is None:
+                self.comm = TorchComm()
+            self.front = ShardedFront(self.cate_list, self.embed_size, self.cont_num, self.CONT_EMBED, self.comm, dev)
+            self.tables = self.front.t                      # this rank's shard
+            self._own = (self.front.a, self.front.b)
+        else:
+            self.tables = EmbeddingTables(self.cate_list, self.embed_size, dev)
+            self.front = EmbedFront(self.tables, self.mode, self.cont_num, self.CONT_EMBED)
+            self._own = (0, self.cate_num)
         self.tables.init_slots(self.OPTIMIZER, dense_adam=(self.adam_mode == 'tf1'))
         self.dense.init_slots(self.OPTIMIZER)
         self._loss_dev = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -151,14 +166,16 @@ class CTRModel:
         for k, v in params.items():
             t = torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32))
             if k.startswith('embedding/embed_cate_w_'):
-                self.tables.table(int(k.rsplit('_', 1)[1])).copy_(t)
+                f = int(k.rsplit('_', 1)[1])
+                if self._own[0] <= f < self._own[1]:
+                    self.tables.table(f - self._own[0]).copy_(t)
             else:
                 self.dense.p(k).copy_(t.reshape(self.dense.shapes[k]))
 
     def get_params(self):
         out = OrderedDict()
-        for f in range(self.cate_num):
-            out['embedding/embed_cate_w_%d' % f] = self.tables.table(f).cpu().numpy()
+        for f in range(*self._own):                       # sharded: only the fields this rank owns
+            out['embedding/embed_cate_w_%d' % f] = self.tables.table(f - self._own[0]).cpu().numpy()
         for k in self.dense.shapes:
             out[k] = self.dense.p(k).cpu().numpy()
         return out
@@ -167,8 +184,8 @@ class CTRModel:
         """Dense-variable gradients of the last training step (tables: only with adam_mode 'tf1')."""
         out = OrderedDict((k, self.dense.g(k).cpu().numpy()) for k in self.dense.shapes)
         if self.tables.grad is not None:
-            for f in range(self.cate_num):
-                out['embedding/embed_cate_w_%d' % f] = self.tables.table(f, self.tables.grad).cpu().numpy()
+            for f in range(*self._own):
+                out['embedding/embed_cate_w_%d' % f] = self.tables.table(f - self._own[0], self.tables.grad).cpu().numpy()
         return out
 
     def _state_dict(self):
@@ -251,6 +268,8 @@ class CTRModel:
         self._forward(idx, xc, bufs, True)
         self._loss(bufs, yy, True)
         self._backward(idx, xc, bufs)
+        if self.world > 1:
+            self.comm.all_reduce_sum(self.dense.grad)       # loss gradient was pre-scaled by 1/world
         self.dense.apply(self._optimizer())
         self.global_step += 1
         return self._loss_dev
@@ -283,7 +302,7 @@ class CTRModel:
     def _loss(self, bufs, yy, train):
         if train:
             ops.loss_head(self.LOSS_KIND, bufs['logit'], yy, y_out=bufs['y_out'], loss_out=self._loss_dev,
-                          dx=bufs['dlogit'], ws=self.session.ws)
+                          dx=bufs['dlogit'], ws=self.session.ws, grad_scale=1.0 / self.world)
         else:
             ops.loss_head(self.LOSS_KIND, bufs['logit'], None, y_out=bufs['y_out'])
 

@@ -327,20 +327,21 @@ def rowdot_bwd_x(g, w, dX, accumulate=False):
 
 
 @_timed
-def loss_head(kind, x, y, *, y_out=None, loss_out=None, dx=None, ws=None):
+def loss_head(kind, x, y, *, y_out=None, loss_out=None, dx=None, ws=None, grad_scale=1.0):
     B = x.numel()
     if y is not None and y.numel() != B:
         raise ValueError('loss_head: label count mismatch')
     wp, wn = (None, 0)
     if loss_out is not None:
         wp, wn = ws.get(lib().ctr_loss_head_workspace_bytes(B))
-    check(lib().ctr_loss_head(int(kind), _ptr(x, torch.float32), _ptr(y, torch.float32), B,
+    check(lib().ctr_loss_head(int(kind), _ptr(x, torch.float32), _ptr(y, torch.float32), B, float(grad_scale),
                               _ptr(y_out, torch.float32), _ptr(loss_out, torch.float32), _ptr(dx, torch.float32),
                               wp, wn, _stream()), 'ctr_loss_head')
 
 
 @_timed
-def esmm_head(ctr_logit, cvr_logit, y, *, y_out=None, loss_out=None, dctr=None, dcvr=None, ws=None):
+def esmm_head(ctr_logit, cvr_logit, y, *, y_out=None, loss_out=None, dctr=None, dcvr=None, ws=None,
+              grad_scale=1.0):
     B = ctr_logit.numel()
     if cvr_logit.numel() != B or (y is not None and y.numel() != B):
         raise ValueError('esmm_head size mismatch')
@@ -348,7 +349,8 @@ def esmm_head(ctr_logit, cvr_logit, y, *, y_out=None, loss_out=None, dctr=None, 
     if loss_out is not None:
         wp, wn = ws.get(lib().ctr_loss_head_workspace_bytes(B))
     f32 = torch.float32
-    check(lib().ctr_esmm_head(_ptr(ctr_logit, f32), _ptr(cvr_logit, f32), _ptr(y, f32), B, _ptr(y_out, f32),
+    check(lib().ctr_esmm_head(_ptr(ctr_logit, f32), _ptr(cvr_logit, f32), _ptr(y, f32), B, float(grad_scale),
+                              _ptr(y_out, f32),
                               _ptr(loss_out, f32), _ptr(dctr, f32), _ptr(dcvr, f32), wp, wn, _stream()),
           'ctr_esmm_head')
 

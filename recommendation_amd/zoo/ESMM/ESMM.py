@@ -33,7 +33,7 @@ class ESMM(CTRModel):
     def _alloc(self, B, bufs, dev):
         Ls = self.deep_layers
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
-        if self.mode == 'R':
+        if self.mode == 'R' or self.world > 1:
             bufs['z'] = z(B, self.N * self.embed_size)
         bufs['inp'] = z(B, round_up(self.d_in, 4))
         bufs['dinp'] = z(B, round_up(self.d_in, 4))
@@ -58,7 +58,8 @@ class ESMM(CTRModel):
     def _loss(self, bufs, yy, train):
         if train:
             ops.esmm_head(bufs['ctr_logit'], bufs['cvr_logit'], yy, y_out=bufs['y_out'], loss_out=self._loss_dev,
-                          dctr=bufs['ctr_dlogit'], dcvr=bufs['cvr_dlogit'], ws=self.session.ws)
+                          dctr=bufs['ctr_dlogit'], dcvr=bufs['cvr_dlogit'], ws=self.session.ws,
+                          grad_scale=1.0 / self.world)
         else:
             ops.esmm_head(bufs['ctr_logit'], bufs['cvr_logit'], None, y_out=bufs['y_out'])
 

@@ -80,6 +80,8 @@ class PNN(CTRModel):
             ops.pnn_inner_fwd(bufs['z'], d.p('product/lp_inner_w'), bufs['usq'], N=N, E=E)
             if self.inner_mode == 'batch_global':
                 ops.colsum(bufs['usq'], bufs['usq_sum'], ws=ws)
+                if self.world > 1:                       # the norm runs over the whole (global) batch
+                    self.comm.all_reduce_sum(bufs['usq_sum'])
                 ops.vec_op(0, bufs['usq_sum'], None, bufs['lp'])                                  # lp[p] = ||u_p||_F
                 ops.bias_act(prod, d.p('product/product_bias'), bufs['lp'], relu=True, dropout=drop)
             else:
@@ -115,6 +117,8 @@ class PNN(CTRModel):
         if self.inner_product:
             if self.inner_mode == 'batch_global':
                 ops.colsum(gpre, bufs['gsum'], ws=ws)
+                if self.world > 1:
+                    self.comm.all_reduce_sum(bufs['gsum'])
                 ops.vec_op(1, bufs['gsum'], bufs['lp'], bufs['coef'])          # d lp / d u = u / lp
                 coef = bufs['coef']
             else:

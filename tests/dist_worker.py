@@ -1,0 +1,89 @@
+"""Worker of the 2-rank equivalence test (launched by torch.distributed.run, gloo group).
+
+Both ranks share cuda:0 on the one-GPU box, so the collectives are staged through host memory
+over gloo (test-only transport; production uses RCCL through distributed.TorchComm).  Each rank
+trains on its half of a global batch; the result must match a single-rank model trained on the
+whole batch: dense variables on every rank, table shards on their owners."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class StagedComm:
+    def __init__(self):
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+
+    def all_to_all(self, out, inp, out_splits, in_splits):
+        from tests.test_distributed_plan import p2p_all_to_all
+        o, i = torch.empty(out.shape, dtype=out.dtype), inp.detach().cpu()
+        p2p_all_to_all(o, i, out_splits, in_splits, self.rank, self.world)
+        out.copy_(o)
+
+    def all_reduce_sum(self, t):
+        c = t.detach().cpu()
+        dist.all_reduce(c)
+        t.copy_(c)
+
+
+def main(model_name):
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import recommendation_amd as ra
+    from oracle import ctr_oracle as O
+    from tests.helpers import rel_err
+    ra.enable_zoo_imports()
+    import importlib
+    cls = getattr(importlib.import_module('%s.%s' % (model_name, model_name)), model_name)
+    cfg = O.default_cfg(model_name, embed_size=8, mode='S')
+    cfg.cate_list = [7, 50, 3, 11, 200]
+    cfg.cate_num, cfg.cont_num = 5, 3
+    for k in ('dropout_fm', 'dropout_deep', 'dropout_bi', 'dropout'):
+        if hasattr(cfg, k):
+            setattr(cfg, k, 0.0)
+    if hasattr(cfg, 'deep_layers'):
+        cfg.deep_layers = [16, 8]
+    if model_name == 'PNN':
+        cfg.hidden_layers, cfg.product_size = [16, 8], 6
+    cfg.adam_mode = 'tf1'
+    P = O.init_params(model_name, cfg, seed=1, std=0.2)
+    rng = np.random.default_rng(5)
+    Bg = 64
+    Xc = np.stack([rng.integers(0, v, Bg) for v in cfg.cate_list], 1)
+    Xf = rng.standard_normal((Bg, 3))
+    y = rng.integers(0, 2, Bg)
+    sess = ra.Session('cuda:0', seed=3)
+    import copy
+    dcfg = copy.copy(cfg)
+    dcfg.world_size, dcfg.rank, dcfg.comm = world, rank, StagedComm()
+    m = cls(dcfg, 5, 3, cfg.cate_list)
+    m.build()
+    m.initialize(sess, params=P)
+    lo, hi = rank * Bg // world, (rank + 1) * Bg // world
+    for _ in range(3):
+        m.run(sess, Xc[lo:hi], Xf[lo:hi], y[lo:hi], True)
+    single = cls(cfg, 5, 3, cfg.cate_list)
+    single.build()
+    single.initialize(sess, params=P)
+    for _ in range(3):
+        single.run(sess, Xc, Xf, y, True)
+    ref = single.get_params()
+    got = m.get_params()
+    n_tab = 0
+    for k, v in got.items():
+        assert rel_err(v, ref[k]) < 2e-5, (rank, k, rel_err(v, ref[k]))
+        n_tab += k.startswith('embedding/embed_cate_w_')
+    assert n_tab == m.front.nf_own
+    dist.barrier()
+    if rank == 0:
+        print('DIST_OK %s' % model_name)
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])

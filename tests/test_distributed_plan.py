@@ -1,0 +1,124 @@
+"""CPU (gloo, world_size 2) test of the sharded-embedding exchange plan: split sizes, buffer
+layouts and block assembly of recommendation_amd.distributed.ShardedFront, with a torch stand-in
+for the device kernels (the stand-in lives here, in the tests; the product has no CPU path)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class TorchBackend:
+    """Minimal CPU restatement of the operators ShardedFront calls."""
+
+    class _Opt:
+        def __init__(self, kind, lr=0.0):
+            self.kind, self.lr = kind, lr
+
+    def make_opt(self, kind, lr=0.0, **kw):
+        return self._Opt(kind, lr)
+
+    def embed_fwd(self, tables, row_offset, idx, x_cont=None, cont_w=None, *, E, z_out=None, cont_tail=False,
+                  oor_count=None, **kw):
+        B, F = idx.shape
+        for f in range(F):
+            off = int(row_offset[f])
+            V = int(row_offset[f + 1]) - off
+            x = idx[:, f].long()
+            ok = (x >= 0) & (x < V)
+            rows = tables[off + torch.where(ok, x, torch.zeros_like(x))] * ok.float().view(-1, 1)
+            z_out[:, f * E:(f + 1) * E] = rows
+
+    def copy2d(self, src, dst, accumulate=False):
+        dst[:, :src.shape[1]] = src
+
+    def fm_fwd(self, z, **kw):
+        raise AssertionError('not used in this test')
+
+    def emb_sort(self, idx, row_offset, *, N, total_rows, rmode, keys_out, src_out, ws):
+        self._idx, self._off = idx.clone(), row_offset
+
+    def emb_sparse_apply(self, keys, src, n_items, *, N, E, total_rows, dz, opt, ws, tables=None, slot0=None,
+                         slot1=None, src_scale=None):
+        idx = self._idx
+        for f in range(idx.shape[1]):
+            off = int(self._off[f])
+            tables.index_add_(0, off + idx[:, f].long(), -opt.lr * dz[:, f * E:(f + 1) * E])
+
+
+def p2p_all_to_all(out, inp, out_splits, in_splits, rank, world):
+    """all-to-all-v from point-to-point sends (gloo has no native alltoall)."""
+    outs, ins = list(out.split(out_splits)), list(inp.split(in_splits))
+    outs[rank].copy_(ins[rank])
+    reqs = []
+    for j in range(world):
+        if j != rank:
+            if ins[j].numel():
+                reqs.append(dist.isend(ins[j].contiguous(), j))
+            if outs[j].numel():
+                reqs.append(dist.irecv(outs[j], j))
+    for r in reqs:
+        r.wait()
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from recommendation_amd.distributed import ShardedFront, field_ranges
+
+    class Comm:
+        def __init__(self):
+            self.world, self.rank = world, rank
+
+        def all_to_all(self, out, inp, out_splits, in_splits):
+            p2p_all_to_all(out, inp, out_splits, in_splits, rank, world)
+
+        def all_reduce_sum(self, t):
+            dist.all_reduce(t)
+
+    cards, E, C, B = [5, 9, 4, 7, 3], 4, 2, 6
+    rng = np.random.default_rng(0)                       # same tables on both ranks
+    full = [torch.tensor(rng.standard_normal((v, E)), dtype=torch.float32) for v in cards]
+    front = ShardedFront(cards, E, C, False, Comm(), torch.device('cpu'), backend=TorchBackend())
+    a, b = front.a, front.b
+    assert (a, b) == field_ranges(5, world)[rank]
+    front.t.weight.copy_(torch.cat(full[a:b]))
+    r2 = np.random.default_rng(100 + rank)               # different batch per rank
+    idx = torch.tensor(np.stack([r2.integers(0, v, B) for v in cards], 1), dtype=torch.int32)
+    xc = torch.tensor(r2.standard_normal((B, C)), dtype=torch.float32)
+    z = torch.zeros(B, len(cards) * E + C)
+    front.forward(idx, xc, z_out=z, cont_tail=True)
+    ref = torch.cat([full[f][idx[:, f].long()] for f in range(5)] + [xc], dim=1)
+    assert torch.equal(z, ref)                           # rows are copies: exact
+    # backward: SGD on the owners with gradients from BOTH ranks' batches
+    dz = torch.tensor(r2.standard_normal((B, len(cards) * E)), dtype=torch.float32)
+    front.backward_tables(idx, dz, None, None, None, TorchBackend._Opt(3, lr=0.5), lazy=True)
+    all_idx = [torch.zeros_like(idx) for _ in range(world)]
+    all_dz = [torch.zeros_like(dz) for _ in range(world)]
+    dist.all_gather(all_idx, idx)
+    dist.all_gather(all_dz, dz)
+    for f in range(a, b):
+        exp = full[f].clone()
+        for i2, d2 in zip(all_idx, all_dz):
+            exp.index_add_(0, i2[:, f].long(), -0.5 * d2[:, f * E:(f + 1) * E])
+        got = front.t.table(f - a)
+        assert torch.allclose(got, exp, atol=1e-6), (rank, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_front_plan_world2():
+    mp.spawn(_worker, args=(2, 29741, None), nprocs=2, join=True)
+
+
+def test_field_ranges():
+    from recommendation_amd.distributed import field_ranges
+    assert field_ranges(26, 8) == [(0, 4), (4, 8), (8, 11), (11, 14), (14, 17), (17, 20), (20, 23), (23, 26)]
+    assert field_ranges(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    assert field_ranges(5, 1) == [(0, 5)]

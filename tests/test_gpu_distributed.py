@@ -1,0 +1,19 @@
+"""2-rank run == 1-rank run (sharded tables + data-parallel towers), on the one-GPU box."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('model', ['DeepFM', 'DCN', 'PNN'])
+def test_two_ranks_match_one_rank(sess, model):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+           '--master-addr', '127.0.0.1', '--master-port', '29731', os.path.join(ROOT, 'tests', 'dist_worker.py'), model]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'DIST_OK %s' % model in r.stdout
