@@ -172,7 +172,7 @@ int ctr_emb_sparse_apply(const uint32_t* keys_sorted, const uint32_t* src_sorted
  * ---------------------------------------------------------------------------------- */
 typedef struct {
   const float* bias;
-  int relu;
+  int relu; /* 0 none, 1 relu, 2 sigmoid (DIN attention MLP, DIN/DIN.py:175-176) */
   int accumulate;
   const ctr_dropout_t* dropout;
   const float* mask_src;
@@ -294,6 +294,41 @@ int ctr_afm_pair_fwd(const float* z, int64_t z_ld, int B, int N, int E,
                      const ctr_dropout_t* pair_drop, float* x_out, void* stream);
 int ctr_afm_pair_bwd(const float* z, int64_t z_ld, const float* dx, int B, int N, int E,
                      const ctr_dropout_t* pair_drop, float* dz, int64_t dz_ld, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * DIN pieces (DIN/DIN.py:17-71,149-196).  The dense layers of the attention MLP and of the
+ * FCN are ctr_gemm_f32 calls over all B*T (resp. B) rows; these are the rest.
+ *   ctr_din_build_idx   out[k] = (ids[k], cate_list[ids[k]]) as int32 pairs: with the item and
+ *                       category tables concatenated as two "fields" of width H/2, ctr_embed_fwd
+ *                       on these pairs yields [item_emb_w[id], cate_emb_w[cate_list[id]]]
+ *                       (DIN/DIN.py:24-42); an id outside [0, item_count) gives (-1,-1) = zero row.
+ *   ctr_din_concat_*    row (b,t) = [q_b, k_bt, q_b - k_bt, q_b * k_bt]  (DIN/DIN.py:171-174)
+ *   ctr_din_attn_pool_* att = softmax(where(t < sl[b], score, -2^32+1) / sqrt(H)) over t;
+ *                       out[b,:] = sum_t att[b,t] K[b,t,:]                (DIN/DIN.py:179-194)
+ *   ctr_bn_infer        tf.layers.batch_normalization with training=False (DIN/DIN.py:45,53)
+ *   ctr_dice_*          dice() with inference-mode statistics             (DIN/DIN.py:149-166)
+ * ---------------------------------------------------------------------------------- */
+int ctr_din_build_idx(const int32_t* ids, const int32_t* cate_list, int64_t n, int item_count,
+                      int32_t* out, void* stream);
+int ctr_din_concat_fwd(const float* q, const float* k, int B, int T, int H, float* out, void* stream);
+int ctr_din_concat_bwd(const float* d_all, const float* q, const float* k, int B, int T, int H,
+                       float* dq, int accumulate_q, float* dk, int accumulate_k, void* stream);
+int ctr_din_attn_pool_fwd(const float* score, const int32_t* sl, const float* K, int B, int T, int H,
+                          float* att_out, float* out, void* stream);
+int ctr_din_attn_pool_bwd(const float* dout, const float* att, const int32_t* sl, const float* K,
+                          int B, int T, int H, float* dscore, float* dK, int accumulate_k, void* stream);
+int ctr_bn_infer(const float* x, int64_t x_ld, int rows, int cols,
+                 const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                 float* y, int64_t y_ld, float* xhat, int64_t xhat_ld, void* stream);
+int ctr_dice_fwd(const float* x, int64_t x_ld, int rows, int cols, const float* alpha, float eps,
+                 float* y, int64_t y_ld, void* stream);
+int ctr_dice_bwd(const float* x, int64_t x_ld, int rows, int cols, const float* alpha, float eps,
+                 const float* dy, int64_t dy_ld, float* dx, int64_t dx_ld,
+                 float* dalpha_src, int64_t dalpha_ld, void* stream);
+/* g[r,c] *= y[r,c]*(1-y[r,c]): backward of a sigmoid layer given its output (DIN/DIN.py:175-176). */
+int ctr_dsigmoid_apply(float* g, int64_t g_ld, const float* y, int64_t y_ld, int rows, int cols, void* stream);
+/* out_mean[0] = mean(a[i] - b[i] > 0)   (mf_auc, DIN/DIN.py:92) */
+int ctr_mean_positive_diff(const float* a, const float* b, int n, float* out_mean, void* stream);
 
 /* g[r,c] = act[r,c] > 0 ? g[r,c]*scale : 0 — gradient of relu followed by dropout through a
  * layer whose stored output is `act` (DeepFM/DeepFM.py:71-72). */

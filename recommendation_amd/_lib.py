@@ -78,6 +78,16 @@ SIGNATURES = {
     'ctr_vec_op': (i, [i, vp, vp, vp, i, vp]),
     'ctr_afm_pair_fwd': (i, [vp, i64, i, i, i, DP, vp, vp]),
     'ctr_afm_pair_bwd': (i, [vp, i64, vp, i, i, i, DP, vp, i64, vp]),
+    'ctr_din_build_idx': (i, [vp, vp, i64, i, vp, vp]),
+    'ctr_din_concat_fwd': (i, [vp, vp, i, i, i, vp, vp]),
+    'ctr_din_concat_bwd': (i, [vp, vp, vp, i, i, i, vp, i, vp, i, vp]),
+    'ctr_din_attn_pool_fwd': (i, [vp, vp, vp, i, i, i, vp, vp, vp]),
+    'ctr_din_attn_pool_bwd': (i, [vp, vp, vp, vp, i, i, i, vp, vp, i, vp]),
+    'ctr_bn_infer': (i, [vp, i64, i, i, vp, vp, vp, vp, f, vp, i64, vp, i64, vp]),
+    'ctr_dice_fwd': (i, [vp, i64, i, i, vp, f, vp, i64, vp]),
+    'ctr_dice_bwd': (i, [vp, i64, i, i, vp, f, vp, i64, vp, i64, vp, i64, vp]),
+    'ctr_dsigmoid_apply': (i, [vp, i64, vp, i64, i, i, vp]),
+    'ctr_mean_positive_diff': (i, [vp, vp, i, vp, vp]),
     'ctr_copy2d': (i, [vp, i64, vp, i64, i, i, i, vp]),
     'ctr_dropout_apply': (i, [vp, i64, i, i, DP, vp]),
 }

@@ -27,7 +27,8 @@ struct Epi {
 __device__ static inline float epilogue(const Epi& e, float v, int m, int n, int N, const float* cptr) {
   if (e.bias) v += e.bias[n];
   if (e.accumulate) v += *cptr;
-  if (e.relu) v = fmaxf(v, 0.f);
+  if (e.relu == 1) v = fmaxf(v, 0.f);
+  else if (e.relu == 2) v = 1.f / (1.f + expf(-v));
   if (e.drop.on) v *= drop_mul(e.drop, (uint64_t)m * (uint64_t)N + (uint64_t)n);
   if (e.mask_src) v = e.mask_src[(int64_t)m * e.mask_ld + n] > 0.f ? v * e.mask_scale : 0.f;
   return v;

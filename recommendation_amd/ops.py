@@ -261,8 +261,8 @@ def emb_sparse_apply(keys, src, n_items, *, N, E, total_rows, dz, opt, ws, table
 
 # ------------------------------------------------------------------ dense pieces
 @_timed
-def gemm(A, B_, Cout, *, trans_a=False, trans_b=False, bias=None, relu=False, accumulate=False, dropout=None,
-         mask_src=None, mask_scale=1.0, ws=None):
+def gemm(A, B_, Cout, *, trans_a=False, trans_b=False, bias=None, relu=False, sigmoid=False, accumulate=False,
+         dropout=None, mask_src=None, mask_scale=1.0, ws=None):
     """Cout[M,N] = epilogue(op(A) @ op(B_)); all three are 2-D views with contiguous last dim."""
     M, N = Cout.shape
     ap, lda = _rows(A, 'A')
@@ -280,7 +280,7 @@ def gemm(A, B_, Cout, *, trans_a=False, trans_b=False, bias=None, relu=False, ac
         mp, mld = _rows(mask_src, 'mask_src')
         if mask_src.shape[0] != M or mask_src.shape[1] < N:
             raise ValueError('mask_src shape mismatch')
-    epi = Epilogue(bias=None if bias is None else bias.data_ptr(), relu=int(relu), accumulate=int(accumulate),
+    epi = Epilogue(bias=None if bias is None else bias.data_ptr(), relu=2 if sigmoid else int(relu), accumulate=int(accumulate),
                    dropout=C.pointer(dropout) if dropout is not None else None,
                    mask_src=None if mask_src is None else mask_src.data_ptr(), mask_ld=mld,
                    mask_scale=float(mask_scale))
@@ -504,3 +504,103 @@ def afm_pair_bwd(z, dx, dz, *, N, E, pair_drop=None):
         raise ValueError('afm_pair_bwd shape mismatch')
     check(lib().ctr_afm_pair_bwd(zp, zld, _ptr(dx, torch.float32), B, N, E, _dp(pair_drop), dp, dld, _stream()),
           'ctr_afm_pair_bwd')
+
+
+# ------------------------------------------------------------------ DIN pieces
+f32 = torch.float32
+
+
+@_timed
+def din_build_idx(ids, cate_list, item_count, out):
+    n = ids.numel()
+    if ids.dtype != torch.int32 or cate_list.dtype != torch.int32 or out.dtype != torch.int32 or out.numel() < 2 * n:
+        raise TypeError('din_build_idx wants int32 ids / cate_list / out[n,2]')
+    if cate_list.numel() < item_count:
+        raise ValueError('cate_list shorter than item_count')
+    check(lib().ctr_din_build_idx(_ptr(ids), _ptr(cate_list), n, int(item_count), _ptr(out), _stream()),
+          'ctr_din_build_idx')
+
+
+@_timed
+def din_concat_fwd(q, k, out, *, B, T, H):
+    if q.numel() != B * H or k.numel() != B * T * H or out.numel() != B * T * 4 * H:
+        raise ValueError('din_concat_fwd size mismatch')
+    check(lib().ctr_din_concat_fwd(_ptr(q, f32), _ptr(k, f32), B, T, H, _ptr(out, f32), _stream()), 'ctr_din_concat_fwd')
+
+
+@_timed
+def din_concat_bwd(d_all, q, k, dq, dk, *, B, T, H, acc_q=False, acc_k=False):
+    if d_all.numel() != B * T * 4 * H or dq.numel() != B * H or dk.numel() != B * T * H:
+        raise ValueError('din_concat_bwd size mismatch')
+    check(lib().ctr_din_concat_bwd(_ptr(d_all, f32), _ptr(q, f32), _ptr(k, f32), B, T, H, _ptr(dq, f32), int(acc_q),
+                                   _ptr(dk, f32), int(acc_k), _stream()), 'ctr_din_concat_bwd')
+
+
+@_timed
+def din_attn_pool_fwd(score, sl, K, att, out, *, B, T, H):
+    if score.numel() != B * T or sl.numel() != B or sl.dtype != torch.int32 or K.numel() != B * T * H \
+            or att.numel() != B * T or out.numel() != B * H:
+        raise ValueError('din_attn_pool_fwd size mismatch')
+    check(lib().ctr_din_attn_pool_fwd(_ptr(score, f32), _ptr(sl), _ptr(K, f32), B, T, H, _ptr(att, f32),
+                                      _ptr(out, f32), _stream()), 'ctr_din_attn_pool_fwd')
+
+
+@_timed
+def din_attn_pool_bwd(dout, att, sl, K, dscore, dK, *, B, T, H, acc_k=False):
+    if dout.numel() != B * H or att.numel() != B * T or dscore.numel() != B * T or dK.numel() != B * T * H:
+        raise ValueError('din_attn_pool_bwd size mismatch')
+    check(lib().ctr_din_attn_pool_bwd(_ptr(dout, f32), _ptr(att, f32), _ptr(sl), _ptr(K, f32), B, T, H,
+                                      _ptr(dscore, f32), _ptr(dK, f32), int(acc_k), _stream()), 'ctr_din_attn_pool_bwd')
+
+
+@_timed
+def bn_infer(x, y, *, gamma=None, beta=None, mean=None, var=None, eps=1e-3, xhat=None):
+    rows, cols = x.shape
+    xp, xld = _rows(x, 'x')
+    yp, yld = _rows(y, 'y')
+    hp, hld = (None, 0) if xhat is None else _rows(xhat, 'xhat')
+    for v in (gamma, beta, mean, var):
+        if v is not None and v.numel() != cols:
+            raise ValueError('bn_infer: per-column vectors must have %d entries' % cols)
+    check(lib().ctr_bn_infer(xp, xld, rows, cols, _ptr(gamma, f32), _ptr(beta, f32), _ptr(mean, f32), _ptr(var, f32),
+                             float(eps), yp, yld, hp, hld, _stream()), 'ctr_bn_infer')
+
+
+@_timed
+def dice_fwd(x, alpha, y, eps=1e-3):
+    rows, cols = x.shape
+    xp, xld = _rows(x, 'x')
+    yp, yld = _rows(y, 'y')
+    if alpha.numel() != cols:
+        raise ValueError('dice alpha size mismatch')
+    check(lib().ctr_dice_fwd(xp, xld, rows, cols, _ptr(alpha, f32), float(eps), yp, yld, _stream()), 'ctr_dice_fwd')
+
+
+@_timed
+def dice_bwd(x, alpha, dy, dx, dalpha_src=None, eps=1e-3):
+    rows, cols = x.shape
+    xp, xld = _rows(x, 'x')
+    gp, gld = _rows(dy, 'dy')
+    dp, dld = _rows(dx, 'dx')
+    ap, ald = (None, 0) if dalpha_src is None else _rows(dalpha_src, 'dalpha_src')
+    check(lib().ctr_dice_bwd(xp, xld, rows, cols, _ptr(alpha, f32), float(eps), gp, gld, dp, dld, ap, ald, _stream()),
+          'ctr_dice_bwd')
+
+
+@_timed
+def dsigmoid_apply(g, y):
+    rows, cols = g.shape
+    gp, gld = _rows(g, 'g')
+    yp, yld = _rows(y, 'y')
+    if y.shape[0] != rows or y.shape[1] < cols:
+        raise ValueError('dsigmoid_apply shape mismatch')
+    check(lib().ctr_dsigmoid_apply(gp, gld, yp, yld, rows, cols, _stream()), 'ctr_dsigmoid_apply')
+
+
+@_timed
+def mean_positive_diff(a, b, out):
+    n = a.numel()
+    if b.numel() != n:
+        raise ValueError('mean_positive_diff size mismatch')
+    check(lib().ctr_mean_positive_diff(_ptr(a, f32), _ptr(b, f32), n, _ptr(out, f32), _stream()),
+          'ctr_mean_positive_diff')

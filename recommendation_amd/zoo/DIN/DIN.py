@@ -1,0 +1,327 @@
+"""Deep Interest Network on the HIP hot path; same class surface as the reference's DIN/DIN.py:4-146:
+DIN(args, user_count, item_count, cate_count, cate_list), train(sess, uij, l), eval(sess, uij),
+save(sess, path), restore(sess, path).
+
+Graph (DIN/DIN.py:17-110): item/category lookups with the cate_list double indirection, target
+attention over the padded history (MLP 4H -> 80 -> 40 -> 1 with sigmoids, length mask, 1/sqrt(H),
+softmax, weighted sum), inference-mode batch norm, dense H, then the FCN 2H -> 80 -> 40 -> 1 with
+Dice, logits = item_b[i] + d3, sigmoid cross-entropy, plain SGD with the learning rate fed per call.
+`user_emb_w` exists in the reference but is never used (DIN/DIN.py:18,48) and is not allocated here;
+`logits_all` / test() (DIN/DIN.py:73-89,133-138) is outside the training/eval hot path."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from recommendation_amd import ops
+from recommendation_amd.engine import DenseParams, EmbeddingTables
+from recommendation_amd._lib import LOSS_SCE_LOGIT, OPT_SGD
+
+BN_EPS = 1e-3
+
+
+class DIN(object):
+    def __init__(self, args, user_count, item_count, cate_count, cate_list):
+        self.H = H = int(args.hidden_units)
+        if H % 2 or (H // 2) & (H // 2 - 1) or H < 8:
+            raise ValueError('hidden_units must be twice a power of two >= 4 (rows are moved 16 bytes per lane)')
+        self.user_count, self.item_count, self.cate_count = int(user_count), int(item_count), int(cate_count)
+        self.cate_list_host = np.asarray(cate_list).astype(np.int32)
+        if self.cate_list_host.shape[0] != self.item_count:
+            raise ValueError('cate_list must have item_count entries')
+        sh = OrderedDict()
+        for name, (i, o) in (('f1_att', (4 * H, 80)), ('f2_att', (80, 40)), ('f3_att', (40, 1))):
+            sh['embedding/%s/kernel' % name] = (i, o)
+            sh['embedding/%s/bias' % name] = (o,)
+        for k in ('gamma', 'beta', 'moving_mean', 'moving_variance'):
+            sh['embedding/batch_normalization/%s' % k] = (H,)
+        sh['embedding/dense/kernel'] = (H, H)
+        sh['embedding/dense/bias'] = (H,)
+        for k in ('gamma', 'beta', 'moving_mean', 'moving_variance'):
+            sh['fcn/b1/%s' % k] = (2 * H,)
+        for name, (i, o) in (('f1', (2 * H, 80)), ('f2', (80, 40)), ('f3', (40, 1))):
+            sh['fcn/%s/kernel' % name] = (i, o)
+            sh['fcn/%s/bias' % name] = (o,)
+        for tag in ('i', 'j'):
+            sh['fcn/alphadice_1_%s' % tag] = (80,)
+            sh['fcn/alphadice_2_%s' % tag] = (40,)
+        self.dense_shapes = sh
+        self.global_step = 0
+        self.global_epoch_step = 0
+        self._ready = False
+        self._bufs = {}
+
+    # ---- variables ------------------------------------------------------------------------
+    def variable_shapes(self):
+        H = self.H
+        out = OrderedDict()
+        out['embedding/item_emb_w'] = (self.item_count, H // 2)
+        out['embedding/item_b'] = (self.item_count,)
+        out['embedding/cate_emb_w'] = (self.cate_count, H // 2)
+        out.update(self.dense_shapes)
+        return out
+
+    def initialize(self, session, params=None, seed=0):
+        """tf defaults (DIN/DIN.py:18-21,47,54,150): Glorot-uniform kernels and embeddings, zero biases,
+        BN gamma=1 / beta=0 / moving stats 0,1, Dice alphas 0, item_b 0."""
+        dev = session.device
+        self.session = session
+        H = self.H
+        self.tables = EmbeddingTables([self.item_count, self.cate_count], H // 2, dev)
+        self.bias_table = EmbeddingTables([self.item_count], 4, dev)     # item_b lives in column 0
+        self.dense = DenseParams(self.dense_shapes, dev)
+        self.cate_list = torch.as_tensor(self.cate_list_host, device=dev)
+        self._loss_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._auc_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        rng = np.random.Generator(np.random.PCG64(seed))
+        init = OrderedDict()
+        for k, s in self.variable_shapes().items():
+            if k.endswith('gamma') or k.endswith('moving_variance'):
+                init[k] = np.ones(s, dtype=np.float32)
+            elif (k.endswith('bias') or k.endswith('beta') or k.endswith('moving_mean') or 'alphadice' in k
+                  or k.endswith('item_b')):
+                init[k] = np.zeros(s, dtype=np.float32)
+            else:
+                lim = np.sqrt(6.0 / (s[0] + s[1]))
+                init[k] = rng.uniform(-lim, lim, size=s).astype(np.float32)
+        if params:
+            for k, v in params.items():
+                if k not in init:
+                    raise KeyError('unknown variable %s' % k)
+                init[k] = np.asarray(v, dtype=np.float32).reshape(init[k].shape)
+        self.set_params(init)
+        self._ready = True
+
+    def _ensure(self, session):
+        if not self._ready:
+            self.initialize(session)
+
+    def set_params(self, params):
+        for k, v in params.items():
+            t = torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32))
+            if k == 'embedding/item_emb_w':
+                self.tables.table(0).copy_(t)
+            elif k == 'embedding/cate_emb_w':
+                self.tables.table(1).copy_(t)
+            elif k == 'embedding/item_b':
+                self.bias_table.weight.zero_()
+                self.bias_table.weight[:, 0].copy_(t)
+            else:
+                self.dense.p(k).copy_(t.reshape(self.dense.shapes[k]))
+
+    def get_params(self):
+        out = OrderedDict()
+        out['embedding/item_emb_w'] = self.tables.table(0).cpu().numpy()
+        out['embedding/item_b'] = self.bias_table.weight[:, 0].cpu().numpy()
+        out['embedding/cate_emb_w'] = self.tables.table(1).cpu().numpy()
+        for k in self.dense.shapes:
+            out[k] = self.dense.p(k).cpu().numpy()
+        return out
+
+    def get_grads(self):
+        return OrderedDict((k, self.dense.g(k).cpu().numpy()) for k in self.dense.shapes)
+
+    def save(self, sess, path):
+        from safetensors.torch import save_file
+        sd = OrderedDict((k, torch.as_tensor(v)) for k, v in self.get_params().items())
+        sd['optimization/global_step'] = torch.tensor([self.global_step], dtype=torch.int64)
+        sd['optimization/global_epoch_step'] = torch.tensor([self.global_epoch_step], dtype=torch.int64)
+        d = os.path.dirname(os.path.abspath(path))
+        os.makedirs(d, exist_ok=True)
+        save_file(sd, path + '.safetensors')
+
+    def restore(self, sess, path):
+        from safetensors.torch import load_file
+        self._ensure(sess)
+        sd = load_file(path + '.safetensors')
+        names = set(self.variable_shapes())
+        self.set_params({k: v.numpy() for k, v in sd.items() if k in names})
+        self.global_step = int(sd['optimization/global_step'][0])
+        self.global_epoch_step = int(sd['optimization/global_epoch_step'][0])
+
+    # ---- buffers ---------------------------------------------------------------------------
+    def _buffers(self, B, T):
+        key = (B, T)
+        if key not in self._bufs:
+            dev, H = self.session.device, self.H
+            z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+            n = B + B * T
+            b = dict(pair=torch.zeros(n, 2, dtype=torch.int32, device=dev), emb=z(n, H), demb=z(n, H),
+                     ib4=z(B, 4), dib4=z(B, 4), din_all=z(B * T, 4 * H), d1=z(B * T, 80), d2=z(B * T, 40),
+                     g1=z(B * T, 80), g2=z(B * T, 40), score=z(B * T), dscore=z(B * T), att=z(B * T),
+                     pooled=z(B, H), dpooled=z(B, H), xhat1=z(B, H), hist_bn=z(B, H), dhist_bn=z(B, H),
+                     u_emb=z(B, H), din=z(B, 2 * H), ddin=z(B, 2 * H), xhat2=z(B, 2 * H), din_bn=z(B, 2 * H),
+                     ddin_bn=z(B, 2 * H), f1=z(B, 80), a1=z(B, 80), f2=z(B, 40), a2=z(B, 40), df1=z(B, 80),
+                     da1=z(B, 80), df2=z(B, 40), da2=z(B, 40), t80=z(B, 80), t40=z(B, 40), d3=z(B), logit=z(B),
+                     dlogit=z(B), y_out=z(B),
+                     keys=torch.zeros(2 * n, dtype=torch.int32, device=dev),
+                     src=torch.zeros(2 * n, dtype=torch.int32, device=dev),
+                     bkeys=torch.zeros(B, dtype=torch.int32, device=dev),
+                     bsrc=torch.zeros(B, dtype=torch.int32, device=dev))
+            self._bufs[key] = b
+        return self._bufs[key]
+
+    def _dev_i32(self, a):
+        if isinstance(a, torch.Tensor) and a.is_cuda:
+            return a.to(torch.int32).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(np.asarray(a).astype(np.int32))).to(self.session.device)
+
+    # ---- graph pieces ----------------------------------------------------------------------
+    def _lookup(self, ids, b):
+        """emb[k] = [item_emb_w[id], cate_emb_w[cate_list[id]]] for all ids (DIN/DIN.py:24-42)."""
+        ops.din_build_idx(ids, self.cate_list, self.item_count, b['pair'])
+        ops.embed_fwd(self.tables.weight, self.tables.row_offset, b['pair'][:ids.numel()], E=self.H // 2,
+                      z_out=b['emb'][:ids.numel()])
+
+    def _user_vector(self, b, sl, B, T):
+        """attention() + batch_normalization + dense (DIN/DIN.py:44-49); returns u_emb."""
+        d, H, ws = self.dense, self.H, self.session.ws
+        i_emb, h_emb = b['emb'][:B], b['emb'][B:B + B * T]
+        ops.din_concat_fwd(i_emb, h_emb, b['din_all'], B=B, T=T, H=H)
+        ops.gemm(b['din_all'], d.p('embedding/f1_att/kernel'), b['d1'], bias=d.p('embedding/f1_att/bias'),
+                 sigmoid=True, ws=ws)
+        ops.gemm(b['d1'], d.p('embedding/f2_att/kernel'), b['d2'], bias=d.p('embedding/f2_att/bias'),
+                 sigmoid=True, ws=ws)
+        ops.rowdot_fwd(b['d2'], d.p('embedding/f3_att/kernel').reshape(-1), d.p('embedding/f3_att/bias'), b['score'])
+        ops.din_attn_pool_fwd(b['score'], sl, h_emb, b['att'], b['pooled'], B=B, T=T, H=H)
+        p = 'embedding/batch_normalization/'
+        ops.bn_infer(b['pooled'], b['hist_bn'], gamma=d.p(p + 'gamma'), beta=d.p(p + 'beta'),
+                     mean=d.p(p + 'moving_mean'), var=d.p(p + 'moving_variance'), eps=BN_EPS, xhat=b['xhat1'])
+        ops.gemm(b['hist_bn'], d.p('embedding/dense/kernel'), b['u_emb'], bias=d.p('embedding/dense/bias'), ws=ws)
+
+    def _fcn(self, b, x_emb, tag, B, keep):
+        """BN(concat(u_emb, x_emb)) -> f1 -> dice -> f2 -> dice -> f3 (DIN/DIN.py:52-58); returns d3 in b['d3']."""
+        d, H, ws = self.dense, self.H, self.session.ws
+        ops.copy2d(b['u_emb'], b['din'][:, :H])
+        ops.copy2d(x_emb, b['din'][:, H:])
+        p = 'fcn/b1/'
+        ops.bn_infer(b['din'], b['din_bn'], gamma=d.p(p + 'gamma'), beta=d.p(p + 'beta'), mean=d.p(p + 'moving_mean'),
+                     var=d.p(p + 'moving_variance'), eps=BN_EPS, xhat=b['xhat2'] if keep else None)
+        ops.gemm(b['din_bn'], d.p('fcn/f1/kernel'), b['f1'], bias=d.p('fcn/f1/bias'), ws=ws)
+        ops.dice_fwd(b['f1'], d.p('fcn/alphadice_1_%s' % tag), b['a1'], BN_EPS)
+        ops.gemm(b['a1'], d.p('fcn/f2/kernel'), b['f2'], bias=d.p('fcn/f2/bias'), ws=ws)
+        ops.dice_fwd(b['f2'], d.p('fcn/alphadice_2_%s' % tag), b['a2'], BN_EPS)
+        ops.rowdot_fwd(b['a2'], d.p('fcn/f3/kernel').reshape(-1), d.p('fcn/f3/bias'), b['d3'])
+
+    def _item_bias(self, ids, out4):
+        ops.embed_fwd(self.bias_table.weight, self.bias_table.row_offset, ids.view(-1, 1), E=4, z_out=out4)
+
+    # ---- public API ------------------------------------------------------------------------
+    def train(self, sess, uij, l):
+        """uij = (u, i, y, hist_i[B,T], sl); one SGD step with learning rate l; returns the loss."""
+        self._ensure(sess)
+        i = self._dev_i32(uij[1])
+        hist = self._dev_i32(uij[3])
+        sl = self._dev_i32(uij[4])
+        y = torch.as_tensor(np.asarray(uij[2], dtype=np.float32)).to(sess.device)
+        B, T = hist.shape
+        if i.numel() != B or sl.numel() != B or y.numel() != B:
+            raise ValueError('DIN.train: batch sizes disagree')
+        b = self._buffers(B, T)
+        d, H, ws = self.dense, self.H, sess.ws
+        # forward
+        self._lookup(torch.cat([i, hist.reshape(-1)]), b)
+        self._item_bias(i, b['ib4'])
+        self._user_vector(b, sl, B, T)
+        self._fcn(b, b['emb'][:B], 'i', B, keep=True)
+        ops.copy2d(b['d3'].view(B, 1), b['logit'].view(B, 1))
+        ops.copy2d(b['ib4'][:, :1], b['logit'].view(B, 1), accumulate=True)          # logits = i_b + d3
+        ops.loss_head(LOSS_SCE_LOGIT, b['logit'], y, y_out=b['y_out'], loss_out=self._loss_dev, dx=b['dlogit'], ws=ws)
+        # backward: FCN
+        dl = b['dlogit']
+        ops.rowdot_bwd_x(dl, d.p('fcn/f3/kernel').reshape(-1), b['da2'])
+        ops.colsum(b['a2'], d.g('fcn/f3/kernel').reshape(-1), w=dl.view(B, 1), w_group=40, ws=ws)
+        ops.colsum(dl.view(B, 1), d.g('fcn/f3/bias'), ws=ws)
+        ops.dice_bwd(b['f2'], d.p('fcn/alphadice_2_i'), b['da2'], b['df2'], b['t40'], BN_EPS)
+        ops.colsum(b['t40'], d.g('fcn/alphadice_2_i'), ws=ws)
+        ops.gemm(b['a1'], b['df2'], d.g('fcn/f2/kernel'), trans_a=True, ws=ws)
+        ops.colsum(b['df2'], d.g('fcn/f2/bias'), ws=ws)
+        ops.gemm(b['df2'], d.p('fcn/f2/kernel'), b['da1'], trans_b=True, ws=ws)
+        ops.dice_bwd(b['f1'], d.p('fcn/alphadice_1_i'), b['da1'], b['df1'], b['t80'], BN_EPS)
+        ops.colsum(b['t80'], d.g('fcn/alphadice_1_i'), ws=ws)
+        ops.gemm(b['din_bn'], b['df1'], d.g('fcn/f1/kernel'), trans_a=True, ws=ws)
+        ops.colsum(b['df1'], d.g('fcn/f1/bias'), ws=ws)
+        ops.gemm(b['df1'], d.p('fcn/f1/kernel'), b['ddin_bn'], trans_b=True, ws=ws)
+        ops.colsum(b['ddin_bn'], d.g('fcn/b1/gamma'), w=b['xhat2'], w_group=1, ws=ws)
+        ops.colsum(b['ddin_bn'], d.g('fcn/b1/beta'), ws=ws)
+        ops.bn_infer(b['ddin_bn'], b['ddin'], gamma=d.p('fcn/b1/gamma'), var=d.p('fcn/b1/moving_variance'), eps=BN_EPS)
+        # backward: dense H, batch norm, attention pooling
+        du = b['ddin'][:, :H]
+        ops.gemm(b['hist_bn'], du, d.g('embedding/dense/kernel'), trans_a=True, ws=ws)
+        ops.colsum(du, d.g('embedding/dense/bias'), ws=ws)
+        ops.gemm(du, d.p('embedding/dense/kernel'), b['dhist_bn'], trans_b=True, ws=ws)
+        p = 'embedding/batch_normalization/'
+        ops.colsum(b['dhist_bn'], d.g(p + 'gamma'), w=b['xhat1'], w_group=1, ws=ws)
+        ops.colsum(b['dhist_bn'], d.g(p + 'beta'), ws=ws)
+        ops.bn_infer(b['dhist_bn'], b['dpooled'], gamma=d.p(p + 'gamma'), var=d.p(p + 'moving_variance'), eps=BN_EPS)
+        i_emb, h_emb = b['emb'][:B], b['emb'][B:B + B * T]
+        dq, dk = b['demb'][:B], b['demb'][B:B + B * T]
+        ops.din_attn_pool_bwd(b['dpooled'], b['att'], sl, h_emb, b['dscore'], dk, B=B, T=T, H=H)
+        # backward: attention MLP
+        ds = b['dscore']
+        ops.rowdot_bwd_x(ds, d.p('embedding/f3_att/kernel').reshape(-1), b['g2'])
+        ops.colsum(b['d2'], d.g('embedding/f3_att/kernel').reshape(-1), w=ds.view(B * T, 1), w_group=40, ws=ws)
+        ops.colsum(ds.view(B * T, 1), d.g('embedding/f3_att/bias'), ws=ws)
+        ops.dsigmoid_apply(b['g2'], b['d2'])
+        ops.gemm(b['d1'], b['g2'], d.g('embedding/f2_att/kernel'), trans_a=True, ws=ws)
+        ops.colsum(b['g2'], d.g('embedding/f2_att/bias'), ws=ws)
+        ops.gemm(b['g2'], d.p('embedding/f2_att/kernel'), b['g1'], trans_b=True, ws=ws)
+        ops.dsigmoid_apply(b['g1'], b['d1'])
+        ops.gemm(b['din_all'], b['g1'], d.g('embedding/f1_att/kernel'), trans_a=True, ws=ws)
+        ops.colsum(b['g1'], d.g('embedding/f1_att/bias'), ws=ws)
+        ops.gemm(b['g1'], d.p('embedding/f1_att/kernel'), b['din_all'], trans_b=True, ws=ws)   # d(din_all), in place
+        ops.din_concat_bwd(b['din_all'], i_emb, h_emb, dq, dk, B=B, T=T, H=H, acc_q=False, acc_k=True)
+        ops.copy2d(b['ddin'][:, H:], dq, accumulate=True)                                # i_emb also feeds the FCN
+        # sparse updates (SGD) on item/category tables and on item_b
+        sgd = ops.make_opt(OPT_SGD, lr=float(l))
+        n = B + B * T
+        t = self.tables
+        ops.emb_sort(b['pair'][:n], t.row_offset, N=2, total_rows=t.total_rows, rmode=False, keys_out=b['keys'],
+                     src_out=b['src'], ws=ws)
+        ops.emb_sparse_apply(b['keys'], b['src'], 2 * n, N=2, E=H // 2, total_rows=t.total_rows, dz=b['demb'][:n],
+                             opt=sgd, tables=t.weight, ws=ws)
+        ops.copy2d(dl.view(B, 1), b['dib4'][:, :1])
+        bt = self.bias_table
+        ops.emb_sort(i.view(B, 1), bt.row_offset, N=1, total_rows=bt.total_rows, rmode=False, keys_out=b['bkeys'],
+                     src_out=b['bsrc'], ws=ws)
+        ops.emb_sparse_apply(b['bkeys'], b['bsrc'], B, N=1, E=4, total_rows=bt.total_rows, dz=b['dib4'], opt=sgd,
+                             tables=bt.weight, ws=ws)
+        # dense variables (the reference never passes global_step to minimize(): it stays 0, DIN/DIN.py:110)
+        self.dense.apply(sgd)
+        return np.float32(self._loss_dev.item())
+
+    def eval(self, sess, uij):
+        """uij = (u, i, j, hist_i, sl) -> (mf_auc, p_and_n[B,2]) (DIN/DIN.py:91-97,123-131)."""
+        self._ensure(sess)
+        i, j = self._dev_i32(uij[1]), self._dev_i32(uij[2])
+        hist, sl = self._dev_i32(uij[3]), self._dev_i32(uij[4])
+        B, T = hist.shape
+        b = self._buffers(B, T)
+        H = self.H
+        self._lookup(torch.cat([i, hist.reshape(-1)]), b)
+        self._item_bias(i, b['ib4'])
+        self._user_vector(b, sl, B, T)
+        self._fcn(b, b['emb'][:B], 'i', B, keep=False)
+        xi = torch.zeros(B, 1, dtype=torch.float32, device=sess.device)
+        ops.copy2d(b['d3'].view(B, 1), xi)
+        ops.copy2d(b['ib4'][:, :1], xi, accumulate=True)
+        # the negative item through the same FCN weights but its own Dice alphas (DIN/DIN.py:60-66)
+        ops.din_build_idx(j, self.cate_list, self.item_count, b['pair'])
+        jemb = torch.zeros(B, H, dtype=torch.float32, device=sess.device)
+        ops.embed_fwd(self.tables.weight, self.tables.row_offset, b['pair'][:B], E=H // 2, z_out=jemb)
+        self._item_bias(j, b['dib4'])
+        self._fcn(b, jemb, 'j', B, keep=False)
+        xj = torch.zeros(B, 1, dtype=torch.float32, device=sess.device)
+        ops.copy2d(b['d3'].view(B, 1), xj)
+        ops.copy2d(b['dib4'][:, :1], xj, accumulate=True)
+        ops.mean_positive_diff(xi.view(-1), xj.view(-1), self._auc_dev)
+        pn = torch.zeros(B, 2, dtype=torch.float32, device=sess.device)
+        ops.loss_head(LOSS_SCE_LOGIT, xi.view(-1), None, y_out=b['y_out'])
+        ops.copy2d(b['y_out'].view(B, 1), pn[:, :1])
+        ops.loss_head(LOSS_SCE_LOGIT, xj.view(-1), None, y_out=b['y_out'])
+        ops.copy2d(b['y_out'].view(B, 1), pn[:, 1:])
+        return np.float32(self._auc_dev.item()), pn.cpu().numpy()
+
+    def test(self, sess, uid, hist_i, sl):
+        raise NotImplementedError('logits over all items (DIN/DIN.py:73-89,133-138) is outside the hot path')

@@ -1,0 +1,75 @@
+"""DIN on the HIP path vs the CPU oracle (DIN/DIN.py): train (loss, dense gradients, SGD steps on
+dense variables and on the item/category/bias tables), eval (mf_auc, p_and_n), padding-invariance."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctr_oracle as O
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(sess, H, seed=0, item_count=40, cate_count=6, B=9, T=11):
+    import recommendation_amd as ra
+    ra.enable_zoo_imports()
+    from DIN import DIN
+    rng = np.random.default_rng(seed)
+    cfg = O.default_cfg('DIN')
+    cfg.hidden_units = H
+    cate_list = rng.integers(0, cate_count, item_count)
+    P = O.din_init_params(cfg, 5, item_count, cate_count, seed=seed + 1)
+    # non-trivial values for the variables that initialise to constants
+    for k in P:
+        if k.endswith('bias') or k.endswith('beta') or 'alphadice' in k or k.endswith('item_b'):
+            P[k] = rng.standard_normal(P[k].shape) * 0.2
+        if k.endswith('gamma'):
+            P[k] = 1.0 + rng.standard_normal(P[k].shape) * 0.2
+    m = DIN.DIN(cfg, 5, item_count, cate_count, cate_list)
+    m.initialize(sess, params=P)
+    orc = O.OracleDIN(cfg, cate_list, P, dtype=torch.float64)
+    sl = rng.integers(1, T + 1, B)
+    sl[0] = T
+    hist = np.zeros((B, T), dtype=np.int64)
+    for b in range(B):
+        hist[b, :sl[b]] = rng.integers(0, item_count, sl[b])
+    i = rng.integers(0, item_count, B)
+    j = rng.integers(0, item_count, B)
+    y = rng.integers(0, 2, B)
+    u = np.zeros(B, dtype=np.int64)
+    return m, orc, (u, i, y, hist, sl), (u, i, j, hist, sl)
+
+
+@pytest.mark.parametrize('H', [8, 32])
+def test_din_train_and_eval_match_oracle(sess, H):
+    m, orc, uij, uij_eval = _setup(sess, H)
+    auc_g, pn_g = m.eval(sess, uij_eval)
+    auc_o, pn_o = orc.eval(uij_eval)
+    assert abs(float(auc_g) - float(auc_o)) < 1e-6
+    assert rel_err(pn_g, pn_o) < 1e-5
+    loss_o, g_o, _ = orc.loss_and_grads(uij)
+    loss_g = m.train(sess, uij, 0.1)
+    assert abs(float(loss_g) - float(loss_o)) < 1e-5
+    for k, v in m.get_grads().items():
+        if k in g_o:      # the f3_att bias gradient is exactly 0 (softmax is shift invariant): absolute floor
+            ref = g_o[k].numpy()
+            assert np.max(np.abs(v - ref)) < 5e-5 * np.max(np.abs(ref)) + 1e-8, k
+    orc.train(uij, 0.1)
+    for _ in range(2):
+        lo = orc.train(uij, 0.1)
+        lg = m.train(sess, uij, 0.1)
+        assert abs(float(lo) - float(lg)) < 1e-5
+    for k, v in m.get_params().items():
+        assert rel_err(v, orc.P[k].numpy()) < 5e-5, k
+
+
+def test_din_padding_positions_do_not_matter(sess):
+    m, orc, uij, _ = _setup(sess, 8, seed=3)
+    u, i, y, hist, sl = uij
+    hist2 = hist.copy()
+    for b in range(hist.shape[0]):
+        hist2[b, sl[b]:] = 7                      # garbage ids behind the valid prefix
+    p0 = m.get_params()
+    l1 = m.train(sess, (u, i, y, hist, sl), 0.0)
+    l2 = m.train(sess, (u, i, y, hist2, sl), 0.0)
+    assert abs(float(l1) - float(l2)) < 1e-6
