@@ -23,10 +23,10 @@ CASES = [('DeepFM', {}), ('DCN', {}), ('NFM', {}), ('ESMM', {}), ('PNN', {}), ('
 
 def make(model, mode, extra):
     cfg = no_dropout(tiny_cfg(model, mode, **extra))
-    P = O.init_params(model, cfg, seed=11, std=0.3)
+    P = O.init_params(model, cfg, seed=11, std=0.12 if model == 'AFM' else 0.3)
     Xc, Xf, y = tiny_batch(cfg, B=8, seed=1)
     if model == 'AFM':                      # keep 0 < y_out < 1 (AFM feeds log_loss an unbounded value)
-        Xf = np.abs(Xf) * 0.5
+        Xf = np.abs(Xf) * 0.3
         P = {k: np.abs(v) for k, v in P.items()}
     m = O.OracleModel(model, cfg, P, dtype=torch.float64)
     out = dict(X_cate=Xc, X_cont=Xf, y=y)
@@ -37,6 +37,7 @@ def make(model, mode, extra):
     out['Z'] = fw.Z.numpy()
     loss, g, _ = m.loss_and_grads(Xc, Xf, y)
     out['loss'] = np.float64(loss.item())
+    assert np.isfinite(out['loss']), (model, mode)
     for k, v in g.items():
         out['grad/' + k] = v.numpy()
     for step in (1, 2, 3):
