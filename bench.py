@@ -130,7 +130,7 @@ def main():
         model.train_step(*batches[i % len(batches)])
     timer = None
     if not args.no_kernel_timers:
-        timer = ops.KernelTimer()
+        timer = ops.KernelTimer(pool=args.steps * 140)
         ops.set_timer(timer)
     barrier()
     t0 = time.perf_counter()

@@ -186,6 +186,15 @@ int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K,
                  float* C, int64_t ldc, const ctr_epilogue_t* epi,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* Weight and bias gradient of a dense layer y = x W + b (gradient of DeepFM/DeepFM.py:71,78):
+ *   dW[M,N] = A^T B  (A = layer input stored [K,M], B = upstream gradient stored [K,N], K = batch),
+ *   db[N]   = column sums of B (optional).  dW is written contiguously (leading dimension N).
+ * Small outputs stream the operands straight into MFMA fragments (no LDS staging) with fixed-order
+ * partial slabs; large ones go through ctr_gemm_f32's split-K path.  Bitwise reproducible. */
+size_t ctr_dense_wgrad_workspace_bytes(int M, int N, int K);
+int ctr_dense_wgrad(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                    float* dW, float* db, void* workspace, size_t workspace_bytes, void* stream);
+
 /* out[j] = sum_b X[b*ld + j] * (w ? w[b*w_ld + j / w_group] : 1),  j in [0, K).
  * Two fixed-order passes (bitwise reproducible).  Serves bias gradients (w == NULL),
  * output-unit weight gradients (w = dlogit, w_group = K) and the continuous-embedding

@@ -57,6 +57,8 @@ SIGNATURES = {
     'ctr_emb_sparse_apply': (i, [vp, vp, i64, i, i, i64, vp, i64, vp, vp, vp, vp, C.POINTER(Opt), vp, sz, vp]),
     'ctr_gemm_f32_workspace_bytes': (sz, [i, i, i]),
     'ctr_gemm_f32': (i, [i, i, i, i, i, vp, i64, vp, i64, vp, i64, C.POINTER(Epilogue), vp, sz, vp]),
+    'ctr_dense_wgrad_workspace_bytes': (sz, [i, i, i]),
+    'ctr_dense_wgrad': (i, [i, i, i, vp, i64, vp, i64, vp, vp, vp, sz, vp]),
     'ctr_colsum_workspace_bytes': (sz, [i, i]),
     'ctr_colsum': (i, [vp, i64, vp, i64, i, i, i, vp, i, vp, sz, vp]),
     'ctr_rowdot_fwd': (i, [vp, i64, vp, vp, i, i, vp, vp]),

@@ -11,9 +11,9 @@ namespace ctr {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LDS_K = BM + 2;   // stride for operands loaded k-contiguous (scalar transposing writes)
-constexpr int LDS_MN = BM + 4;  // stride for operands loaded mn-contiguous (16-byte writes)
+constexpr int BK = 16;
+// LDS row stride: tile rows + 2 for operands loaded k-contiguous (scalar transposing writes land on
+// distinct banks), + 4 for operands loaded mn-contiguous (16-byte aligned vector writes).
 
 struct Epi {
   const float* bias;
@@ -34,121 +34,142 @@ __device__ static inline float epilogue(const Epi& e, float v, int m, int n, int
   return v;
 }
 
-// Fetch this thread's share of a 128 x 16 operand tile into 8 registers.
-//   KCONTIG: element (r, k) at P[r*ld + k]   (rows = the M or N index)
-//   else:    element (r, k) at P[k*ld + r]
-template <bool KCONTIG>
+// Fetch this thread's share of an R x 16 operand tile (R = 32..256) as float4 slots.
+//   KCONTIG: element (r, k) at P[r*ld + k]   (rows = the M or N index); slot -> (r = s/4, k = 4*(s%4))
+//   else:    element (r, k) at P[k*ld + r];                            slot -> (k = s/(R/4), r = 4*(s%(R/4)))
+template <bool KCONTIG, int R>
 __device__ static inline void tile_load(const float* __restrict__ P, int64_t ld, bool vec, int r0, int rmax,
-                                        int k0, int kend, int t, float (&reg)[8]) {
+                                        int k0, int kend, int t, float (&reg)[(R * 4 + 255) / 256 * 4]) {
+  constexpr int SLOTS = R * 4;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    if (KCONTIG) {
-      const int r = r0 + (t >> 2) + 64 * j;
-      const int k = k0 + (t & 3) * 4;
-      const float* p = P + (int64_t)r * ld + k;
-      if (r < rmax && vec && k + 3 < kend) {
-        const float4 v = *reinterpret_cast<const float4*>(p);
-        reg[4 * j + 0] = v.x; reg[4 * j + 1] = v.y; reg[4 * j + 2] = v.z; reg[4 * j + 3] = v.w;
+  for (int j = 0; j < (SLOTS + 255) / 256; ++j) {
+    const int s = t + 256 * j;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (SLOTS % 256 == 0 || s < SLOTS) {
+      if (KCONTIG) {
+        const int r = r0 + (s >> 2);
+        const int k = k0 + (s & 3) * 4;
+        const float* p = P + (int64_t)r * ld + k;
+        if (r < rmax && vec && k + 3 < kend) {
+          const float4 v = *reinterpret_cast<const float4*>(p);
+          v0 = v.x; v1 = v.y; v2 = v.z; v3 = v.w;
+        } else if (r < rmax) {
+          if (k + 0 < kend) v0 = p[0];
+          if (k + 1 < kend) v1 = p[1];
+          if (k + 2 < kend) v2 = p[2];
+          if (k + 3 < kend) v3 = p[3];
+        }
       } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) reg[4 * j + i] = (r < rmax && k + i < kend) ? p[i] : 0.f;
-      }
-    } else {
-      const int k = k0 + (t >> 5) + 8 * j;
-      const int r = r0 + (t & 31) * 4;
-      const float* p = P + (int64_t)k * ld + r;
-      if (k < kend && vec && r + 3 < rmax) {
-        const float4 v = *reinterpret_cast<const float4*>(p);
-        reg[4 * j + 0] = v.x; reg[4 * j + 1] = v.y; reg[4 * j + 2] = v.z; reg[4 * j + 3] = v.w;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) reg[4 * j + i] = (k < kend && r + i < rmax) ? p[i] : 0.f;
+        const int k = k0 + s / (R / 4);
+        const int r = r0 + (s % (R / 4)) * 4;
+        const float* p = P + (int64_t)k * ld + r;
+        if (k < kend && vec && r + 3 < rmax) {
+          const float4 v = *reinterpret_cast<const float4*>(p);
+          v0 = v.x; v1 = v.y; v2 = v.z; v3 = v.w;
+        } else if (k < kend) {
+          if (r + 0 < rmax) v0 = p[0];
+          if (r + 1 < rmax) v1 = p[1];
+          if (r + 2 < rmax) v2 = p[2];
+          if (r + 3 < rmax) v3 = p[3];
+        }
       }
     }
+    reg[4 * j + 0] = v0; reg[4 * j + 1] = v1; reg[4 * j + 2] = v2; reg[4 * j + 3] = v3;
   }
 }
 
-template <bool KCONTIG>
-__device__ static inline void tile_store(float* __restrict__ S, int t, const float (&reg)[8]) {
+template <bool KCONTIG, int R>
+__device__ static inline void tile_store(float* __restrict__ S, int t, const float (&reg)[(R * 4 + 255) / 256 * 4]) {
+  constexpr int SLOTS = R * 4;
+  constexpr int LD = KCONTIG ? R + 2 : R + 4;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    if (KCONTIG) {
-      const int r = (t >> 2) + 64 * j;
-      const int k = (t & 3) * 4;
+  for (int j = 0; j < (SLOTS + 255) / 256; ++j) {
+    const int s = t + 256 * j;
+    if (SLOTS % 256 == 0 || s < SLOTS) {
+      if (KCONTIG) {
+        const int r = s >> 2;
+        const int k = (s & 3) * 4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) S[(k + i) * LDS_K + r] = reg[4 * j + i];
-    } else {
-      const int k = (t >> 5) + 8 * j;
-      const int r = (t & 31) * 4;
-      *reinterpret_cast<float4*>(&S[k * LDS_MN + r]) =
-          make_float4(reg[4 * j + 0], reg[4 * j + 1], reg[4 * j + 2], reg[4 * j + 3]);
+        for (int i = 0; i < 4; ++i) S[(k + i) * LD + r] = reg[4 * j + i];
+      } else {
+        const int k = s / (R / 4);
+        const int r = (s % (R / 4)) * 4;
+        *reinterpret_cast<float4*>(&S[k * LD + r]) =
+            make_float4(reg[4 * j + 0], reg[4 * j + 1], reg[4 * j + 2], reg[4 * j + 3]);
+      }
     }
   }
 }
 
 // A_K: A stored [M,K] (k contiguous).  B_K: B stored [N,K] (k contiguous).
-template <bool A_K, bool B_K>
+// Tile TBM x TBN x 16, four waves as WGM x (4/WGM); a wave owns TM x TN MFMA tiles of 32x32.
+template <bool A_K, bool B_K, int TBM, int TBN, int WGM>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A,
                                                       int64_t lda, bool vecA, const float* __restrict__ Bm,
                                                       int64_t ldb, bool vecB, float* __restrict__ C,
                                                       int64_t ldc, Epi epi, int k_chunk,
                                                       float* __restrict__ partial) {
-  constexpr int SA = A_K ? LDS_K : LDS_MN;
-  constexpr int SB = B_K ? LDS_K : LDS_MN;
+  constexpr int WGN = 4 / WGM;
+  constexpr int TM = TBM / WGM / 32, TN = TBN / WGN / 32;
+  constexpr int SA = A_K ? TBM + 2 : TBM + 4;
+  constexpr int SB = B_K ? TBN + 2 : TBN + 4;
+  constexpr int RA = (TBM * 4 + 255) / 256 * 4, RB = (TBN * 4 + 255) / 256 * 4;
   __shared__ __attribute__((aligned(16))) float As[BK * SA];
   __shared__ __attribute__((aligned(16))) float Bs[BK * SB];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
   const int kbeg = blockIdx.z * k_chunk;
   const int kend = kbeg + k_chunk < K ? kbeg + k_chunk : K;
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float ra[8], rb[8];
-  tile_load<A_K>(A, lda, vecA, m0, M, kbeg, kend, t, ra);
-  tile_load<B_K>(Bm, ldb, vecB, n0, N, kbeg, kend, t, rb);
+  float ra[RA], rb[RB];
+  tile_load<A_K, TBM>(A, lda, vecA, m0, M, kbeg, kend, t, ra);
+  tile_load<B_K, TBN>(Bm, ldb, vecB, n0, N, kbeg, kend, t, rb);
 
   const int lr = lane & 31, lk = lane >> 5;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();  // previous tile fully consumed
-    tile_store<A_K>(As, t, ra);
-    tile_store<B_K>(Bs, t, rb);
+    tile_store<A_K, TBM>(As, t, ra);
+    tile_store<B_K, TBN>(Bs, t, rb);
     __syncthreads();
     if (k0 + BK < kend) {  // prefetch the next tile while this one is multiplied
-      tile_load<A_K>(A, lda, vecA, m0, M, k0 + BK, kend, t, ra);
-      tile_load<B_K>(Bm, ldb, vecB, n0, N, k0 + BK, kend, t, rb);
+      tile_load<A_K, TBM>(A, lda, vecA, m0, M, k0 + BK, kend, t, ra);
+      tile_load<B_K, TBN>(Bm, ldb, vecB, n0, N, k0 + BK, kend, t, rb);
     }
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       const int k = 2 * kk + lk;
-      const float a0 = As[k * SA + wm * 64 + lr];
-      const float a1 = As[k * SA + wm * 64 + 32 + lr];
-      const float b0 = Bs[k * SB + wn * 64 + lr];
-      const float b1 = Bs[k * SB + wn * 64 + 32 + lr];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[k * SA + wm * (32 * TM) + i * 32 + lr];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[k * SB + wn * (32 * TN) + j * 32 + lr];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
 
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        const int n = n0 + wn * 64 + j * 32 + lr;
+        const int m = m0 + wm * (32 * TM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int n = n0 + wn * (32 * TN) + j * 32 + lr;
         if (m < M && n < N) {
           if (partial) {
             partial[((int64_t)blockIdx.z * M + m) * N + n] = acc[i][j][r];
@@ -169,20 +190,202 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const int n = (int)(p % N);
     const int m = (int)(p / N);
     float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += partial[(int64_t)s * total + p];
+    int s = 0;
+    for (; s + 7 < splits; s += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = partial[(int64_t)(s + u) * total + p];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; s < splits; ++s) v += partial[(int64_t)s * total + p];
     float* cp = C + (int64_t)m * ldc + n;
     *cp = epilogue(epi, v, m, n, N, cp);
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Weight-gradient GEMM for small outputs:  C[M,N] = A^T B,  A stored [K,M], B stored [K,N],
+// K = batch (huge), M*N small.  No LDS staging: for a fixed k the M (resp. N) index is
+// contiguous in memory, which IS the MFMA operand layout (lane l holds A[k0 + (l>>5)][m0 + (l&31)]),
+// so fragments are loaded straight from global memory in 128-byte segments.  Each wave owns a
+// (32*TM) x (32*TN) output tile over its own K slice; the four waves of a block cover four
+// consecutive K slices and are summed through LDS in a fixed order; blocks write partial slabs
+// that a second kernel adds in slab order.  The column sums of B (= the bias gradient) fall out
+// of the B fragments for free.
+// ---------------------------------------------------------------------------------------
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad_stream_kernel(int M, int N, int K, const float* __restrict__ A,
+                                                          int64_t lda, const float* __restrict__ Bm, int64_t ldb,
+                                                          int k_per_wave, float* __restrict__ part,
+                                                          float* __restrict__ bias_part) {
+  extern __shared__ float red[];  // 2 * (TM*TN*16*64) floats
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 31, lk = lane >> 5;
+  const int m0 = blockIdx.y * (32 * TM), n0 = blockIdx.x * (32 * TN);
+  const int64_t kbeg = ((int64_t)blockIdx.z * 4 + wave) * k_per_wave;
+  const int64_t kend = kbeg + k_per_wave < K ? kbeg + k_per_wave : K;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bsum[j] = 0.f;
+  bool mok[TM], nok[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) mok[i] = m0 + i * 32 + lr < M;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) nok[j] = n0 + j * 32 + lr < N;
+  // per-tile row pointers walk down K two rows at a time (this lane's k parity is lk)
+  const float* ap = A + (kbeg + lk) * lda + m0 + lr;
+  const float* bp = Bm + (kbeg + lk) * ldb + n0 + lr;
+  const int64_t astep = 2 * lda, bstep = 2 * ldb;
+  const int steps = (int)((kend - kbeg + 1) / 2);
+  const int last_live = (int)(kend - kbeg) - lk;   // this lane's k offset must stay below this (exclusive: k < kend)
+#pragma unroll 2
+  for (int it = 0; it < steps; ++it) {
+    const bool kok = 2 * it < last_live;
+    float a[TM], b[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[i] = (kok && mok[i]) ? ap[i * 32] : 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      b[j] = (kok && nok[j]) ? bp[j * 32] : 0.f;
+      bsum[j] += b[j];
+    }
+    ap += astep;
+    bp += bstep;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+  // fixed-order sum over the four waves: (w2 -> w0, w3 -> w1), then (w1 -> w0)
+  constexpr int NACC = TM * TN * 16;
+  float* slot = red + (wave & 1) * (NACC * 64);
+  if (wave >= 2) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slot[((i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += slot[((i * TN + j) * 16 + r) * 64 + lane];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[i][j][r] + red[((i * TN + j) * 16 + r) * 64 + lane];
+          const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const int n = n0 + j * 32 + lr;
+          if (m < M && n < N) part[((int64_t)blockIdx.z * M + m) * N + n] = v;
+        }
+  }
+  if (bias_part && blockIdx.y == 0) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float v = bsum[j] + __shfl_xor(bsum[j], 32);  // k parity halves
+      if (lk == 0) red[(wave * TN + j) * 32 + lr] = v;
+    }
+    __syncthreads();
+    if (wave == 0 && lk == 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 32 + lr;
+        const float v = (red[(0 * TN + j) * 32 + lr] + red[(2 * TN + j) * 32 + lr]) +
+                        (red[(1 * TN + j) * 32 + lr] + red[(3 * TN + j) * 32 + lr]);
+        if (n < N) bias_part[(int64_t)blockIdx.z * N + n] = v;
+      }
+    }
+  }
+}
+
+// out[j] (+)= sum over slabs of part[s*cols + j]; block (64,4): slab phase ty takes slabs ty, ty+4, ...
+// eight loads in flight per thread; the four phases are added in a fixed order
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ part, int nslabs, int cols,
+                                                      float* __restrict__ out, int accumulate) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + tx;
+  float acc = 0.f;
+  if (j < cols) {
+    int s = ty;
+    for (; s + 28 < nslabs; s += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(s + 4 * u) * cols + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; s < nslabs; s += 4) acc += part[(int64_t)s * cols + j];
+  }
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && j < cols) {
+    const float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    out[j] = accumulate ? out[j] + v : v;
+  }
+}
+
+struct WPlan {
+  int tm, tn, tiles_m, tiles_n, nkb, k_per_wave;
+};
+
+static WPlan make_wplan(int M, int N, int K) {
+  WPlan p;
+  p.tm = M > 32 ? 2 : 1;   // 64x64 per wave at most: 64 accumulator registers keep two waves per SIMD
+  p.tn = N > 32 ? 2 : 1;
+  p.tiles_m = (int)cdiv(M, 32 * p.tm);
+  p.tiles_n = (int)cdiv(N, 32 * p.tn);
+  const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
+  int64_t nkb = cdiv(512, tiles);              // aim at >= 512 blocks
+  int64_t max_nkb = cdiv(K, 4 * 32);           // at least 32 samples per wave
+  if (nkb > max_nkb) nkb = max_nkb;
+  if (nkb < 1) nkb = 1;
+  p.k_per_wave = (int)(cdiv(cdiv(K, nkb * 4), 2) * 2);
+  p.nkb = (int)cdiv(K, (int64_t)p.k_per_wave * 4);
+  return p;
+}
+
 struct Plan {
-  int tiles_m, tiles_n, splits, k_chunk;
+  int bm, bn, tiles_m, tiles_n, splits, k_chunk;
 };
 
 static Plan make_plan(int M, int N, int K) {
   Plan p;
-  p.tiles_m = (int)cdiv(M, BM);
-  p.tiles_n = (int)cdiv(N, BN);
+  // narrow outputs get tall tiles so the MFMA work is not spent on padding columns
+  if (N <= 32) { p.bm = 256; p.bn = 32; }
+  else if (N <= 64) { p.bm = 256; p.bn = 64; }
+  else { p.bm = 128; p.bn = 128; }
+  p.tiles_m = (int)cdiv(M, p.bm);
+  p.tiles_n = (int)cdiv(N, p.bn);
   const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
   int splits = 1;
   if (tiles < 256 && K >= 8 * BK) {
@@ -242,20 +445,141 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
   const bool vecB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
   const dim3 grid(p.tiles_n, p.tiles_m, p.splits), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(AK, BK_)                                                                                 \
-  hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), grid, block, 0, st, M, N, K, A, lda, vecA, B, ldb, vecB, C, \
-                     ldc, e, p.k_chunk, partial)
+#define LAUNCH3(AK, BK_, TBM, TBN, WGM)                                                                     \
+  hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, TBM, TBN, WGM>), grid, block, 0, st, M, N, K, A, lda, vecA, B, ldb, \
+                     vecB, C, ldc, e, p.k_chunk, partial)
+#define LAUNCH(AK, BK_)                                    \
+  do {                                                     \
+    if (p.bn == 32) LAUNCH3(AK, BK_, 256, 32, 4);          \
+    else if (p.bn == 64) LAUNCH3(AK, BK_, 256, 64, 4);     \
+    else LAUNCH3(AK, BK_, 128, 128, 2);                    \
+  } while (0)
   if (!trans_a && !trans_b) LAUNCH(true, false);
   else if (!trans_a && trans_b) LAUNCH(true, true);
   else if (trans_a && !trans_b) LAUNCH(false, false);
   else LAUNCH(false, true);
 #undef LAUNCH
+#undef LAUNCH3
   if (partial) {
     const int64_t total = (int64_t)M * N;
     const int64_t blocks = cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, partial, p.splits, M, N,
                        C, ldc, e);
   }
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+// Stream path is used when the output is small next to K: M*N <= 8192, N <= 128, K >= 2048.
+static bool wgrad_streams(int M, int N, int K) { return (int64_t)M * N <= 8192 && N <= 128 && K >= 2048; }
+
+extern "C" size_t ctr_dense_wgrad_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (wgrad_streams(M, N, K)) {
+    const WPlan p = make_wplan(M, N, K);
+    return (size_t)p.nkb * ((size_t)M * N + N) * sizeof(float);
+  }
+  const size_t a = ctr_gemm_f32_workspace_bytes(M, N, K);
+  const size_t b = (size_t)128 * N * sizeof(float);   // column-sum partials
+  return a > b ? a : b;
+}
+
+namespace ctr {
+// column sums of X[B,K] into per-chunk partial rows; V4: 16 bytes per lane (K % 4 == 0, ld % 4 == 0)
+template <bool V4>
+__global__ __launch_bounds__(256) void wgrad_colsum_partial(const float* __restrict__ X, int64_t ld, int B, int K,
+                                                           int rows_per_chunk, float* __restrict__ part) {
+  constexpr int W = V4 ? 4 : 1;
+  __shared__ float red[4][64 * W];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = (blockIdx.x * 64 + tx) * W;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+  const int64_t r1 = r0 + rows_per_chunk < B ? r0 + rows_per_chunk : B;
+  float acc[W];
+#pragma unroll
+  for (int u = 0; u < W; ++u) acc[u] = 0.f;
+  if (j < K) {
+    int64_t r = r0 + ty;
+    for (; r + 12 < r1; r += 16) {   // four independent row loads in flight
+      if (V4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(X + (r + 4 * u) * ld + j);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc[0] += v[u].x; acc[1 % W] += v[u].y; acc[2 % W] += v[u].z; acc[3 % W] += v[u].w; }
+      } else {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = X[(r + 4 * u) * ld + j];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[0] += v[u];
+      }
+    }
+    for (; r < r1; r += 4) {
+      if (V4) {
+        const float4 v = *reinterpret_cast<const float4*>(X + r * ld + j);
+        acc[0] += v.x; acc[1 % W] += v.y; acc[2 % W] += v.z; acc[3 % W] += v.w;
+      } else {
+        acc[0] += X[r * ld + j];
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < W; ++u) red[ty][tx * W + u] = acc[u];
+  __syncthreads();
+  if (ty == 0 && j < K) {
+#pragma unroll
+    for (int u = 0; u < W; ++u)
+      part[(int64_t)blockIdx.y * K + j + u] =
+          (red[0][tx * W + u] + red[1][tx * W + u]) + (red[2][tx * W + u] + red[3][tx * W + u]);
+  }
+}
+}  // namespace ctr
+
+extern "C" int ctr_dense_wgrad(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                               float* dW, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+  CTR_REQUIRE(M > 0 && N > 0 && K > 0, "ctr_dense_wgrad: sizes must be positive");
+  CTR_REQUIRE(A && B && dW, "ctr_dense_wgrad: null pointer");
+  CTR_REQUIRE(lda >= M && ldb >= N, "ctr_dense_wgrad: leading dimension too small");
+  const size_t need = ctr_dense_wgrad_workspace_bytes(M, N, K);
+  if (!workspace || workspace_bytes < need) {
+    set_error("ctr_dense_wgrad: workspace %zu < %zu", workspace_bytes, need);
+    return CTR_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (!wgrad_streams(M, N, K)) {
+    const int rc = ctr_gemm_f32(1, 0, M, N, K, A, lda, B, ldb, dW, N, nullptr, workspace, workspace_bytes, stream);
+    if (rc != CTR_OK || !db) return rc;
+    // bias gradient: fixed-order column sums of B (the slab region is free again: same stream)
+    const int nchunks = K < 128 * 64 ? (int)cdiv(K, 64) : 128;
+    const int rows_per_chunk = (int)cdiv(K, nchunks);
+    float* part = (float*)workspace;
+    if (N % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)B % 16) == 0)
+      hipLaunchKernelGGL(wgrad_colsum_partial<true>, dim3((unsigned)cdiv(N, 256), nchunks), dim3(256), 0, st, B, ldb,
+                         K, N, rows_per_chunk, part);
+    else
+      hipLaunchKernelGGL(wgrad_colsum_partial<false>, dim3((unsigned)cdiv(N, 64), nchunks), dim3(256), 0, st, B, ldb,
+                         K, N, rows_per_chunk, part);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, part, nchunks, N, db, 0);
+    CTR_LAUNCH_CHECK();
+    return CTR_OK;
+  }
+  const WPlan p = make_wplan(M, N, K);
+  float* part = (float*)workspace;
+  float* bias_part = db ? part + (size_t)p.nkb * M * N : nullptr;
+  const dim3 grid(p.tiles_n, p.tiles_m, p.nkb), block(256);
+  const size_t lds = (size_t)2 * p.tm * p.tn * 16 * 64 * sizeof(float);
+#define WLAUNCH(TM_, TN_)                                                                                  \
+  hipLaunchKernelGGL((wgrad_stream_kernel<TM_, TN_>), grid, block, lds, st, M, N, K, A, lda, B, ldb, p.k_per_wave, \
+                     part, bias_part)
+  if (p.tm == 2 && p.tn == 2) WLAUNCH(2, 2);
+  else if (p.tm == 2 && p.tn == 1) WLAUNCH(2, 1);
+  else if (p.tm == 1 && p.tn == 2) WLAUNCH(1, 2);
+  else WLAUNCH(1, 1);
+#undef WLAUNCH
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv((int64_t)M * N, 64)), dim3(256), 0, st, part, p.nkb, M * N,
+                     dW, 0);
+  if (db) hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, bias_part, p.nkb, N, db, 0);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }

@@ -62,18 +62,38 @@ __global__ __launch_bounds__(256) void sparse_apply_kernel(
   const bool run_head = item == 0 || keys[item - 1] != key;
   if (!run_head && (item % SEG) != 0) return;  // not the start of a piece
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Walk the piece four pairs at a time: the four (src, row) loads are issued together and then
+  // added in sorted order, stopping at the first pair that leaves the piece.
+  const int64_t piece_end = (item / SEG + 1) * SEG < n_items ? (item / SEG + 1) * SEG : n_items;
   int64_t j = item;
-  bool more;
-  do {
-    const uint32_t sj = src[j];
-    const int64_t b = sj / (uint32_t)N;
-    const int64_t n = sj % (uint32_t)N;
-    const float4 v = *reinterpret_cast<const float4*>(dz + b * dz_ld + n * E + g * 4);
-    const float sc = src_scale ? src_scale[sj] : 1.f;
-    acc.x += v.x * sc; acc.y += v.y * sc; acc.z += v.z * sc; acc.w += v.w * sc;
-    ++j;
-    more = j < n_items && keys[j] == key;
-  } while (more && (j % SEG) != 0);
+  bool more = true;   // "pair j belongs to this run" for the pair the loop is about to add
+  while (more && j < piece_end) {
+    uint32_t kk[4], sj[4];
+    float4 v[4];
+    float sc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t q = j + u < n_items ? j + u : n_items - 1;
+      kk[u] = keys[q];
+      sj[u] = src[q];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t b = sj[u] / (uint32_t)N;
+      const int64_t n = sj[u] % (uint32_t)N;
+      v[u] = *reinterpret_cast<const float4*>(dz + b * dz_ld + n * E + g * 4);
+      sc[u] = src_scale ? src_scale[sj[u]] : 1.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool inside = j + u < piece_end;
+      if (inside && kk[u] != key) more = false;          // the run ends inside this piece
+      if (more && inside) { acc.x += v[u].x * sc[u]; acc.y += v[u].y * sc[u]; acc.z += v[u].z * sc[u]; acc.w += v[u].w * sc[u]; }
+    }
+    j += 4;
+  }
+  // does the run continue past this piece?
+  more = more && piece_end < n_items && keys[piece_end] == key;
   const int64_t blk = item / SEG;
   if (run_head && !more) {
     const int64_t off = (int64_t)key * E + g * 4;

@@ -208,8 +208,7 @@ class Tower:
         for i in range(n - 1, -1, -1):
             wn, bn = self.names[i]
             h_in = x[:, :self.d_in] if i == 0 else acts[i - 1]
-            ops.gemm(h_in, g, self.dense.g(wn), trans_a=True, ws=ws)                 # dW = h_in^T g
-            ops.colsum(g, self.dense.g(bn).reshape(-1), ws=ws)                        # db
+            ops.dense_wgrad(h_in, g, self.dense.g(wn), self.dense.g(bn).reshape(-1), ws=ws)   # dW = h_in^T g, db
             if i > 0:
                 ops.gemm(g, self.dense.p(wn), gbufs[i - 1], trans_b=True, mask_src=acts[i - 1],
                          mask_scale=scale[i - 1], ws=ws)

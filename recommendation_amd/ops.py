@@ -22,11 +22,22 @@ def lib():
 
 
 class KernelTimer:
-    """Optional HIP-event timer around every operator call (events are recorded on the stream
-    the kernels run on).  Used by bench.py to attribute the timed region to kernels."""
+    """Optional HIP-event timer around operator calls (events are recorded on the stream the kernels
+    run on).  Used by bench.py to attribute the timed region to kernels.  Events come from a
+    pre-allocated pool and `only` restricts the timed operators, so the host cost stays small."""
 
-    def __init__(self):
+    def __init__(self, only=None, pool=4096):
+        self.only = set(only) if only else None
+        self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(pool)]
+        self.used = 0
         self.records = []          # (name, start_event, end_event)
+
+    def pair(self):
+        if self.used + 2 > len(self.pool):
+            return None
+        a, b = self.pool[self.used], self.pool[self.used + 1]
+        self.used += 2
+        return a, b
 
     def summary(self):
         torch.cuda.synchronize()
@@ -51,10 +62,12 @@ def _timed(fn):
 
     @functools.wraps(fn)
     def wrap(*a, **k):
-        if _TIMER is None:
+        if _TIMER is None or (_TIMER.only is not None and fn.__name__ not in _TIMER.only):
             return fn(*a, **k)
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
+        ev = _TIMER.pair()
+        if ev is None:
+            return fn(*a, **k)
+        e0, e1 = ev
         e0.record()
         r = fn(*a, **k)
         e1.record()
@@ -64,6 +77,8 @@ def _timed(fn):
             ta = bool(k.get('trans_a', False))
             name = 'gemm_%dx%dx%d_%s%s' % (Cout.shape[0], Cout.shape[1], A.shape[0] if ta else A.shape[1],
                                             'T' if ta else 'N', 'T' if k.get('trans_b', False) else 'N')
+        elif name == 'dense_wgrad':             # and per weight-gradient shape (M x N x K)
+            name = 'wgrad_%dx%dx%d' % (a[0].shape[1], a[1].shape[1], a[0].shape[0])
         _TIMER.records.append((name, e0, e1))
         return r
     return wrap
@@ -290,6 +305,20 @@ def gemm(A, B_, Cout, *, trans_a=False, trans_b=False, bias=None, relu=False, si
         wp, wn = ws.get(need)
     check(lib().ctr_gemm_f32(int(trans_a), int(trans_b), M, N, K, ap, lda, bp, ldb, cp, ldc, C.byref(epi), wp, wn,
                              _stream()), 'ctr_gemm_f32')
+
+
+@_timed
+def dense_wgrad(x, g, dW, db=None, *, ws):
+    """dW[M,N] = x^T g (x: [K,M] view, g: [K,N] view), db[N] = column sums of g."""
+    K, M = x.shape
+    N = g.shape[1]
+    xp, lda = _rows(x, 'x')
+    gp, ldb = _rows(g, 'g')
+    if g.shape[0] != K or dW.numel() != M * N or not dW.is_contiguous() or (db is not None and db.numel() != N):
+        raise ValueError('dense_wgrad shape mismatch')
+    wp, wn = ws.get(lib().ctr_dense_wgrad_workspace_bytes(M, N, K))
+    check(lib().ctr_dense_wgrad(M, N, K, xp, lda, gp, ldb, _ptr(dW, torch.float32), _ptr(db, torch.float32), wp, wn,
+                                _stream()), 'ctr_dense_wgrad')
 
 
 @_timed

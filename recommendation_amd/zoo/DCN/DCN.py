@@ -66,8 +66,7 @@ class DCN(CTRModel):
         stack, dstack, dl = bufs['stack'], bufs['dstack'], bufs['dlogit']
         wn, bn = 'stack_layer/stack_w_%d' % (n - 1), 'stack_layer/stack_b_%d' % (n - 1)
         ops.rowdot_bwd_x(dl, self.dense.p(wn).reshape(-1), dstack)
-        ops.colsum(stack, self.dense.g(wn).reshape(-1), w=dl.view(B, 1), w_group=self.stack_width, ws=ws)
-        ops.colsum(dl.view(B, 1), self.dense.g(bn), ws=ws)
+        ops.dense_wgrad(stack, dl.view(B, 1), self.dense.g(wn), self.dense.g(bn), ws=ws)
         self.tower.backward(bufs['x0'], bufs['acts'], dstack[:, D:], bufs['gbufs'], [self.dropout] * n,
                             bufs['dx0'], ws)
         ops.cross_bwd(bufs['x0'], self.dense.stacked(self._wn), self.dense.stacked(self._bn), bufs['aux'],

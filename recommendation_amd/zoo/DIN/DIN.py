@@ -231,8 +231,7 @@ class DIN(object):
         # backward: FCN
         dl = b['dlogit']
         ops.rowdot_bwd_x(dl, d.p('fcn/f3/kernel').reshape(-1), b['da2'])
-        ops.colsum(b['a2'], d.g('fcn/f3/kernel').reshape(-1), w=dl.view(B, 1), w_group=40, ws=ws)
-        ops.colsum(dl.view(B, 1), d.g('fcn/f3/bias'), ws=ws)
+        ops.dense_wgrad(b['a2'], dl.view(B, 1), d.g('fcn/f3/kernel'), d.g('fcn/f3/bias'), ws=ws)
         ops.dice_bwd(b['f2'], d.p('fcn/alphadice_2_i'), b['da2'], b['df2'], b['t40'], BN_EPS)
         ops.colsum(b['t40'], d.g('fcn/alphadice_2_i'), ws=ws)
         ops.gemm(b['a1'], b['df2'], d.g('fcn/f2/kernel'), trans_a=True, ws=ws)
@@ -261,8 +260,7 @@ class DIN(object):
         # backward: attention MLP
         ds = b['dscore']
         ops.rowdot_bwd_x(ds, d.p('embedding/f3_att/kernel').reshape(-1), b['g2'])
-        ops.colsum(b['d2'], d.g('embedding/f3_att/kernel').reshape(-1), w=ds.view(B * T, 1), w_group=40, ws=ws)
-        ops.colsum(ds.view(B * T, 1), d.g('embedding/f3_att/bias'), ws=ws)
+        ops.dense_wgrad(b['d2'], ds.view(B * T, 1), d.g('embedding/f3_att/kernel'), d.g('embedding/f3_att/bias'), ws=ws)
         ops.dsigmoid_apply(b['g2'], b['d2'])
         ops.gemm(b['d1'], b['g2'], d.g('embedding/f2_att/kernel'), trans_a=True, ws=ws)
         ops.colsum(b['g2'], d.g('embedding/f2_att/bias'), ws=ws)

@@ -62,8 +62,7 @@ class DeepFM(CTRModel):
         concat, dconcat, dl = bufs['concat'], bufs['dconcat'], bufs['dlogit']
         wn, bn = 'output_unit/output_w_%d' % (n - 1), 'output_unit/output_b_%d' % (n - 1)
         ops.rowdot_bwd_x(dl, self.dense.p(wn).reshape(-1), dconcat)
-        ops.colsum(concat, self.dense.g(wn).reshape(-1), w=dl.view(B, 1), w_group=self.concat_width, ws=ws)
-        ops.colsum(dl.view(B, 1), self.dense.g(bn), ws=ws)
+        ops.dense_wgrad(concat, dl.view(B, 1), self.dense.g(wn), self.dense.g(bn), ws=ws)
         self.tower.backward(bufs['x0'], bufs['acts'], dconcat[:, N + E:], bufs['gbufs'],
                             [self.dropout_deep] * n, bufs['dx0'], ws)
         ops.embed_bwd_dz(bufs['dx0'], B=B, N=N, E=E, gz=bufs['dx0'], g_first=dconcat[:, :N],

@@ -70,8 +70,7 @@ class ESMM(CTRModel):
             dl, last = bufs[t + '_dlogit'], bufs[t + '_acts'][-1]
             wn, bn = '%s_deep_part/%s_output_w' % (t, t), '%s_deep_part/%s_output_b' % (t, t)
             ops.rowdot_bwd_x(dl, self.dense.p(wn).reshape(-1), bufs[t + '_glast'])
-            ops.colsum(last, self.dense.g(wn).reshape(-1), w=dl.view(B, 1), w_group=last.shape[1], ws=ws)
-            ops.colsum(dl.view(B, 1), self.dense.g(bn), ws=ws)
+            ops.dense_wgrad(last, dl.view(B, 1), self.dense.g(wn), self.dense.g(bn), ws=ws)
             self.towers[t].backward(bufs['inp'], bufs[t + '_acts'], bufs[t + '_glast'], bufs[t + '_gbufs'],
                                     [self.dropout] * n, bufs['dinp'], ws, accumulate_dx=(k == 1))
         ops.embed_bwd_dz(bufs['dz'], B=B, N=self.N, E=self.embed_size, g_first=bufs['dinp'][:, :self.N])

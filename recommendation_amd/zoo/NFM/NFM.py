@@ -59,8 +59,7 @@ class NFM(CTRModel):
         dl, last = bufs['dlogit'], bufs['acts'][-1]
         wn, bn = 'output/output_w_%d' % (n - 1), 'output/output_b_%d' % (n - 1)
         ops.rowdot_bwd_x(dl, self.dense.p(wn).reshape(-1), bufs['glast'])
-        ops.colsum(last, self.dense.g(wn).reshape(-1), w=dl.view(B, 1), w_group=last.shape[1], ws=ws)
-        ops.colsum(dl.view(B, 1), self.dense.g(bn), ws=ws)
+        ops.dense_wgrad(last, dl.view(B, 1), self.dense.g(wn), self.dense.g(bn), ws=ws)
         self.tower.backward(bufs['x0'], bufs['acts'], bufs['glast'], bufs['gbufs'], [self.dropout_deep] * n,
                             bufs['dx0'], ws)
         ops.embed_bwd_dz(bufs['z'], B=B, N=self.N, E=E, g_second=bufs['dx0'][:, :E], s=bufs['s'], z=bufs['z'],

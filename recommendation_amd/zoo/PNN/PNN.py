@@ -104,8 +104,7 @@ class PNN(CTRModel):
         n = len(self.hidden_layers)
         dl, last = bufs['dlogit'], bufs['acts'][-1]
         ops.rowdot_bwd_x(dl, d.p('hidden/output_w').reshape(-1), bufs['glast'])
-        ops.colsum(last, d.g('hidden/output_w').reshape(-1), w=dl.view(B, 1), w_group=last.shape[1], ws=ws)
-        ops.colsum(dl.view(B, 1), d.g('hidden/output_b'), ws=ws)
+        ops.dense_wgrad(last, dl.view(B, 1), d.g('hidden/output_w'), d.g('hidden/output_b'), ws=ws)
         self.tower.backward(bufs['prod'], bufs['acts'], bufs['glast'], bufs['gbufs'], [self.dropout] * n,
                             bufs['dprod'], ws)
         gpre = bufs['dprod']

@@ -1,0 +1,54 @@
+"""Micro-benchmark of ctr_gemm_f32 on the tower shapes (run on the GPU box)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import recommendation_amd as ra
+from recommendation_amd import ops
+
+sess = ra.Session('cuda:0')
+ws = sess.ws
+B = 65536
+shapes = [  # (name, M, N, K, ta, tb)
+    ('fwd0', B, 256, 429, 0, 0), ('fwd1', B, 128, 256, 0, 0), ('fwd2', B, 64, 128, 0, 0), ('fwd3', B, 32, 64, 0, 0),
+    ('dx0', B, 429, 256, 0, 1), ('dx1', B, 256, 128, 0, 1), ('dx2', B, 128, 64, 0, 1), ('dx3', B, 64, 32, 0, 1),
+    ('dw0', 429, 256, B, 1, 0), ('dw1', 256, 128, B, 1, 0), ('dw2', 128, 64, B, 1, 0), ('dw3', 64, 32, B, 1, 0),
+    ('sq4k', 4096, 4096, 4096, 0, 0),
+]
+for name, M, N, K, ta, tb in shapes:
+    def mk(r, c):
+        ld = (c + 3) // 4 * 4
+        return torch.randn(r, ld, device='cuda')[:, :c]
+    A = mk(K, M) if ta else mk(M, K)
+    Bm = mk(N, K) if tb else mk(K, N)
+    C = mk(M, N)
+    bias = torch.randn(N, device='cuda')
+    for _ in range(3):
+        ops.gemm(A, Bm, C, trans_a=bool(ta), trans_b=bool(tb), ws=ws)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        ops.gemm(A, Bm, C, trans_a=bool(ta), trans_b=bool(tb), ws=ws)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    print('%-6s M=%6d N=%5d K=%6d  %8.1f us  %6.1f TF' % (name, M, N, K, us, 2.0 * M * N * K / us / 1e6))
+print('--- dense_wgrad')
+for name, M, N, K in [('dw0', 429, 256, B), ('dw1', 256, 128, B), ('dw2', 128, 64, B), ('dw3', 64, 32, B), ('dwo', 74, 1, B)]:
+    x = torch.randn(K, (M + 3) // 4 * 4, device='cuda')[:, :M]
+    g = torch.randn(K, (N + 3) // 4 * 4, device='cuda')[:, :N]
+    dW = torch.zeros(M, N, device='cuda'); db = torch.zeros(N, device='cuda')
+    for _ in range(3):
+        ops.dense_wgrad(x, g, dW, db, ws=ws)
+    torch.cuda.synchronize()
+    ref = x.double().t() @ g.double()
+    err = ((dW.double() - ref).abs().max() / ref.abs().max()).item()
+    errb = ((db.double() - g.double().sum(0)).abs().max() / g.double().sum(0).abs().max()).item()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.dense_wgrad(x, g, dW, db, ws=ws)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 20
+    print('%-4s M=%4d N=%4d K=%6d %8.1f us %6.1f TF  relerr %.2e  bias %.2e' % (name, M, N, K, us, 2.0 * M * N * K / us / 1e6, err, errb))
