@@ -32,10 +32,12 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=65536, help='per-GPU batch')
-    ap.add_argument('--embed', type=int, default=16)
+    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: 65536 DeepFM, 8192 DCN)')
+    ap.add_argument('--embed', type=int, default=0, help='embedding dim (default: 16 DeepFM, 64 DCN)')
     ap.add_argument('--alpha', type=float, default=1.05, help='Zipf exponent of the ids (0 = uniform)')
     ap.add_argument('--model', default='DeepFM', choices=['DeepFM', 'DCN'])
+    ap.add_argument('--comm', default='rccl', choices=['rccl', 'host-staged'],
+                    help='host-staged: gloo through host memory, to rehearse N>1 with all ranks on one GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timers', action='store_true')
     return ap.parse_args()
@@ -58,6 +60,9 @@ def build_model(args, sess, cards, rank, world):
         cls = mod.DCN
     if world > 1:
         margs.world_size, margs.rank = world, rank
+        if args.comm == 'host-staged':
+            from recommendation_amd.distributed import HostStagedComm
+            margs.comm = HostStagedComm()
     m = cls(margs, len(cards), 13, cards)
     m.build()
     m.initialize(sess, seed=1234)
@@ -97,6 +102,10 @@ def cpu_baseline(args, cards):
 
 def main():
     args = parse()
+    if not args.batch:
+        args.batch = 65536 if args.model == 'DeepFM' else 8192
+    if not args.embed:
+        args.embed = 16 if args.model == 'DeepFM' else 64
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -108,15 +117,23 @@ def main():
         raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
     import recommendation_amd as ra
     from recommendation_amd import ops
-    from recommendation_amd.synthetic import CRITEO_KAGGLE, make_batches
+    from recommendation_amd.synthetic import CRITEO_1TB, CRITEO_KAGGLE, make_batches, scaled
 
+    if args.comm == 'host-staged':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = 'cuda:%d' % local_rank
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device(dev))
+        if args.comm == 'host-staged':
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device(dev))
     sess = ra.Session(dev, seed=11 + rank)
-    cards = CRITEO_KAGGLE
+    # DeepFM: BASELINE configs[1] (Criteo-Kaggle cardinalities).  DCN: configs[2] per-GPU share —
+    # Criteo-1TB cardinalities / 8 (one GPU of the 8-GPU shard), dim 64, 6 cross layers, 1024x3 tower.
+    cards = CRITEO_KAGGLE if args.model == 'DeepFM' else scaled(CRITEO_1TB, 8 // min(world, 8))
+    shape_name = 'Criteo-Kaggle' if args.model == 'DeepFM' else 'Criteo-1TB/%d' % (8 // min(world, 8))
     model = build_model(args, sess, cards, rank, world)
     B = args.batch
     batches = make_batches(cards, 13, B, 8, args.alpha, 20240601 + rank, dev)
@@ -141,7 +158,7 @@ def main():
     ops.set_timer(None)
     loss = float(model._loss_dev.item())
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device='cpu' if args.comm == 'host-staged' else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
@@ -153,10 +170,10 @@ def main():
                value=value, unit='samples/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling='weak', vs_baseline=None,
                dtype='f32', data='synthetic',
-               config=dict(workload='%s Criteo-Kaggle shape: 13 dense + 26 sparse fields, sum(V)=%d rows, '
+               config=dict(workload='%s %s shape: 13 dense + 26 sparse fields, sum(V)=%d rows, '
                                     'embed dim %d, per-GPU batch %d, Zipf(%.2f) ids, fwd+bwd+Adam (sparse rows: '
                                     'row-wise Adam on touched rows), dropout at the reference rates'
-                                    % (args.model, int(np.sum(cards)), args.embed, B, args.alpha),
+                                    % (args.model, shape_name, int(np.sum(cards)), args.embed, B, args.alpha),
                            global_batch=world * B, parallelism='dp%d' % world if world > 1 else 'single'),
                final_loss=loss)
     if timer is not None:

@@ -34,21 +34,21 @@ __device__ static inline float epilogue(const Epi& e, float v, int m, int n, int
   return v;
 }
 
-// Fetch this thread's share of an R x 16 operand tile (R = 32..256) as float4 slots.
-//   KCONTIG: element (r, k) at P[r*ld + k]   (rows = the M or N index); slot -> (r = s/4, k = 4*(s%4))
+// Fetch this thread's share of an R x BK operand tile (R = 32..256) as float4 slots.
+//   KCONTIG: element (r, k) at P[r*ld + k]   (rows = the M or N index); slot -> (r = s/(BK/4), k = 4*(s%(BK/4)))
 //   else:    element (r, k) at P[k*ld + r];                            slot -> (k = s/(R/4), r = 4*(s%(R/4)))
 template <bool KCONTIG, int R>
 __device__ static inline void tile_load(const float* __restrict__ P, int64_t ld, bool vec, int r0, int rmax,
-                                        int k0, int kend, int t, float (&reg)[(R * 4 + 255) / 256 * 4]) {
-  constexpr int SLOTS = R * 4;
+                                        int k0, int kend, int t, float (&reg)[(R * (BK / 4) + 255) / 256 * 4]) {
+  constexpr int SLOTS = R * (BK / 4);
 #pragma unroll
   for (int j = 0; j < (SLOTS + 255) / 256; ++j) {
     const int s = t + 256 * j;
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
     if (SLOTS % 256 == 0 || s < SLOTS) {
       if (KCONTIG) {
-        const int r = r0 + (s >> 2);
-        const int k = k0 + (s & 3) * 4;
+        const int r = r0 + s / (BK / 4);
+        const int k = k0 + (s % (BK / 4)) * 4;
         const float* p = P + (int64_t)r * ld + k;
         if (r < rmax && vec && k + 3 < kend) {
           const float4 v = *reinterpret_cast<const float4*>(p);
@@ -79,16 +79,16 @@ __device__ static inline void tile_load(const float* __restrict__ P, int64_t ld,
 }
 
 template <bool KCONTIG, int R>
-__device__ static inline void tile_store(float* __restrict__ S, int t, const float (&reg)[(R * 4 + 255) / 256 * 4]) {
-  constexpr int SLOTS = R * 4;
+__device__ static inline void tile_store(float* __restrict__ S, int t, const float (&reg)[(R * (BK / 4) + 255) / 256 * 4]) {
+  constexpr int SLOTS = R * (BK / 4);
   constexpr int LD = KCONTIG ? R + 2 : R + 4;
 #pragma unroll
   for (int j = 0; j < (SLOTS + 255) / 256; ++j) {
     const int s = t + 256 * j;
     if (SLOTS % 256 == 0 || s < SLOTS) {
       if (KCONTIG) {
-        const int r = s >> 2;
-        const int k = (s & 3) * 4;
+        const int r = s / (BK / 4);
+        const int k = (s % (BK / 4)) * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) S[(k + i) * LD + r] = reg[4 * j + i];
       } else {
@@ -102,7 +102,7 @@ __device__ static inline void tile_store(float* __restrict__ S, int t, const flo
 }
 
 // A_K: A stored [M,K] (k contiguous).  B_K: B stored [N,K] (k contiguous).
-// Tile TBM x TBN x 16, four waves as WGM x (4/WGM); a wave owns TM x TN MFMA tiles of 32x32.
+// Tile TBM x TBN x BK, four waves as WGM x (4/WGM); a wave owns TM x TN MFMA tiles of 32x32.
 template <bool A_K, bool B_K, int TBM, int TBN, int WGM>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A,
                                                       int64_t lda, bool vecA, const float* __restrict__ Bm,
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
   constexpr int TM = TBM / WGM / 32, TN = TBN / WGN / 32;
   constexpr int SA = A_K ? TBM + 2 : TBM + 4;
   constexpr int SB = B_K ? TBN + 2 : TBN + 4;
-  constexpr int RA = (TBM * 4 + 255) / 256 * 4, RB = (TBN * 4 + 255) / 256 * 4;
+  constexpr int RA = (TBM * (BK / 4) + 255) / 256 * 4, RB = (TBN * (BK / 4) + 255) / 256 * 4;
   __shared__ __attribute__((aligned(16))) float As[BK * SA];
   __shared__ __attribute__((aligned(16))) float Bs[BK * SB];
   const int t = threadIdx.x;

@@ -55,6 +55,40 @@ class TorchComm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
 
+class HostStagedComm:
+    """Same collectives staged through host memory over a gloo group.  For rehearsing the multi-rank
+    path when several ranks share one GPU (RCCL cannot place two ranks on one device); never the
+    transport of a real multi-GPU run."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_to_all(self, out, inp, out_splits, in_splits):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        i = inp.detach().cpu()
+        outs, ins = list(o.split(out_splits)), list(i.split(in_splits))
+        outs[self.rank].copy_(ins[self.rank])
+        reqs = []
+        for j in range(self.world):
+            if j != self.rank:
+                if ins[j].numel():
+                    reqs.append(self.dist.isend(ins[j].contiguous(), j, group=self.group))
+                if outs[j].numel():
+                    reqs.append(self.dist.irecv(outs[j], j, group=self.group))
+        for r in reqs:
+            r.wait()
+        out.copy_(o)
+
+    def all_reduce_sum(self, t):
+        c = t.detach().cpu()
+        self.dist.all_reduce(c, group=self.group)
+        t.copy_(c)
+
+
 class ShardedFront:
     """Drop-in for engine.EmbedFront (S semantics) when the tables are sharded over ranks."""
 
