@@ -100,6 +100,19 @@ def cpu_baseline(args, cards):
                        % (B, n, div, int(np.sum(small))))
 
 
+def load_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC pass (FETCH_SIZE/WRITE_SIZE collected in
+    separate runs, gfx950 x2 read correction; see tools/pmc_summary.py), keyed by kernel symbol."""
+    path = os.path.join(ROOT, 'profiles', 'r01_b_deepfm_c2_pmc_traffic.json')
+    out = {}
+    if os.path.exists(path):
+        for k, v in json.load(open(path)).items():
+            for sym in ('embed_fwd_kernel', 'sparse_apply_kernel', 'embed_bwd_dz_kernel'):
+                if sym + '<' in k or sym + '(' in k:
+                    out[sym] = out.get(sym, 0) + v['hbm_bytes_per_launch']
+    return out
+
+
 def main():
     args = parse()
     if not args.batch:
@@ -143,6 +156,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # distinct table rows touched per step (for the algorithmic bytes of the sparse update)
+    offs = torch.as_tensor(np.concatenate([[0], np.cumsum(cards)[:-1]]), device=dev)
+    uniq = float(np.mean([torch.unique(b[0].to(torch.int64) + offs).numel() for b in batches]))
     for i in range(args.warmup):
         model.train_step(*batches[i % len(batches)])
     timer = None
@@ -179,29 +195,39 @@ def main():
     if timer is not None:
         ks = timer.summary()
         F, E = len(cards), args.embed
-        # algorithmic bytes per sample: ids + row read + row write (embedding gather forward)
-        emb_bytes = F * (4 + E * 4 + E * 4) * B
-        k = ks.get('embed_fwd')
-        roof_emb = None
-        if k:
-            ach = emb_bytes / (k['avg_us'] * 1e-6) / 1e9
-            roof_emb = dict(kernel='embed_fwd_kernel (gather + FM first/second order + concat)', bound='hbm',
-                            achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
-                            traffic=None, avg_us=k['avg_us'], bytes_per_launch=emb_bytes)
+        traffic = load_traffic()
+
+        def hbm_roof(name, kernel, nbytes, avg_us, sym):
+            ach = nbytes / (avg_us * 1e-6) / 1e9
+            return dict(kernel=kernel, bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=ach / HBM_PEAK_GBS, traffic=traffic.get(sym), avg_us=avg_us, bytes_per_launch=nbytes)
+
+        def mfma_roof(name, M, N, K, avg_us):
+            ach = 2.0 * M * N * K / (avg_us * 1e-6) / 1e12
+            return dict(kernel=name, bound='mfma', achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=None, avg_us=avg_us)
+
+        def roof_of(name):
+            k = ks[name]
+            if name == 'embed_fwd':
+                # algorithmic bytes per sample: ids + row read + row write (embedding gather forward)
+                return hbm_roof(name, 'embed_fwd_kernel (gather + FM first/second order + concat)',
+                                F * (4 + E * 4 + E * 4) * B, k['avg_us'], 'embed_fwd_kernel')
+            if name == 'emb_sparse_apply':
+                # per lookup: key + src + gradient row; per unique row: read+write of W, m, v
+                return hbm_roof(name, 'sparse_apply_kernel (+tail): segment-reduce + row-wise Adam',
+                                int(F * B * (8 + E * 4) + uniq * 6 * E * 4), k['avg_us'], 'sparse_apply_kernel')
+            if name.startswith('gemm_') or name.startswith('wgrad_'):
+                M, N, K = [int(v) for v in name.split('_')[1].split('x')]
+                return mfma_roof(name, M, N, K, k['avg_us'])
+            return dict(kernel=name, bound='hbm', achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None,
+                        traffic=None, avg_us=k['avg_us'])
+
         dom_name = max(ks, key=lambda n: ks[n]['total_ms'])
-        dom = ks[dom_name]
-        if dom_name.startswith('gemm_'):
-            M, N, K = [int(v) for v in dom_name.split('_')[1].split('x')]
-            ach = 2.0 * M * N * K / (dom['avg_us'] * 1e-6) / 1e12
-            roof = dict(kernel=dom_name, bound='mfma', achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
-                        frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=None, avg_us=dom['avg_us'])
-        elif dom_name == 'embed_fwd' and roof_emb:
-            roof = roof_emb
-        else:
-            roof = dict(kernel=dom_name, bound='hbm', achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None,
-                        traffic=None, avg_us=dom['avg_us'])
-        out['roofline'] = roof
-        out['roofline_emb'] = roof_emb
+        out['roofline'] = roof_of(dom_name)
+        out['roofline_emb'] = roof_of('embed_fwd') if 'embed_fwd' in ks else None
+        out['roofline_emb_bwd'] = roof_of('emb_sparse_apply') if 'emb_sparse_apply' in ks else None
+        out['unique_rows_per_step'] = uniq
         out['kernel_ms_per_step'] = {n: round(v['total_ms'] / args.steps, 4) for n, v in
                                      sorted(ks.items(), key=lambda kv: -kv[1]['total_ms'])}
     if not args.no_cpu_baseline and world == 1:
