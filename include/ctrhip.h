@@ -305,6 +305,23 @@ int ctr_afm_pair_bwd(const float* z, int64_t z_ld, const float* dx, int B, int N
                      const ctr_dropout_t* pair_drop, float* dz, int64_t dz_ld, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * AFM pair layer with the attention softmax taken ACROSS the P = N(N-1)/2 pairs (the network
+ * AFM/AFM.py:60-85 builds, with the softmax axis of AFM/AFM.py:79 moved from the size-1 axis to
+ * the pair axis):
+ *   p_k = Z_i * Z_j;  e_k = h . relu(p_k W + b);  a = softmax_k(e);  x = sum_k a_k m_k p_k
+ * W[E,A] row-major, b[A], h[A], A <= 32; m_k = dropout multiplier of element b*P + k.
+ * Backward writes dz and the three parameter gradients (overwritten, fixed summation order).
+ * ---------------------------------------------------------------------------------- */
+int ctr_afm_attn_fwd(const float* z, int64_t z_ld, int B, int N, int E, int A, const float* W,
+                     const float* b, const float* h, const ctr_dropout_t* pair_drop, float* x_out,
+                     void* stream);
+size_t ctr_afm_attn_bwd_workspace_bytes(int B, int E, int A);
+int ctr_afm_attn_bwd(const float* z, int64_t z_ld, const float* dx, int B, int N, int E, int A,
+                     const float* W, const float* b, const float* h, const ctr_dropout_t* pair_drop,
+                     float* dz, int64_t dz_ld, float* dW, float* db, float* dh, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * DIN pieces (DIN/DIN.py:17-71,149-196).  The dense layers of the attention MLP and of the
  * FCN are ctr_gemm_f32 calls over all B*T (resp. B) rows; these are the rest.
  *   ctr_din_build_idx   out[k] = (ids[k], cate_list[ids[k]]) as int32 pairs: with the item and

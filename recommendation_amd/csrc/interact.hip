@@ -98,6 +98,19 @@ __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__
   out[j] = a;
 }
 
+// like rows_sum_kernel, with the summed row split over three destinations [n0 | n1 | rest]
+__global__ __launch_bounds__(256) void rows_sum_strided_kernel(const float* __restrict__ part, int rows, int cols,
+                                                              float* __restrict__ o0, int n0, float* __restrict__ o1,
+                                                              int n1, float* __restrict__ o2) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= cols) return;
+  float a = 0.f;
+  for (int r = 0; r < rows; ++r) a += part[(int64_t)r * cols + j];
+  if (j < n0) o0[j] = a;
+  else if (j < n0 + n1) o1[j - n0] = a;
+  else o2[j - n0 - n1] = a;
+}
+
 // ss[b, e*E + f] = s[b,e] * s[b,f]                                   (PNN/PNN.py:83-84)
 __global__ __launch_bounds__(256) void outer_fwd_kernel(const float* __restrict__ s, int B, int E,
                                                        float* __restrict__ ss) {
@@ -201,6 +214,221 @@ __global__ __launch_bounds__(256) void afm_pair_kernel(const float* __restrict__
         x_out[b * E + e] = 0.5f * a;
       }
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// AFM with attention over the pairs (softmax across the N(N-1)/2 pair scores; the form the AFM
+// paper defines — the reference's softmax over a size-1 axis is ctr_afm_pair_* above).
+//   p_k = Z_i * Z_j;  t_k = relu(p_k W + b);  e_k = t_k . h;  a = softmax_k(e);  x = sum_k a_k m_k p_k
+// One wave per sample, lanes over pairs; Z, W, b, h in LDS; the pair tensor never leaves the chip.
+// Backward recomputes the scores and needs per pair only (de_k, c_k = a_k m_k, relu mask bits):
+//   dZ_i[e] = sum_{j != i} (c_k dx[e] + de_k G_k[e]) Z_j[e],  G_k[e] = sum_a mask_ka h_a W[e,a]
+//   dW[e,a] = h_a sum_k mask_ka de_k p_k[e];  db_a = h_a sum_k mask_ka de_k;  dh_a = sum_k de_k t_ka
+// Per-wave parameter partials are added in a fixed order afterwards: bitwise reproducible.
+// ---------------------------------------------------------------------------------------
+__device__ static inline int64_t pair_base(int i, int N) { return (int64_t)i * N - (int64_t)i * (i + 1) / 2; }
+
+template <int E, bool BWD>
+__global__ __launch_bounds__(256) void afm_attn_kernel(const float* __restrict__ z, int64_t z_ld, int B, int N, int A,
+                                                      const float* __restrict__ W, const float* __restrict__ bv,
+                                                      const float* __restrict__ hv, Drop drop,
+                                                      float* __restrict__ x_out, const float* __restrict__ dx,
+                                                      float* __restrict__ dz, int64_t dz_ld,
+                                                      float* __restrict__ part /*[waves][E*A + 2A]*/) {
+  extern __shared__ float lds[];
+  const int P = N * (N - 1) / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* Wl = lds;                 // [E*A]
+  float* hW = Wl + E * A;          // [E*A]  h_a * W[e,a]
+  float* bl = hW + E * A;          // [A]
+  float* hl = bl + A;              // [A]
+  const int per_wave = N * E + (BWD ? 4 * P : P);
+  float* Zs = hl + A + wave * per_wave;
+  float* sc = Zs + N * E;          // [P] scores, then attention weights
+  float* de = sc + P;              // [P]
+  float* ck = de + P;              // [P]
+  uint32_t* mk = reinterpret_cast<uint32_t*>(ck + P);  // [P] relu mask bits
+  for (int q = threadIdx.x; q < E * A; q += 256) {
+    Wl[q] = W[q];
+    hW[q] = W[q] * hv[q % A];
+  }
+  for (int q = threadIdx.x; q < A; q += 256) { bl[q] = bv[q]; hl[q] = hv[q]; }
+  constexpr int MAXW = (E * 32 + 63) / 64;  // dW elements per lane (A <= 32)
+  float dWacc[BWD ? MAXW : 1];
+  float dha[BWD ? 32 : 1], dba[BWD ? 32 : 1];  // this lane's share of dh_a and of sum_k mask_ka de_k
+  if (BWD) {
+#pragma unroll
+    for (int u = 0; u < MAXW; ++u) dWacc[u] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 32; ++a) dha[a] = dba[a] = 0.f;
+  }
+  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  const int64_t iters = (B + stride - 1) / stride;
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t b = it * stride + (int64_t)blockIdx.x * WAVES + wave;
+    const bool live = b < B;
+    __syncthreads();
+    if (live)
+      for (int q = lane; q < N * E; q += 64) Zs[q] = z[b * z_ld + q];
+    __syncthreads();
+    // pass 1: scores (and relu masks)
+    float mx = -INFINITY;
+    if (live) {
+      int i = 0;
+      for (int k = lane; k < P; k += 64) {
+        while (k >= pair_base(i + 1, N)) ++i;
+        const int j = i + 1 + (int)(k - pair_base(i, N));
+        float p[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) p[e] = Zs[i * E + e] * Zs[j * E + e];
+        float ek = 0.f;
+        uint32_t bits = 0;
+        for (int a = 0; a < A; ++a) {
+          float t = bl[a];
+#pragma unroll
+          for (int e = 0; e < E; ++e) t += p[e] * Wl[e * A + a];
+          if (t > 0.f) { ek += t * hl[a]; bits |= 1u << a; }
+        }
+        sc[k] = ek;
+        if (BWD) mk[k] = bits;
+        mx = fmaxf(mx, ek);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    if (live)
+      for (int k = lane; k < P; k += 64) sum += expf(sc[k] - mx);
+    sum = wave_sum(sum);
+    const float rs = 1.f / sum;
+    // pass 2: attention weights; forward pools, backward forms da_k and the softmax dot
+    float xacc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) xacc[e] = 0.f;
+    float sdot = 0.f;
+    if (live) {
+      int i = 0;
+      for (int k = lane; k < P; k += 64) {
+        while (k >= pair_base(i + 1, N)) ++i;
+        const int j = i + 1 + (int)(k - pair_base(i, N));
+        const float a = expf(sc[k] - mx) * rs;
+        const float m = drop_mul(drop, (uint64_t)(b * P + k));
+        if (!BWD) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) xacc[e] += a * m * Zs[i * E + e] * Zs[j * E + e];
+        } else {
+          float da = 0.f;
+#pragma unroll
+          for (int e = 0; e < E; ++e) da += dx[b * E + e] * Zs[i * E + e] * Zs[j * E + e];
+          da *= m;
+          sc[k] = a;
+          de[k] = da;      // staged: da_k
+          ck[k] = a * m;
+          sdot += a * da;
+        }
+      }
+    }
+    if (!BWD) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) xacc[e] = wave_sum(xacc[e]);
+      if (live && lane == 0) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) x_out[b * E + e] = xacc[e];
+      }
+      continue;
+    }
+    sdot = wave_sum(sdot);
+    // pass 3: de_k = a_k (da_k - sdot); db / dh partial sums stay in this lane's registers
+    if (live) {
+      int i = 0;
+      for (int k = lane; k < P; k += 64) {
+        while (k >= pair_base(i + 1, N)) ++i;
+        const int j = i + 1 + (int)(k - pair_base(i, N));
+        const float dek = sc[k] * (de[k] - sdot);
+        de[k] = dek;
+        float p[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) p[e] = Zs[i * E + e] * Zs[j * E + e];
+        const uint32_t bits = mk[k];
+#pragma unroll
+        for (int a = 0; a < 32; ++a) {
+          if (a < A && (bits >> a & 1u)) {
+            float t = bl[a];
+#pragma unroll
+            for (int e = 0; e < E; ++e) t += p[e] * Wl[e * A + a];
+            dha[a] += dek * t;
+            dba[a] += dek;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // dZ: lane (i, e) walks j != i
+    if (live) {
+      for (int q = lane; q < N * E; q += 64) {
+        const int i = q / E, e = q % E;
+        const float dxe = dx[b * E + e];
+        float acc = 0.f;
+        for (int j = 0; j < N; ++j) {
+          if (j == i) continue;
+          const int lo = i < j ? i : j, hi = i < j ? j : i;
+          const int k = (int)pair_base(lo, N) + (hi - lo - 1);
+          const uint32_t bits = mk[k];
+          float g = 0.f;
+          for (int a = 0; a < A; ++a)
+            if (bits >> a & 1u) g += hW[e * A + a];
+          acc += (ck[k] * dxe + de[k] * g) * Zs[j * E + e];
+        }
+        dz[b * dz_ld + q] = acc;
+      }
+      // dW: lane-owned (e, a) elements walk all pairs
+#pragma unroll
+      for (int u = 0; u < MAXW; ++u) {
+        const int q = lane + 64 * u;
+        if (q < E * A) {
+          const int e = q / A, a = q % A;
+          int i = 0, j = 1;
+          float acc = 0.f;
+          for (int k = 0; k < P; ++k) {
+            if (mk[k] >> a & 1u) acc += de[k] * Zs[i * E + e] * Zs[j * E + e];
+            if (++j == N) { ++i; j = i + 1; }
+          }
+          dWacc[u] += acc * hl[a];
+        }
+      }
+    }
+  }
+  if (BWD) {
+    const int64_t row = (int64_t)blockIdx.x * WAVES + wave;
+    float* out = part + row * (E * A + 2 * A);
+#pragma unroll
+    for (int u = 0; u < MAXW; ++u) {
+      const int q = lane + 64 * u;
+      if (q < E * A) out[q] = dWacc[u];
+    }
+#pragma unroll
+    for (int a = 0; a < 32; ++a) {
+      if (a < A) {
+        const float sb = wave_sum(dba[a]), sh = wave_sum(dha[a]);
+        if (lane == 0) {
+          out[E * A + a] = sb * hl[a];
+          out[E * A + A + a] = sh;
+        }
+      }
+    }
+  }
+}
+
+static int afm_blocks(int B) {
+  int64_t n = cdiv(B, WAVES);
+  if (n > 1024) n = 1024;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+static size_t afm_attn_lds(int N, int E, int A, bool bwd) {
+  const int P = N * (N - 1) / 2;
+  return ((size_t)2 * E * A + 2 * A + (size_t)WAVES * (N * E + (bwd ? 4 : 1) * P)) * sizeof(float);
 }
 
 static unsigned grid_for(int64_t total) {
@@ -326,6 +554,64 @@ extern "C" int ctr_afm_pair_bwd(const float* z, int64_t z_ld, const float* dx, i
   CTR_REQUIRE(z && dx && dz && z_ld >= (int64_t)N * E && dz_ld >= (int64_t)N * E, "ctr_afm_pair_bwd: null pointer / ld");
   hipLaunchKernelGGL(afm_pair_kernel<true>, dim3((unsigned)cdiv(B, WAVES)), dim3(256), (size_t)WAVES * 2 * N * E * 4,
                      (hipStream_t)stream, z, z_ld, B, N, E, make_drop(pair_drop), (float*)nullptr, dx, dz, dz_ld);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_afm_attn_fwd(const float* z, int64_t z_ld, int B, int N, int E, int A, const float* W,
+                                const float* b, const float* h, const ctr_dropout_t* pair_drop, float* x_out,
+                                void* stream) {
+  CTR_REQUIRE(B >= 0 && N >= 2 && A >= 1 && A <= 32, "ctr_afm_attn_fwd: need N >= 2 and 1 <= A <= 32");
+  CTR_REQUIRE(pow2_le64(E), "ctr_afm_attn_fwd: E=%d must be a power of two in [4,64]", E);
+  CTR_REQUIRE(afm_attn_lds(N, E, A, false) <= 64 * 1024, "ctr_afm_attn_fwd: N=%d, E=%d exceed the LDS budget", N, E);
+  if (B == 0) return CTR_OK;
+  CTR_REQUIRE(z && W && b && h && x_out && z_ld >= (int64_t)N * E, "ctr_afm_attn_fwd: null pointer / z_ld");
+  const dim3 grid(afm_blocks(B)), block(256);
+  const size_t lds = afm_attn_lds(N, E, A, false);
+  hipStream_t st = (hipStream_t)stream;
+  const Drop d = make_drop(pair_drop);
+#define AL(EE)                                                                                                  \
+  hipLaunchKernelGGL((afm_attn_kernel<EE, false>), grid, block, lds, st, z, z_ld, B, N, A, W, b, h, d, x_out,    \
+                     (const float*)nullptr, (float*)nullptr, (int64_t)0, (float*)nullptr)
+  switch (E) { case 4: AL(4); break; case 8: AL(8); break; case 16: AL(16); break; case 32: AL(32); break; default: AL(64); }
+#undef AL
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" size_t ctr_afm_attn_bwd_workspace_bytes(int B, int E, int A) {
+  return (size_t)afm_blocks(B) * WAVES * ((size_t)E * A + 2 * A) * sizeof(float);
+}
+
+extern "C" int ctr_afm_attn_bwd(const float* z, int64_t z_ld, const float* dx, int B, int N, int E, int A,
+                                const float* W, const float* b, const float* h, const ctr_dropout_t* pair_drop,
+                                float* dz, int64_t dz_ld, float* dW, float* db, float* dh, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  CTR_REQUIRE(B > 0 && N >= 2 && A >= 1 && A <= 32, "ctr_afm_attn_bwd: need B > 0, N >= 2 and 1 <= A <= 32");
+  CTR_REQUIRE(pow2_le64(E), "ctr_afm_attn_bwd: E=%d must be a power of two in [4,64]", E);
+  CTR_REQUIRE(afm_attn_lds(N, E, A, true) <= 64 * 1024, "ctr_afm_attn_bwd: N=%d, E=%d exceed the LDS budget", N, E);
+  CTR_REQUIRE(z && dx && W && b && h && dz && dW && db && dh && workspace, "ctr_afm_attn_bwd: null pointer");
+  CTR_REQUIRE(z_ld >= (int64_t)N * E && dz_ld >= (int64_t)N * E, "ctr_afm_attn_bwd: leading dimension");
+  if (workspace_bytes < ctr_afm_attn_bwd_workspace_bytes(B, E, A)) {
+    set_error("ctr_afm_attn_bwd: workspace %zu < %zu", workspace_bytes, ctr_afm_attn_bwd_workspace_bytes(B, E, A));
+    return CTR_EWORKSPACE;
+  }
+  const int nb = afm_blocks(B);
+  const dim3 grid(nb), block(256);
+  const size_t lds = afm_attn_lds(N, E, A, true);
+  hipStream_t st = (hipStream_t)stream;
+  const Drop d = make_drop(pair_drop);
+  float* part = (float*)workspace;
+#define AL(EE)                                                                                                  \
+  hipLaunchKernelGGL((afm_attn_kernel<EE, true>), grid, block, lds, st, z, z_ld, B, N, A, W, b, h, d,            \
+                     (float*)nullptr, dx, dz, dz_ld, part)
+  switch (E) { case 4: AL(4); break; case 8: AL(8); break; case 16: AL(16); break; case 32: AL(32); break; default: AL(64); }
+#undef AL
+  // fixed-order sums of the per-wave partial rows: [dW (E*A) | db (A) | dh (A)]
+  const int cols = E * A + 2 * A;
+  float* tmp = part;  // rows_sum writes to the destinations directly
+  hipLaunchKernelGGL(rows_sum_strided_kernel, dim3((unsigned)cdiv(cols, 256)), dim3(256), 0, st, tmp, nb * WAVES, cols,
+                     dW, E * A, db, A, dh);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }

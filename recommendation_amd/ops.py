@@ -514,6 +514,9 @@ def vec_op(kind, a, b, out):
                            _stream()), 'ctr_vec_op')
 
 
+f32 = torch.float32
+
+
 @_timed
 def afm_pair_fwd(z, x_out, *, N, E, pair_drop=None):
     B = z.shape[0]
@@ -535,10 +538,47 @@ def afm_pair_bwd(z, dx, dz, *, N, E, pair_drop=None):
           'ctr_afm_pair_bwd')
 
 
+def _afm_attn_check(z, W, b, h, N, E):
+    A = W.shape[1]
+    if tuple(W.shape) != (E, A) or b.numel() != A or h.numel() != A or z.shape[1] < N * E:
+        raise ValueError('afm_attn: W must be [E,A], b and h [A], z at least N*E wide')
+    for t in (W, b, h):
+        if not t.is_contiguous():
+            raise ValueError('afm_attn: parameters must be contiguous')
+    return A
+
+
+@_timed
+def afm_attn_fwd(z, W, b, h, x_out, *, N, E, pair_drop=None):
+    B = z.shape[0]
+    A = _afm_attn_check(z, W, b, h, N, E)
+    zp, zld = _rows(z, 'z')
+    if tuple(x_out.shape) != (B, E) or not x_out.is_contiguous():
+        raise ValueError('afm_attn_fwd: x_out must be contiguous [B,E]')
+    check(lib().ctr_afm_attn_fwd(zp, zld, B, N, E, A, _ptr(W, f32), _ptr(b, f32), _ptr(h, f32), _dp(pair_drop),
+                                 _ptr(x_out, f32), _stream()), 'ctr_afm_attn_fwd')
+
+
+@_timed
+def afm_attn_bwd(z, dx, W, b, h, dz, dW, db, dh, *, N, E, ws, pair_drop=None):
+    B = z.shape[0]
+    A = _afm_attn_check(z, W, b, h, N, E)
+    zp, zld = _rows(z, 'z')
+    dp, dld = _rows(dz, 'dz')
+    if tuple(dx.shape) != (B, E) or not dx.is_contiguous() or dz.shape[1] < N * E:
+        raise ValueError('afm_attn_bwd shape mismatch')
+    if dW.numel() != E * A or db.numel() != A or dh.numel() != A:
+        raise ValueError('afm_attn_bwd: gradient buffers must match W, b, h')
+    for t in (dW, db, dh):
+        if not t.is_contiguous():
+            raise ValueError('afm_attn_bwd: gradient buffers must be contiguous')
+    wp, wn = ws.get(lib().ctr_afm_attn_bwd_workspace_bytes(B, E, A))
+    check(lib().ctr_afm_attn_bwd(zp, zld, _ptr(dx, f32), B, N, E, A, _ptr(W, f32), _ptr(b, f32), _ptr(h, f32),
+                                 _dp(pair_drop), dp, dld, _ptr(dW, f32), _ptr(db, f32), _ptr(dh, f32), wp, wn,
+                                 _stream()), 'ctr_afm_attn_bwd')
+
+
 # ------------------------------------------------------------------ DIN pieces
-f32 = torch.float32
-
-
 @_timed
 def din_build_idx(ids, cate_list, item_count, out):
     n = ids.numel()

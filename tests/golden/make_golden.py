@@ -18,7 +18,7 @@ from oracle import ctr_oracle as O  # noqa: E402
 from tests.helpers import no_dropout, tiny_batch, tiny_cfg  # noqa: E402
 
 CASES = [('DeepFM', {}), ('DCN', {}), ('NFM', {}), ('ESMM', {}), ('PNN', {}), ('PNN', {'inner_product': False}),
-         ('AFM', {})]
+         ('AFM', {}), ('AFM', {'attention': 'pairs', 'canonical_softmax': True})]
 
 
 def make(model, mode, extra):
@@ -27,7 +27,7 @@ def make(model, mode, extra):
     Xc, Xf, y = tiny_batch(cfg, B=8, seed=1)
     if model == 'AFM':                      # keep 0 < y_out < 1 (AFM feeds log_loss an unbounded value)
         Xf = np.abs(Xf) * 0.3
-        P = {k: np.abs(v) for k, v in P.items()}
+        P = {k: (v if extra and 'attention' in k else np.abs(v)) for k, v in P.items()}
     m = O.OracleModel(model, cfg, P, dtype=torch.float64)
     out = dict(X_cate=Xc, X_cont=Xf, y=y)
     for k, v in P.items():
@@ -49,12 +49,15 @@ def make(model, mode, extra):
 
 
 def name(model, mode, extra):
-    tag = '_outer' if extra.get('inner_product') is False else ''
+    tag = '_outer' if extra.get('inner_product') is False else '_pairs' if extra.get('attention') else ''
     return '%s%s_%s.npz' % (model, tag, mode)
 
 
 if __name__ == '__main__':
+    only = sys.argv[1:]                     # optional file-name filter: rewrite just those fixtures
     for model, extra in CASES:
         for mode in ('R', 'S'):
+            if only and name(model, mode, extra) not in only:
+                continue
             np.savez_compressed(os.path.join(HERE, name(model, mode, extra)), **make(model, mode, extra))
             print('wrote', name(model, mode, extra))

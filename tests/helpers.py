@@ -39,7 +39,9 @@ def no_dropout(cfg):
     return cfg
 
 
-def rel_err(a, b):
+def rel_err(a, b, floor=1e-30):
+    """max-norm relative error; `floor` bounds the denominator from below for quantities that are
+    analytically zero (a sum of cancelling fp32 terms is then compared on an absolute scale)."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
-    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + floor))

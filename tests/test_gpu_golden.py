@@ -24,6 +24,8 @@ def test_hip_path_reproduces_golden(sess, path):
     cfg = no_dropout(tiny_cfg(name, mode))
     if 'outer' in parts:
         cfg.inner_product = False
+    if 'pairs' in parts:
+        cfg.attention = 'pairs'
     cfg.adam_mode = 'tf1'
     P = {k[6:]: g[k] for k in g.files if k.startswith('param/')}
     m = getattr(importlib.import_module('%s.%s' % (name, name)), name)(cfg, cfg.cate_num, cfg.cont_num, cfg.cate_list)
@@ -34,7 +36,8 @@ def test_hip_path_reproduces_golden(sess, path):
     loss = m.run(sess, Xc, Xf, y, True)
     assert abs(float(loss) - float(g['loss'])) < 1e-5 * max(1.0, abs(float(g['loss'])))
     for k, v in m.get_grads().items():
-        assert rel_err(v, g['grad/' + k]) < 5e-5, k
+        # softmax gradients sum to zero: attention_b's gradient cancels exactly in R-mode's repeated rows
+        assert rel_err(v, g['grad/' + k], floor=1e-4 if 'pairs' in parts else 1e-30) < 5e-5, k
     for k, v in m.get_params().items():
         assert rel_err(v, g['after1/' + k]) < 5e-5, k
     m.run(sess, Xc, Xf, y, True)

@@ -130,3 +130,42 @@ def test_afm_pair_and_output_dropout_match_hash(sess):
     assert abs(float(loss_gpu) - float(loss_ref)) < 1e-5 * max(1.0, abs(float(loss_ref)))
     for k, v in m.get_grads().items():
         assert rel_err(v, g_ref[k].numpy()) < 5e-5, k
+
+
+@pytest.mark.parametrize('dropout', [0.0, 0.4])
+def test_afm_attention_over_pairs_trains_the_attention_variables(sess, dropout):
+    """attention='pairs' (softmax over the pair axis, not a reference flag): forward, gradients of
+    every variable including attention_w/b/h, and Adagrad steps against the oracle's
+    canonical_softmax form."""
+    cfg = tiny_cfg('AFM', 'S')
+    cfg.dropout = dropout
+    cfg.attention = 'pairs'
+    cfg.canonical_softmax = True
+    P = {k: (v if 'attention' in k else np.abs(v)) for k, v in O.init_params('AFM', cfg, seed=8, std=0.3).items()}
+    Xc, Xf, y = tiny_batch(cfg, B=16, seed=4, oor=False)
+    Xf = np.abs(Xf) * 0.5
+    m = _build(sess, 'AFM', cfg, P)
+    B, N, E = 16, cfg.cate_num + cfg.cont_num, cfg.embed_size
+    npairs = N * (N - 1) // 2
+    masks = None
+    if dropout:
+        seed = sess.seed * 1000003 + 0
+        masks = {'att': torch.as_tensor(O.keep_mask(seed, 4, B * npairs, 1 - dropout).reshape(B, npairs, 1)),
+                 'out': torch.as_tensor(O.keep_mask(seed, 5, B * E, 1 - dropout).reshape(B, E))}
+    orc = O.OracleModel('AFM', cfg, P, dtype=torch.float64)
+    loss_ref, g_ref, _ = orc.loss_and_grads(Xc, Xf, y, masks)
+    assert torch.isfinite(loss_ref)
+    p_gpu = m.predict_proba(sess, Xc, Xf)
+    assert rel_err(p_gpu, orc.forward(Xc, Xf).y_out.numpy()) < TOL
+    loss_gpu = m.run(sess, Xc, Xf, y, True)
+    assert abs(float(loss_gpu) - float(loss_ref)) < 1e-5 * max(1.0, abs(float(loss_ref)))
+    g = m.get_grads()
+    for k, v in g.items():
+        assert rel_err(v, g_ref[k].numpy()) < 5e-5, k
+    assert np.abs(g['attention_based_pooling/attention_w']).max() > 0
+    if not dropout:
+        orc.run(Xc, Xf, y, True)
+        for _ in range(2):
+            assert abs(float(orc.run(Xc, Xf, y, True)) - float(m.run(sess, Xc, Xf, y, True))) < 1e-5
+        for k, v in m.get_params().items():
+            assert rel_err(v, orc.P[k].numpy()) < 1e-4, k

@@ -172,6 +172,8 @@ def test_oracle_reproduces_golden(path):
     parts = base.split('_')
     model, mode = parts[0], parts[-1]
     extra = {'inner_product': False} if 'outer' in parts else {}
+    if 'pairs' in parts:
+        extra = {'attention': 'pairs', 'canonical_softmax': True}
     new = make(model, mode, extra)
     old = np.load(path)
     assert set(old.files) == set(new)
