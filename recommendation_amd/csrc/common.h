@@ -18,6 +18,15 @@ void set_error(const char* fmt, ...);
     }                                     \
   } while (0)
 
+#define CTR_HIP(call)                                                \
+  do {                                                               \
+    hipError_t e__ = (call);                                         \
+    if (e__ != hipSuccess) {                                         \
+      ctr::set_error("%s: %s", __func__, hipGetErrorString(e__));    \
+      return (int)e__;                                               \
+    }                                                                \
+  } while (0)
+
 #define CTR_LAUNCH_CHECK()                                           \
   do {                                                               \
     hipError_t e__ = hipGetLastError();                              \

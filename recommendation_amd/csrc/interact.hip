@@ -15,6 +15,9 @@ constexpr int WAVES = 4;
 //                                                  dw[p,n]  += sum_{b,e} du * Z[b,n,e]
 // LDS: w [P*N] shared by the block, then per wave Z [N*E] and u [P*E].
 // ---------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int PMT = 2, PNT = 8;  // backward handles product_size <= 32 and N <= 128 (16 x 16 dw tiles)
+
 template <bool BWD>
 __global__ __launch_bounds__(256) void pnn_inner_kernel(const float* __restrict__ z, int64_t z_ld,
                                                        const float* __restrict__ w, int B, int N, int E, int P,
@@ -24,14 +27,17 @@ __global__ __launch_bounds__(256) void pnn_inner_kernel(const float* __restrict_
   extern __shared__ float lds[];
   float* ws = lds;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* Zs = ws + P * N + wave * (N * E + P * E);
-  float* us = Zs + N * E;
+  const int ES = E + 1;  // padded row: lanes that differ in n (or p) at a fixed e land in different banks
+  float* Zs = ws + P * N + wave * (N * ES + P * ES);
+  float* us = Zs + N * ES;
   for (int i = threadIdx.x; i < P * N; i += 256) ws[i] = w[i];
-  constexpr int MAXACC = 64;  // dw accumulators per lane (P*N <= 4096)
-  float acc[BWD ? MAXACC : 1];
+  const int l16 = lane & 15, g4 = lane >> 4;
+  f32x4 acc[BWD ? PMT : 1][BWD ? PNT : 1];  // dw tiles: rows p (16 per tile), columns n
   if (BWD) {
 #pragma unroll
-    for (int i = 0; i < MAXACC; ++i) acc[i] = 0.f;
+    for (int m = 0; m < PMT; ++m)
+#pragma unroll
+      for (int t = 0; t < PNT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int64_t stride = (int64_t)gridDim.x * WAVES;
   const int64_t iters = (B + stride - 1) / stride;
@@ -40,19 +46,25 @@ __global__ __launch_bounds__(256) void pnn_inner_kernel(const float* __restrict_
     const bool live = b < B;
     __syncthreads();  // previous sample's tiles fully consumed (and w staged, first time)
     if (live)
-      for (int i = lane; i < N * E; i += 64) Zs[i] = z[b * z_ld + i];
+      for (int i = lane; i < N * E; i += 64) Zs[(i / E) * ES + i % E] = z[b * z_ld + i];
     __syncthreads();
     if (live) {
       for (int q = lane; q < P * E; q += 64) {
         const int p = q / E, e = q % E;
-        float u = 0.f;
-        for (int n = 0; n < N; ++n) u += Zs[n * E + e] * ws[p * N + n];
+        float u0 = 0.f, u1 = 0.f;
+        int n = 0;
+        for (; n + 1 < N; n += 2) {
+          u0 += Zs[n * ES + e] * ws[p * N + n];
+          u1 += Zs[(n + 1) * ES + e] * ws[p * N + n + 1];
+        }
+        if (n < N) u0 += Zs[n * ES + e] * ws[p * N + n];
+        const float u = u0 + u1;
         if (!BWD) {
           float sq = u * u;
           for (int o = E / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
           if (e == 0) usq[b * P + p] = sq;
         } else {
-          us[q] = u * (coef_ld ? coef[b * coef_ld + p] : coef[p]);
+          us[p * ES + e] = u * (coef_ld ? coef[b * coef_ld + p] : coef[p]);
         }
       }
     }
@@ -62,53 +74,73 @@ __global__ __launch_bounds__(256) void pnn_inner_kernel(const float* __restrict_
         for (int q = lane; q < N * E; q += 64) {
           const int n = q / E, e = q % E;
           float d = 0.f;
-          for (int p = 0; p < P; ++p) d += us[p * E + e] * ws[p * N + n];
+          for (int p = 0; p < P; ++p) d += us[p * ES + e] * ws[p * N + n];
           dz[b * dz_ld + q] += d;
         }
+        // dw[p,n] += sum_e du[p,e] Z[n,e] on the matrix cores: rows p, columns n, 4 values of e per step
+        for (int e0 = 0; e0 < E; e0 += 4) {
+          float av[PMT], bvv[PNT];
 #pragma unroll
-        for (int i = 0; i < MAXACC; ++i) {
-          const int q = lane + 64 * i;
-          if (q < P * N) {
-            const int p = q / N, n = q % N;
-            float d = 0.f;
-            for (int e = 0; e < E; ++e) d += us[p * E + e] * Zs[n * E + e];
-            acc[i] += d;
-          }
+          for (int m = 0; m < PMT; ++m) av[m] = 16 * m + l16 < P ? us[(16 * m + l16) * ES + e0 + g4] : 0.f;
+#pragma unroll
+          for (int t = 0; t < PNT; ++t) bvv[t] = 16 * t + l16 < N ? Zs[(16 * t + l16) * ES + e0 + g4] : 0.f;
+#pragma unroll
+          for (int m = 0; m < PMT; ++m)
+            if (16 * m < P) {
+#pragma unroll
+              for (int t = 0; t < PNT; ++t)
+                if (16 * t < N) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bvv[t], acc[m][t], 0, 0, 0);
+            }
         }
       }
     }
   }
   if (BWD) {
     const int64_t row = (int64_t)blockIdx.x * WAVES + wave;
+    // element r of lane (g4, l16) of tile (m, t): p = 16 m + 4 g4 + r, n = 16 t + l16
 #pragma unroll
-    for (int i = 0; i < MAXACC; ++i) {
-      const int q = lane + 64 * i;
-      if (q < P * N) dw_part[row * (P * N) + q] = acc[i];
-    }
+    for (int m = 0; m < PMT; ++m)
+#pragma unroll
+      for (int t = 0; t < PNT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pp = 16 * m + 4 * g4 + r, n = 16 * t + l16;
+          if (pp < P && n < N) dw_part[row * (P * N) + pp * N + n] = acc[m][t][r];
+        }
   }
 }
 
-// fixed-order sum of the per-wave dw partial rows
+// Fixed-order sum of the per-wave partial rows; the summed row is split over up to three
+// destinations [n0 | n1 | rest].  A block owns 16 columns; its 16 row groups each add every 16th
+// row with 8 loads in flight, then the groups are added in order.
 __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ part, int rows, int cols,
-                                                      float* __restrict__ out) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= cols) return;
+                                                      float* __restrict__ o0, int n0, float* __restrict__ o1,
+                                                      int n1, float* __restrict__ o2) {
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + c;
   float a = 0.f;
-  for (int r = 0; r < rows; ++r) a += part[(int64_t)r * cols + j];
-  out[j] = a;
-}
-
-// like rows_sum_kernel, with the summed row split over three destinations [n0 | n1 | rest]
-__global__ __launch_bounds__(256) void rows_sum_strided_kernel(const float* __restrict__ part, int rows, int cols,
-                                                              float* __restrict__ o0, int n0, float* __restrict__ o1,
-                                                              int n1, float* __restrict__ o2) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= cols) return;
-  float a = 0.f;
-  for (int r = 0; r < rows; ++r) a += part[(int64_t)r * cols + j];
-  if (j < n0) o0[j] = a;
-  else if (j < n0 + n1) o1[j - n0] = a;
-  else o2[j - n0 - n1] = a;
+  if (j < cols) {
+    int r = rg;
+    for (; r + 7 * 16 < rows; r += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(r + 16 * u) * cols + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; r < rows; r += 16) a += part[(int64_t)r * cols + j];
+  }
+  red[rg][c] = a;
+  __syncthreads();
+  if (rg == 0 && j < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][c];
+    if (j < n0) o0[j] = t;
+    else if (j < n0 + n1) o1[j - n0] = t;
+    else o2[j - n0 - n1] = t;
+  }
 }
 
 // ss[b, e*E + f] = s[b,e] * s[b,f]                                   (PNN/PNN.py:83-84)
@@ -184,25 +216,33 @@ __global__ __launch_bounds__(256) void afm_pair_kernel(const float* __restrict__
                                                       int64_t dz_ld) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* Zs = lds + wave * (2 * N * E);
-  float* Rs = Zs + N * E;
+  const int ES = E + 1;
+  const int P = N * (N - 1) / 2;
+  float* Zs = lds + wave * (2 * N * ES + P);
+  float* Rs = Zs + N * ES;
+  float* ms = Rs + N * ES;  // [P] dropout multiplier of each pair: hashed once, not once per (i, e)
   const int64_t b = (int64_t)blockIdx.x * WAVES + wave;
   const bool live = b < B;
-  const int64_t P = (int64_t)N * (N - 1) / 2;
-  if (live)
-    for (int i = lane; i < N * E; i += 64) Zs[i] = z[b * z_ld + i];
+  if (live) {
+    for (int i = lane; i < N * E; i += 64) Zs[(i / E) * ES + i % E] = z[b * z_ld + i];
+    for (int k = lane; k < P; k += 64) ms[k] = drop_mul(d, (uint64_t)(b * P + k));
+  }
   __syncthreads();
   if (live) {
     for (int q = lane; q < N * E; q += 64) {
       const int i = q / E, e = q % E;
-      float r = 0.f;
-      for (int j = 0; j < N; ++j) {
-        if (j == i) continue;
-        const int64_t k = i < j ? pair_index(i, j, N) : pair_index(j, i, N);
-        r += drop_mul(d, (uint64_t)(b * P + k)) * Zs[j * E + e];
+      float r0 = 0.f, r1 = 0.f;
+      // pairs (j, i), j < i: index base(j) + i - j - 1;  pairs (i, j), j > i: contiguous from base(i)
+      int k = i - 1;
+      for (int j = 0; j < i; ++j) {
+        r0 += ms[k] * Zs[j * ES + e];
+        k += N - j - 2;
       }
+      const int base = (int)pair_index(i, i + 1, N);
+      for (int j = i + 1; j < N; ++j) r1 += ms[base + j - i - 1] * Zs[j * ES + e];
+      const float r = r0 + r1;
       if (BWD) dz[b * dz_ld + q] = dx[b * E + e] * r;
-      else Rs[q] = Zs[q] * r;
+      else Rs[i * ES + e] = Zs[i * ES + e] * r;
     }
   }
   if (!BWD) {
@@ -210,7 +250,7 @@ __global__ __launch_bounds__(256) void afm_pair_kernel(const float* __restrict__
     if (live)
       for (int e = lane; e < E; e += 64) {
         float a = 0.f;
-        for (int i = 0; i < N; ++i) a += Rs[i * E + e];
+        for (int i = 0; i < N; ++i) a += Rs[i * ES + e];
         x_out[b * E + e] = 0.5f * a;
       }
   }
@@ -226,41 +266,60 @@ __global__ __launch_bounds__(256) void afm_pair_kernel(const float* __restrict__
 //   dW[e,a] = h_a sum_k mask_ka de_k p_k[e];  db_a = h_a sum_k mask_ka de_k;  dh_a = sum_k de_k t_ka
 // Per-wave parameter partials are added in a fixed order afterwards: bitwise reproducible.
 // ---------------------------------------------------------------------------------------
-__device__ static inline int64_t pair_base(int i, int N) { return (int64_t)i * N - (int64_t)i * (i + 1) / 2; }
+__device__ static inline int pair_base(int i, int N) { return i * N - i * (i + 1) / 2; }
 
+// LDS rows of Z are padded to E + 1 floats: lanes that walk pairs read rows j, j+1, ... at a fixed e,
+// and a stride of E floats would put all of them in E/64-th of the banks.
 template <int E, bool BWD>
-__global__ __launch_bounds__(256) void afm_attn_kernel(const float* __restrict__ z, int64_t z_ld, int B, int N, int A,
+__global__ __launch_bounds__(256, 2) void afm_attn_kernel(const float* __restrict__ z, int64_t z_ld, int B, int N, int A,
                                                       const float* __restrict__ W, const float* __restrict__ bv,
                                                       const float* __restrict__ hv, Drop drop,
                                                       float* __restrict__ x_out, const float* __restrict__ dx,
                                                       float* __restrict__ dz, int64_t dz_ld,
                                                       float* __restrict__ part /*[waves][E*A + 2A]*/) {
   extern __shared__ float lds[];
+  constexpr int ES = E + 1;
+  constexpr int MT = (E + 15) / 16;  // 16-row tiles of dW over e
   const int P = N * (N - 1) / 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* Wl = lds;                 // [E*A]
-  float* hW = Wl + E * A;          // [E*A]  h_a * W[e,a]
-  float* bl = hW + E * A;          // [A]
+  const int l16 = lane & 15, g4 = lane >> 4;
+  float* Wt = lds;                 // [A*E]  W transposed: Wt[a*E + e]
+  float* bl = Wt + E * A;          // [A]
   float* hl = bl + A;              // [A]
-  const int per_wave = N * E + (BWD ? 4 * P : P);
-  float* Zs = hl + A + wave * per_wave;
-  float* sc = Zs + N * E;          // [P] scores, then attention weights
+  uint32_t* ij = reinterpret_cast<uint32_t*>(hl + A);  // [P]  i | j << 16, lexicographic pair order
+  const int per_wave = N * ES + E + (BWD ? 4 * P : P);
+  float* Zs = reinterpret_cast<float*>(ij + P) + wave * per_wave;
+  float* dxs = Zs + N * ES;        // [E]
+  float* sc = dxs + E;             // [P] scores, then attention weights
   float* de = sc + P;              // [P]
   float* ck = de + P;              // [P]
   uint32_t* mk = reinterpret_cast<uint32_t*>(ck + P);  // [P] relu mask bits
-  for (int q = threadIdx.x; q < E * A; q += 256) {
-    Wl[q] = W[q];
-    hW[q] = W[q] * hv[q % A];
-  }
+  for (int q = threadIdx.x; q < E * A; q += 256) Wt[(q % A) * E + q / A] = W[q];
   for (int q = threadIdx.x; q < A; q += 256) { bl[q] = bv[q]; hl[q] = hv[q]; }
-  constexpr int MAXW = (E * 32 + 63) / 64;  // dW elements per lane (A <= 32)
-  float dWacc[BWD ? MAXW : 1];
-  float dha[BWD ? 32 : 1], dba[BWD ? 32 : 1];  // this lane's share of dh_a and of sum_k mask_ka de_k
+  for (int i = threadIdx.x; i < N - 1; i += 256) {
+    const int base = pair_base(i, N);
+    for (int j = i + 1; j < N; ++j) ij[base + j - i - 1] = (uint32_t)i | (uint32_t)j << 16;
+  }
+  // pass-1 operands held for the whole kernel: W^T (A operand: row a = 16 nt + l16, k = e = 4 s + g4)
+  // and b, h at this lane's accumulator rows a = 16 nt + 4 g4 + r; zero beyond A
+  float wreg[E / 4][2], breg[2][4], hreg[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+    for (int s4 = 0; s4 < E / 4; ++s4) wreg[s4][nt] = 16 * nt + l16 < A ? W[(4 * s4 + g4) * A + 16 * nt + l16] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int a = 16 * nt + 4 * g4 + r;
+      breg[nt][r] = a < A ? bv[a] : 0.f;
+      hreg[nt][r] = a < A ? hv[a] : 0.f;
+    }
+  }
+  // backward state that lives across the samples of this wave
+  f32x4 qacc[BWD ? MT : 1][2];   // Q[e,a] = sum_k mask_ka de_k p_k[e]  (MFMA 16x16 tiles over e x a)
+  float racc[2] = {0.f, 0.f};    // lane's share of R_a = sum_k mask_ka de_k, a = 16 nt + l16
   if (BWD) {
 #pragma unroll
-    for (int u = 0; u < MAXW; ++u) dWacc[u] = 0.f;
-#pragma unroll
-    for (int a = 0; a < 32; ++a) dha[a] = dba[a] = 0.f;
+    for (int m = 0; m < MT; ++m) qacc[m][0] = qacc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int64_t stride = (int64_t)gridDim.x * WAVES;
   const int64_t iters = (B + stride - 1) / stride;
@@ -268,32 +327,53 @@ __global__ __launch_bounds__(256) void afm_attn_kernel(const float* __restrict__
     const int64_t b = it * stride + (int64_t)blockIdx.x * WAVES + wave;
     const bool live = b < B;
     __syncthreads();
-    if (live)
-      for (int q = lane; q < N * E; q += 64) Zs[q] = z[b * z_ld + q];
+    if (live) {
+      for (int q = lane; q < N * E; q += 64) Zs[(q / E) * ES + q % E] = z[b * z_ld + q];
+      if (BWD && lane < E) dxs[lane] = dx[b * E + lane];
+    }
     __syncthreads();
-    // pass 1: scores (and relu masks)
+    // pass 1: scores and relu masks, 16 pairs per step on the matrix cores: T^T = W^T P^T with rows a,
+    // columns pair, contraction over e; element r of lane (g4, l16) is t[a = 4 g4 + r][pair l16]
     float mx = -INFINITY;
     if (live) {
-      int i = 0;
-      for (int k = lane; k < P; k += 64) {
-        while (k >= pair_base(i + 1, N)) ++i;
-        const int j = i + 1 + (int)(k - pair_base(i, N));
-        float p[E];
+      for (int k0 = 0; k0 < P; k0 += 16) {
+        const int k = k0 + l16;
+        const bool ok = k < P;
+        const uint32_t pr = ok ? ij[k] : 0u;
+        const float* zi = Zs + (pr & 0xffffu) * ES;
+        const float* zj = Zs + (pr >> 16) * ES;
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+        float pv[E / 4];
 #pragma unroll
-        for (int e = 0; e < E; ++e) p[e] = Zs[i * E + e] * Zs[j * E + e];
+        for (int s4 = 0; s4 < E / 4; ++s4) pv[s4] = zi[4 * s4 + g4] * zj[4 * s4 + g4];
+#pragma unroll
+        for (int s4 = 0; s4 < E / 4; ++s4) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s4][0], pv[s4], c0, 0, 0, 0);
+        if (A > 16) {
+#pragma unroll
+          for (int s4 = 0; s4 < E / 4; ++s4)
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s4][1], pv[s4], c1, 0, 0, 0);
+        }
         float ek = 0.f;
         uint32_t bits = 0;
-        for (int a = 0; a < A; ++a) {
-          float t = bl[a];
 #pragma unroll
-          for (int e = 0; e < E; ++e) t += p[e] * Wl[e * A + a];
-          if (t > 0.f) { ek += t * hl[a]; bits |= 1u << a; }
+        for (int r = 0; r < 4; ++r) {
+          const float t0 = c0[r] + breg[0][r];
+          if (t0 > 0.f) { ek += t0 * hreg[0][r]; bits |= 1u << (4 * g4 + r); }
+          const float t1 = c1[r] + breg[1][r];
+          if (t1 > 0.f) { ek += t1 * hreg[1][r]; bits |= 1u << (16 + 4 * g4 + r); }
         }
-        sc[k] = ek;
-        if (BWD) mk[k] = bits;
-        mx = fmaxf(mx, ek);
+        ek += __shfl_xor(ek, 16);
+        ek += __shfl_xor(ek, 32);
+        bits |= __shfl_xor(bits, 16);
+        bits |= __shfl_xor(bits, 32);
+        if (ok && g4 == 0) {
+          sc[k] = ek;
+          if (BWD) mk[k] = bits;
+        }
+        if (ok) mx = fmaxf(mx, ek);
       }
     }
+    __syncthreads();
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     float sum = 0.f;
@@ -302,24 +382,27 @@ __global__ __launch_bounds__(256) void afm_attn_kernel(const float* __restrict__
     sum = wave_sum(sum);
     const float rs = 1.f / sum;
     // pass 2: attention weights; forward pools, backward forms da_k and the softmax dot
-    float xacc[E];
+    float xacc[BWD ? 1 : E];
+    if (!BWD) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) xacc[e] = 0.f;
+      for (int e = 0; e < E; ++e) xacc[e] = 0.f;
+    }
     float sdot = 0.f;
     if (live) {
-      int i = 0;
       for (int k = lane; k < P; k += 64) {
-        while (k >= pair_base(i + 1, N)) ++i;
-        const int j = i + 1 + (int)(k - pair_base(i, N));
+        const uint32_t pr = ij[k];
+        const float* zi = Zs + (pr & 0xffffu) * ES;
+        const float* zj = Zs + (pr >> 16) * ES;
         const float a = expf(sc[k] - mx) * rs;
         const float m = drop_mul(drop, (uint64_t)(b * P + k));
         if (!BWD) {
+          const float am = a * m;
 #pragma unroll
-          for (int e = 0; e < E; ++e) xacc[e] += a * m * Zs[i * E + e] * Zs[j * E + e];
+          for (int e = 0; e < E; ++e) xacc[e] += am * zi[e] * zj[e];
         } else {
           float da = 0.f;
 #pragma unroll
-          for (int e = 0; e < E; ++e) da += dx[b * E + e] * Zs[i * E + e] * Zs[j * E + e];
+          for (int e = 0; e < E; ++e) da += dxs[e] * zi[e] * zj[e];
           da *= m;
           sc[k] = a;
           de[k] = da;      // staged: da_k
@@ -338,85 +421,143 @@ __global__ __launch_bounds__(256) void afm_attn_kernel(const float* __restrict__
       continue;
     }
     sdot = wave_sum(sdot);
-    // pass 3: de_k = a_k (da_k - sdot); db / dh partial sums stay in this lane's registers
-    if (live) {
-      int i = 0;
-      for (int k = lane; k < P; k += 64) {
-        while (k >= pair_base(i + 1, N)) ++i;
-        const int j = i + 1 + (int)(k - pair_base(i, N));
-        const float dek = sc[k] * (de[k] - sdot);
-        de[k] = dek;
-        float p[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) p[e] = Zs[i * E + e] * Zs[j * E + e];
-        const uint32_t bits = mk[k];
-#pragma unroll
-        for (int a = 0; a < 32; ++a) {
-          if (a < A && (bits >> a & 1u)) {
-            float t = bl[a];
-#pragma unroll
-            for (int e = 0; e < E; ++e) t += p[e] * Wl[e * A + a];
-            dha[a] += dek * t;
-            dba[a] += dek;
-          }
-        }
-      }
-    }
+    if (live)
+      for (int k = lane; k < P; k += 64) de[k] = sc[k] * (de[k] - sdot);  // de_k = a_k (da_k - sum a da)
     __syncthreads();
-    // dZ: lane (i, e) walks j != i
     if (live) {
-      for (int q = lane; q < N * E; q += 64) {
-        const int i = q / E, e = q % E;
-        const float dxe = dx[b * E + e];
-        float acc = 0.f;
-        for (int j = 0; j < N; ++j) {
-          if (j == i) continue;
-          const int lo = i < j ? i : j, hi = i < j ? j : i;
-          const int k = (int)pair_base(lo, N) + (hi - lo - 1);
-          const uint32_t bits = mk[k];
-          float g = 0.f;
-          for (int a = 0; a < A; ++a)
-            if (bits >> a & 1u) g += hW[e * A + a];
-          acc += (ck[k] * dxe + de[k] * g) * Zs[j * E + e];
-        }
-        dz[b * dz_ld + q] = acc;
-      }
-      // dW: lane-owned (e, a) elements walk all pairs
+      // dZ_i[e] = dx[e] (C Z)[i,e] + sum_a h_a W[e,a] (V_a Z)[i,e] with the symmetric N x N matrices
+      // C[i,j] = c_k and V_a[i,j] = mask_ka de_k (k = pair of i and j, zero diagonal): products on the
+      // matrix cores, rows i (16 per tile), contraction over j (4 per step), columns e.
+      for (int et = 0; et < MT; ++et) {
+        const int e = 16 * et + l16;
+        const bool eok = e < E;
+        for (int i0 = 0; i0 < N; i0 += 16) {
+          const int i = i0 + l16;
+          float outv[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int a0 = 0; a0 < A; a0 += 16) {
+            f32x4 T[16];
 #pragma unroll
-      for (int u = 0; u < MAXW; ++u) {
-        const int q = lane + 64 * u;
-        if (q < E * A) {
-          const int e = q / A, a = q % A;
-          int i = 0, j = 1;
-          float acc = 0.f;
-          for (int k = 0; k < P; ++k) {
-            if (mk[k] >> a & 1u) acc += de[k] * Zs[i * E + e] * Zs[j * E + e];
-            if (++j == N) { ++i; j = i + 1; }
+            for (int a = 0; a < 16; ++a) T[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 Tc = {0.f, 0.f, 0.f, 0.f};
+            for (int j0 = 0; j0 < N; j0 += 4) {
+              const int j = j0 + g4;
+              const bool ok = i < N && j < N && i != j;
+              const int lo = i < j ? i : j, hi = i < j ? j : i;
+              const int k = ok ? pair_base(lo, N) + (hi - lo - 1) : 0;
+              const float dek = ok ? de[k] : 0.f;
+              const uint32_t bits = ok ? mk[k] >> a0 : 0u;
+              const float zv = (j < N && eok) ? Zs[j * ES + e] : 0.f;
+              Tc = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? ck[k] : 0.f, zv, Tc, 0, 0, 0);
+#pragma unroll
+              for (int a = 0; a < 16; ++a)  // mask bits at and beyond A are zero
+                T[a] = __builtin_amdgcn_mfma_f32_16x16x4f32((bits >> a & 1u) ? dek : 0.f, zv, T[a], 0, 0, 0);
+            }
+            // element r of lane (g4, l16): row i0 + 4 g4 + r, column e
+            if (eok) {
+              if (a0 == 0) {
+                const float dxe = dxs[e];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) outv[r] += dxe * Tc[r];
+              }
+#pragma unroll
+              for (int a = 0; a < 16; ++a) {
+                const float hwv = a0 + a < A ? hl[a0 + a] * Wt[(a0 + a) * E + e] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) outv[r] += hwv * T[a][r];
+              }
+            }
           }
-          dWacc[u] += acc * hl[a];
+          if (eok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int ii = i0 + 4 * g4 + r;
+              if (ii < N) dz[b * dz_ld + ii * E + e] = outv[r];
+            }
+          }
         }
+      }
+      // Q += P^T V on the matrix cores: rows e, columns a, contraction over pairs (4 per step);
+      // A operand lane (row l16, k g4), B operand lane (k g4, column l16)
+      // 16 pairs per trip, operands of all four MFMA steps fetched together
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        if (nt == 1 && A <= 16) break;
+        f32x4 q[MT];
+        float rsum = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) q[m] = qacc[m][nt];
+        for (int k0 = 0; k0 < P; k0 += 16) {
+          uint32_t pr[4], bt[4];
+          float dk[4], pv[4][MT];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 4 * u + g4;
+            const bool ok = k < P;
+            pr[u] = ok ? ij[k] : 0u;
+            dk[u] = ok ? de[k] : 0.f;
+            bt[u] = ok ? mk[k] : 0u;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float* zi = Zs + (pr[u] & 0xffffu) * ES;
+            const float* zj = Zs + (pr[u] >> 16) * ES;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              const int e = 16 * m + l16;
+              pv[u][m] = e < E ? zi[e] * zj[e] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float v = (bt[u] >> (16 * nt + l16) & 1u) ? dk[u] : 0.f;
+            rsum += v;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) q[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[u][m], v, q[m], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) qacc[m][nt] = q[m];
+        racc[nt] += rsum;
       }
     }
   }
   if (BWD) {
+    // accumulator element r of lane (g4, l16) is Q[e = 16 m + 4 g4 + r][a = 16 nt + l16]
+    //   dW = h_a Q;  db_a = h_a R_a;  dh_a = sum_e W[e,a] Q[e,a] + b_a R_a   (relu'(t) t = mask t)
     const int64_t row = (int64_t)blockIdx.x * WAVES + wave;
     float* out = part + row * (E * A + 2 * A);
 #pragma unroll
-    for (int u = 0; u < MAXW; ++u) {
-      const int q = lane + 64 * u;
-      if (q < E * A) out[q] = dWacc[u];
-    }
+    for (int nt = 0; nt < 2; ++nt) {
+      const int a = 16 * nt + l16;
+      const bool aok = a < A;
+      float r = racc[nt];
+      r += __shfl_xor(r, 16);
+      r += __shfl_xor(r, 32);
+      float sh = 0.f;
 #pragma unroll
-    for (int a = 0; a < 32; ++a) {
-      if (a < A) {
-        const float sb = wave_sum(dba[a]), sh = wave_sum(dha[a]);
-        if (lane == 0) {
-          out[E * A + a] = sb * hl[a];
-          out[E * A + A + a] = sh;
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int e = 16 * m + 4 * g4 + rr;
+          if (aok && e < E) {
+            const float qv = qacc[m][nt][rr];
+            out[e * A + a] = hl[a] * qv;
+            sh += Wt[a * E + e] * qv;
+          }
         }
+      }
+      sh += __shfl_xor(sh, 16);
+      sh += __shfl_xor(sh, 32);
+      if (aok && g4 == 0) {
+        out[E * A + a] = hl[a] * r;
+        out[E * A + A + a] = sh + bl[a] * r;
       }
     }
   }
+}
+
+static size_t afm_pair_lds(int N, int E) {
+  return (size_t)WAVES * (2 * (size_t)N * (E + 1) + (size_t)N * (N - 1) / 2) * 4;
 }
 
 static int afm_blocks(int B) {
@@ -426,9 +567,11 @@ static int afm_blocks(int B) {
   return (int)n;
 }
 
+constexpr size_t AFM_LDS_MAX = 160 * 1024;  // LDS of one CU
+
 static size_t afm_attn_lds(int N, int E, int A, bool bwd) {
   const int P = N * (N - 1) / 2;
-  return ((size_t)2 * E * A + 2 * A + (size_t)WAVES * (N * E + (bwd ? 4 : 1) * P)) * sizeof(float);
+  return ((size_t)E * A + 2 * A + P + (size_t)WAVES * (N * (E + 1) + E + (bwd ? 4 : 1) * P)) * sizeof(float);
 }
 
 static unsigned grid_for(int64_t total) {
@@ -445,7 +588,9 @@ static int pnn_blocks(int B) {
 
 static bool pow2_le64(int E) { return E >= 4 && E <= 64 && (E & (E - 1)) == 0; }
 
-static size_t pnn_lds_bytes(int N, int E, int P) { return ((size_t)P * N + WAVES * ((size_t)N * E + (size_t)P * E)) * 4; }
+static size_t pnn_lds_bytes(int N, int E, int P) {
+  return ((size_t)P * N + WAVES * ((size_t)N * (E + 1) + (size_t)P * (E + 1))) * 4;
+}
 
 }  // namespace ctr
 
@@ -474,7 +619,8 @@ extern "C" int ctr_pnn_inner_bwd(const float* z, int64_t z_ld, const float* w, c
                                  void* workspace, size_t workspace_bytes, void* stream) {
   CTR_REQUIRE(B > 0 && N > 0 && P > 0, "ctr_pnn_inner_bwd: bad size");
   CTR_REQUIRE(pow2_le64(E), "ctr_pnn_inner_bwd: E=%d must be a power of two in [4,64]", E);
-  CTR_REQUIRE((int64_t)P * N <= 4096, "ctr_pnn_inner_bwd: P*N=%lld exceeds 4096", (long long)P * N);
+  CTR_REQUIRE(P <= 16 * PMT && N <= 16 * PNT, "ctr_pnn_inner_bwd: needs product_size <= %d and N <= %d", 16 * PMT,
+              16 * PNT);
   CTR_REQUIRE(pnn_lds_bytes(N, E, P) <= 64 * 1024, "ctr_pnn_inner_bwd: sizes exceed the LDS budget");
   CTR_REQUIRE(z && w && coef && dz && dw_out && workspace, "ctr_pnn_inner_bwd: null pointer");
   CTR_REQUIRE(z_ld >= (int64_t)N * E && dz_ld >= (int64_t)N * E, "ctr_pnn_inner_bwd: leading dimension");
@@ -487,8 +633,8 @@ extern "C" int ctr_pnn_inner_bwd(const float* z, int64_t z_ld, const float* w, c
   float* part = (float*)workspace;
   hipLaunchKernelGGL(pnn_inner_kernel<true>, dim3(nb), dim3(256), pnn_lds_bytes(N, E, P), st, z, z_ld, w, B, N, E,
                      P, (float*)nullptr, coef, coef_ld, dz, dz_ld, part);
-  hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)cdiv((int64_t)P * N, 256)), dim3(256), 0, st, part, nb * WAVES,
-                     P * N, dw_out);
+  hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)cdiv((int64_t)P * N, 16)), dim3(256), 0, st, part, nb * WAVES,
+                     P * N, dw_out, P * N, (float*)nullptr, 0, (float*)nullptr);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
@@ -536,10 +682,10 @@ extern "C" int ctr_vec_op(int kind, const float* a, const float* b, float* out, 
 extern "C" int ctr_afm_pair_fwd(const float* z, int64_t z_ld, int B, int N, int E, const ctr_dropout_t* pair_drop,
                                 float* x_out, void* stream) {
   CTR_REQUIRE(B >= 0 && N > 0 && E > 0, "ctr_afm_pair_fwd: bad size");
-  CTR_REQUIRE((size_t)WAVES * 2 * N * E * 4 <= 64 * 1024, "ctr_afm_pair_fwd: N*E=%d exceeds the LDS budget", N * E);
+  CTR_REQUIRE(afm_pair_lds(N, E) <= 64 * 1024, "ctr_afm_pair_fwd: N*E=%d exceeds the LDS budget", N * E);
   if (B == 0) return CTR_OK;
   CTR_REQUIRE(z && x_out && z_ld >= (int64_t)N * E, "ctr_afm_pair_fwd: null pointer / z_ld");
-  hipLaunchKernelGGL(afm_pair_kernel<false>, dim3((unsigned)cdiv(B, WAVES)), dim3(256), (size_t)WAVES * 2 * N * E * 4,
+  hipLaunchKernelGGL(afm_pair_kernel<false>, dim3((unsigned)cdiv(B, WAVES)), dim3(256), afm_pair_lds(N, E),
                      (hipStream_t)stream, z, z_ld, B, N, E, make_drop(pair_drop), x_out, (const float*)nullptr,
                      (float*)nullptr, (int64_t)0);
   CTR_LAUNCH_CHECK();
@@ -549,10 +695,10 @@ extern "C" int ctr_afm_pair_fwd(const float* z, int64_t z_ld, int B, int N, int 
 extern "C" int ctr_afm_pair_bwd(const float* z, int64_t z_ld, const float* dx, int B, int N, int E,
                                 const ctr_dropout_t* pair_drop, float* dz, int64_t dz_ld, void* stream) {
   CTR_REQUIRE(B >= 0 && N > 0 && E > 0, "ctr_afm_pair_bwd: bad size");
-  CTR_REQUIRE((size_t)WAVES * 2 * N * E * 4 <= 64 * 1024, "ctr_afm_pair_bwd: N*E=%d exceeds the LDS budget", N * E);
+  CTR_REQUIRE(afm_pair_lds(N, E) <= 64 * 1024, "ctr_afm_pair_bwd: N*E=%d exceeds the LDS budget", N * E);
   if (B == 0) return CTR_OK;
   CTR_REQUIRE(z && dx && dz && z_ld >= (int64_t)N * E && dz_ld >= (int64_t)N * E, "ctr_afm_pair_bwd: null pointer / ld");
-  hipLaunchKernelGGL(afm_pair_kernel<true>, dim3((unsigned)cdiv(B, WAVES)), dim3(256), (size_t)WAVES * 2 * N * E * 4,
+  hipLaunchKernelGGL(afm_pair_kernel<true>, dim3((unsigned)cdiv(B, WAVES)), dim3(256), afm_pair_lds(N, E),
                      (hipStream_t)stream, z, z_ld, B, N, E, make_drop(pair_drop), (float*)nullptr, dx, dz, dz_ld);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
@@ -563,7 +709,7 @@ extern "C" int ctr_afm_attn_fwd(const float* z, int64_t z_ld, int B, int N, int 
                                 void* stream) {
   CTR_REQUIRE(B >= 0 && N >= 2 && A >= 1 && A <= 32, "ctr_afm_attn_fwd: need N >= 2 and 1 <= A <= 32");
   CTR_REQUIRE(pow2_le64(E), "ctr_afm_attn_fwd: E=%d must be a power of two in [4,64]", E);
-  CTR_REQUIRE(afm_attn_lds(N, E, A, false) <= 64 * 1024, "ctr_afm_attn_fwd: N=%d, E=%d exceed the LDS budget", N, E);
+  CTR_REQUIRE(afm_attn_lds(N, E, A, false) <= AFM_LDS_MAX, "ctr_afm_attn_fwd: N=%d, E=%d exceed the LDS budget", N, E);
   if (B == 0) return CTR_OK;
   CTR_REQUIRE(z && W && b && h && x_out && z_ld >= (int64_t)N * E, "ctr_afm_attn_fwd: null pointer / z_ld");
   const dim3 grid(afm_blocks(B)), block(256);
@@ -571,6 +717,9 @@ extern "C" int ctr_afm_attn_fwd(const float* z, int64_t z_ld, int B, int N, int 
   hipStream_t st = (hipStream_t)stream;
   const Drop d = make_drop(pair_drop);
 #define AL(EE)                                                                                                  \
+  if (lds > 64 * 1024)                                                                                          \
+    CTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&afm_attn_kernel<EE, false>),                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
   hipLaunchKernelGGL((afm_attn_kernel<EE, false>), grid, block, lds, st, z, z_ld, B, N, A, W, b, h, d, x_out,    \
                      (const float*)nullptr, (float*)nullptr, (int64_t)0, (float*)nullptr)
   switch (E) { case 4: AL(4); break; case 8: AL(8); break; case 16: AL(16); break; case 32: AL(32); break; default: AL(64); }
@@ -589,7 +738,7 @@ extern "C" int ctr_afm_attn_bwd(const float* z, int64_t z_ld, const float* dx, i
                                 size_t workspace_bytes, void* stream) {
   CTR_REQUIRE(B > 0 && N >= 2 && A >= 1 && A <= 32, "ctr_afm_attn_bwd: need B > 0, N >= 2 and 1 <= A <= 32");
   CTR_REQUIRE(pow2_le64(E), "ctr_afm_attn_bwd: E=%d must be a power of two in [4,64]", E);
-  CTR_REQUIRE(afm_attn_lds(N, E, A, true) <= 64 * 1024, "ctr_afm_attn_bwd: N=%d, E=%d exceed the LDS budget", N, E);
+  CTR_REQUIRE(afm_attn_lds(N, E, A, true) <= AFM_LDS_MAX, "ctr_afm_attn_bwd: N=%d, E=%d exceed the LDS budget", N, E);
   CTR_REQUIRE(z && dx && W && b && h && dz && dW && db && dh && workspace, "ctr_afm_attn_bwd: null pointer");
   CTR_REQUIRE(z_ld >= (int64_t)N * E && dz_ld >= (int64_t)N * E, "ctr_afm_attn_bwd: leading dimension");
   if (workspace_bytes < ctr_afm_attn_bwd_workspace_bytes(B, E, A)) {
@@ -603,15 +752,17 @@ extern "C" int ctr_afm_attn_bwd(const float* z, int64_t z_ld, const float* dx, i
   const Drop d = make_drop(pair_drop);
   float* part = (float*)workspace;
 #define AL(EE)                                                                                                  \
+  if (lds > 64 * 1024)                                                                                          \
+    CTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&afm_attn_kernel<EE, true>),                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
   hipLaunchKernelGGL((afm_attn_kernel<EE, true>), grid, block, lds, st, z, z_ld, B, N, A, W, b, h, d,            \
                      (float*)nullptr, dx, dz, dz_ld, part)
   switch (E) { case 4: AL(4); break; case 8: AL(8); break; case 16: AL(16); break; case 32: AL(32); break; default: AL(64); }
 #undef AL
   // fixed-order sums of the per-wave partial rows: [dW (E*A) | db (A) | dh (A)]
   const int cols = E * A + 2 * A;
-  float* tmp = part;  // rows_sum writes to the destinations directly
-  hipLaunchKernelGGL(rows_sum_strided_kernel, dim3((unsigned)cdiv(cols, 256)), dim3(256), 0, st, tmp, nb * WAVES, cols,
-                     dW, E * A, db, A, dh);
+  hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)cdiv(cols, 16)), dim3(256), 0, st, part, nb * WAVES, cols, dW,
+                     E * A, db, A, dh);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
