@@ -35,7 +35,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: 65536 DeepFM, 8192 DCN)')
     ap.add_argument('--embed', type=int, default=0, help='embedding dim (default: 16 DeepFM, 64 DCN)')
     ap.add_argument('--alpha', type=float, default=1.05, help='Zipf exponent of the ids (0 = uniform)')
-    ap.add_argument('--model', default='DeepFM', choices=['DeepFM', 'DCN'])
+    ap.add_argument('--model', default='DeepFM', choices=sorted(MODEL_ARGS),
+                    help='DeepFM is the headline workload; the others time the same step for their family')
     ap.add_argument('--comm', default='rccl', choices=['rccl', 'host-staged'],
                     help='host-staged: gloo through host memory, to rehearse N>1 with all ranks on one GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -43,21 +44,28 @@ def parse():
     return ap.parse_args()
 
 
+# reference flag defaults of each model's main.py (DeepFM/main.py:48-59 and siblings); the DCN entry is
+# BASELINE configs[2] (6 cross layers, 1024x3 tower), the others run on the Criteo-Kaggle shape
+MODEL_ARGS = {
+    'DeepFM': dict(deep_layers=[256, 128, 64, 32], dropout_fm=0.5, dropout_deep=0.2),
+    'DCN': dict(deep_layers=[1024, 1024, 1024], cross_layer_num=6, dropout=0.2),
+    'NFM': dict(deep_layers=[256, 128, 64, 32], dropout_bi=0.5, dropout_deep=0.2),
+    'ESMM': dict(deep_layers=[256, 128, 64, 32], dropout=0.2),
+    'PNN': dict(inner_product=True, product_size=50, hidden_layers=[32, 64, 128], dropout=0.2),
+    'PNN_outer': dict(inner_product=False, product_size=50, hidden_layers=[32, 64, 128], dropout=0.2),
+    'AFM': dict(attention_size=10, dropout=0.2),
+    'AFM_pairs': dict(attention_size=10, dropout=0.2, attention='pairs'),
+}
+
+
 def build_model(args, sess, cards, rank, world):
+    import importlib
     import recommendation_amd as ra
     ra.enable_zoo_imports()
-    if args.model == 'DeepFM':
-        from DeepFM import DeepFM as mod
-        margs = SimpleNamespace(embed_size=args.embed, deep_layers=[256, 128, 64, 32], regular_rate=0.1,
-                                dropout_fm=0.5, dropout_deep=0.2, learning_rate=0.001, decay_steps=10000,
-                                decay_rate=0.99, mode='S', adam_mode='lazy', init_std=0.01)
-        cls = mod.DeepFM
-    else:
-        from DCN import DCN as mod
-        margs = SimpleNamespace(embed_size=args.embed, deep_layers=[1024, 1024, 1024], cross_layer_num=6,
-                                regular_rate=0.1, dropout=0.2, learning_rate=0.001, decay_steps=10000,
-                                decay_rate=0.99, mode='S', adam_mode='lazy', init_std=0.01)
-        cls = mod.DCN
+    name = args.model.split('_')[0]
+    margs = SimpleNamespace(embed_size=args.embed, regular_rate=0.1, learning_rate=0.001, decay_steps=10000,
+                            decay_rate=0.99, mode='S', adam_mode='lazy', init_std=0.01, **MODEL_ARGS[args.model])
+    cls = getattr(importlib.import_module('%s.%s' % (name, name)), name)
     if world > 1:
         margs.world_size, margs.rank = world, rank
         if args.comm == 'host-staged':
@@ -116,9 +124,9 @@ def load_traffic():
 def main():
     args = parse()
     if not args.batch:
-        args.batch = 65536 if args.model == 'DeepFM' else 8192
+        args.batch = 8192 if args.model == 'DCN' else 65536
     if not args.embed:
-        args.embed = 16 if args.model == 'DeepFM' else 64
+        args.embed = 64 if args.model == 'DCN' else 16
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -145,8 +153,8 @@ def main():
     sess = ra.Session(dev, seed=11 + rank)
     # DeepFM: BASELINE configs[1] (Criteo-Kaggle cardinalities).  DCN: configs[2] per-GPU share —
     # Criteo-1TB cardinalities / 8 (one GPU of the 8-GPU shard), dim 64, 6 cross layers, 1024x3 tower.
-    cards = CRITEO_KAGGLE if args.model == 'DeepFM' else scaled(CRITEO_1TB, 8 // min(world, 8))
-    shape_name = 'Criteo-Kaggle' if args.model == 'DeepFM' else 'Criteo-1TB/%d' % (8 // min(world, 8))
+    cards = CRITEO_KAGGLE if args.model != 'DCN' else scaled(CRITEO_1TB, 8 // min(world, 8))
+    shape_name = 'Criteo-Kaggle' if args.model != 'DCN' else 'Criteo-1TB/%d' % (8 // min(world, 8))
     model = build_model(args, sess, cards, rank, world)
     B = args.batch
     batches = make_batches(cards, 13, B, 8, args.alpha, 20240601 + rank, dev)
@@ -191,7 +199,7 @@ def main():
                                     'row-wise Adam on touched rows), dropout at the reference rates'
                                     % (args.model, shape_name, int(np.sum(cards)), args.embed, B, args.alpha),
                            global_batch=world * B, parallelism='dp%d' % world if world > 1 else 'single'),
-               final_loss=loss)
+               final_loss=loss if np.isfinite(loss) else None)
     if timer is not None:
         ks = timer.summary()
         F, E = len(cards), args.embed

@@ -276,7 +276,7 @@ int ctr_cross_bwd(const float* x0, int64_t x0_ld, const float* w, const float* b
  *   inner backward: du[b,p,e] = coef * u[b,p,e] with coef = coef[p] (coef_ld == 0) or
  *          coef[b*coef_ld + p];  dz += du . w;  dw_out[p,n] = sum_{b,e} du * Z.
  *   outer: ss_out[b, e*E+f] = s[b,e]*s[b,f];  ds_out[b,e] = sum_f (dss[b,e,f]+dss[b,f,e])*s[b,f].
- * E must be a power of two in [4,64]; P*N <= 4096.
+ * E must be a power of two in [4,64]; the backward needs P <= 64 and N <= 128.
  * ---------------------------------------------------------------------------------- */
 int ctr_pnn_inner_fwd(const float* z, int64_t z_ld, const float* w, int B, int N, int E, int P,
                       float* usq_out, void* stream);

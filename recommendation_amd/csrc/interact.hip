@@ -16,9 +16,8 @@ constexpr int WAVES = 4;
 // LDS: w [P*N] shared by the block, then per wave Z [N*E] and u [P*E].
 // ---------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int PMT = 2, PNT = 8;  // backward handles product_size <= 32 and N <= 128 (16 x 16 dw tiles)
-
-template <bool BWD>
+// PMT x PNT: number of 16 x 16 dw tiles (rows p, columns n) the backward instance keeps in registers
+template <bool BWD, int PMT, int PNT>
 __global__ __launch_bounds__(256) void pnn_inner_kernel(const float* __restrict__ z, int64_t z_ld,
                                                        const float* __restrict__ w, int B, int N, int E, int P,
                                                        float* __restrict__ usq, const float* __restrict__ coef,
@@ -603,7 +602,7 @@ extern "C" int ctr_pnn_inner_fwd(const float* z, int64_t z_ld, const float* w, i
   CTR_REQUIRE(pnn_lds_bytes(N, E, P) <= 64 * 1024, "ctr_pnn_inner_fwd: N=%d,E=%d,P=%d exceed the LDS budget", N, E, P);
   if (B == 0) return CTR_OK;
   CTR_REQUIRE(z && w && usq_out && z_ld >= (int64_t)N * E, "ctr_pnn_inner_fwd: null pointer / z_ld");
-  hipLaunchKernelGGL(pnn_inner_kernel<false>, dim3(pnn_blocks(B)), dim3(256), pnn_lds_bytes(N, E, P),
+  hipLaunchKernelGGL((pnn_inner_kernel<false, 1, 1>), dim3(pnn_blocks(B)), dim3(256), pnn_lds_bytes(N, E, P),
                      (hipStream_t)stream, z, z_ld, w, B, N, E, P, usq_out, (const float*)nullptr, (int64_t)0,
                      (float*)nullptr, (int64_t)0, (float*)nullptr);
   CTR_LAUNCH_CHECK();
@@ -619,8 +618,7 @@ extern "C" int ctr_pnn_inner_bwd(const float* z, int64_t z_ld, const float* w, c
                                  void* workspace, size_t workspace_bytes, void* stream) {
   CTR_REQUIRE(B > 0 && N > 0 && P > 0, "ctr_pnn_inner_bwd: bad size");
   CTR_REQUIRE(pow2_le64(E), "ctr_pnn_inner_bwd: E=%d must be a power of two in [4,64]", E);
-  CTR_REQUIRE(P <= 16 * PMT && N <= 16 * PNT, "ctr_pnn_inner_bwd: needs product_size <= %d and N <= %d", 16 * PMT,
-              16 * PNT);
+  CTR_REQUIRE(P <= 64 && N <= 128, "ctr_pnn_inner_bwd: needs product_size <= 64 and N <= 128 (got %d, %d)", P, N);
   CTR_REQUIRE(pnn_lds_bytes(N, E, P) <= 64 * 1024, "ctr_pnn_inner_bwd: sizes exceed the LDS budget");
   CTR_REQUIRE(z && w && coef && dz && dw_out && workspace, "ctr_pnn_inner_bwd: null pointer");
   CTR_REQUIRE(z_ld >= (int64_t)N * E && dz_ld >= (int64_t)N * E, "ctr_pnn_inner_bwd: leading dimension");
@@ -631,8 +629,21 @@ extern "C" int ctr_pnn_inner_bwd(const float* z, int64_t z_ld, const float* w, c
   hipStream_t st = (hipStream_t)stream;
   const int nb = pnn_blocks(B);
   float* part = (float*)workspace;
-  hipLaunchKernelGGL(pnn_inner_kernel<true>, dim3(nb), dim3(256), pnn_lds_bytes(N, E, P), st, z, z_ld, w, B, N, E,
-                     P, (float*)nullptr, coef, coef_ld, dz, dz_ld, part);
+  const size_t lds = pnn_lds_bytes(N, E, P);
+#define PL(MT, NT)                                                                                              \
+  hipLaunchKernelGGL((pnn_inner_kernel<true, MT, NT>), dim3(nb), dim3(256), lds, st, z, z_ld, w, B, N, E, P,      \
+                     (float*)nullptr, coef, coef_ld, dz, dz_ld, part)
+#define PLN(MT)                                                                                                 \
+  do {                                                                                                          \
+    if (N <= 32) PL(MT, 2);                                                                                     \
+    else if (N <= 64) PL(MT, 4);                                                                                \
+    else PL(MT, 8);                                                                                             \
+  } while (0)
+  if (P <= 16) PLN(1);
+  else if (P <= 32) PLN(2);
+  else PLN(4);
+#undef PLN
+#undef PL
   hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)cdiv((int64_t)P * N, 16)), dim3(256), 0, st, part, nb * WAVES,
                      P * N, dw_out, P * N, (float*)nullptr, 0, (float*)nullptr);
   CTR_LAUNCH_CHECK();

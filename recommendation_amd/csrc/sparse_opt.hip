@@ -1,7 +1,7 @@
 // Segment-reduce over sorted (key, src) pairs + fused row-wise optimizer, and the dense
-// (flat-buffer) optimizers.  A row of E floats is owned by G = E/4 lanes; the group that
-// sits on the first pair of a run of equal keys walks the run in sorted order (fixed
-// summation order => bitwise reproducible), then updates that table row once.
+// (flat-buffer) optimizers.  A row of E floats is owned by G = E/4 lanes; runs of equal keys are
+// added with a segmented scan in a fixed order (bitwise reproducible) and each touched table
+// row is updated exactly once.
 #include "common.h"
 
 namespace ctr {
@@ -36,17 +36,27 @@ __device__ static inline void opt_apply4(const Opt& o, float4 g, float4* w, floa
   }
 }
 
-// Runs of equal keys are cut at every multiple of SEG positions of the sorted array, so no
-// lane group ever walks more than SEG pairs (a Zipf-hot row can own tens of thousands).
-//   pass 1: one lane group per piece start (key change or position % SEG == 0) sums its piece.
-//           A run that fits inside one SEG block is finished here.  Otherwise the piece that
-//           holds the run's head goes to part_head[block] (+ head_key[block] = key) and every
-//           later piece, which starts exactly at a block boundary, goes to part[block].
+// The sorted array is cut into blocks of SEG pairs, one wave per block.
+//   pass 1: every lane group fetches the gradient row of its OWN pair (R = 64/G pairs per round, all
+//           rounds' loads in flight together), then a segmented inclusive scan over the groups adds
+//           rows of equal key (keys are sorted, so "same key d groups back" means one run); a carry
+//           links the rounds.  The last pair of each run holds the run's sum inside the block.
+//           A run that lies inside the block is finished here (optimizer applied once).  A run that
+//           starts here and continues goes to part_head[block] (+ head_key[block] = key); the part of a
+//           run that started in an earlier block goes to part[block].
 //   pass 2: one wave per block with a recorded head adds part_head + the continuation pieces in
 //           block order (R pieces per step in fixed lane slots, then a fixed-order shuffle tree)
-//           and applies the optimizer.  No atomics: bitwise reproducible.
+//           and applies the optimizer.
+// Fixed summation order and no atomics: bitwise reproducible.
 constexpr int SEG = 64;
 constexpr uint32_t NO_KEY = 0xFFFFFFFFu;
+
+__device__ static inline float4 shfl_up4(float4 v, int d) {
+  return make_float4(__shfl_up(v.x, d), __shfl_up(v.y, d), __shfl_up(v.z, d), __shfl_up(v.w, d));
+}
+__device__ static inline float4 shfl4(float4 v, int l) {
+  return make_float4(__shfl(v.x, l), __shfl(v.y, l), __shfl(v.z, l), __shfl(v.w, l));
+}
 
 template <int G>
 __global__ __launch_bounds__(256) void sparse_apply_kernel(
@@ -54,57 +64,72 @@ __global__ __launch_bounds__(256) void sparse_apply_kernel(
     int64_t total_rows, const float* __restrict__ dz, int64_t dz_ld, const float* __restrict__ src_scale,
     float* __restrict__ tables, float* __restrict__ slot0, float* __restrict__ slot1, Opt opt,
     float* __restrict__ part, float* __restrict__ part_head, uint32_t* __restrict__ head_key) {
-  const int64_t item = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
-  const int g = threadIdx.x % G;
-  if (item >= n_items) return;
-  const uint32_t key = keys[item];
-  if ((int64_t)key >= total_rows) return;
-  const bool run_head = item == 0 || keys[item - 1] != key;
-  if (!run_head && (item % SEG) != 0) return;  // not the start of a piece
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  // Walk the piece four pairs at a time: the four (src, row) loads are issued together and then
-  // added in sorted order, stopping at the first pair that leaves the piece.
-  const int64_t piece_end = (item / SEG + 1) * SEG < n_items ? (item / SEG + 1) * SEG : n_items;
-  int64_t j = item;
-  bool more = true;   // "pair j belongs to this run" for the pair the loop is about to add
-  while (more && j < piece_end) {
-    uint32_t kk[4], sj[4];
-    float4 v[4];
-    float sc[4];
+  constexpr int R = 64 / G;        // pairs per round
+  constexpr int ROUNDS = SEG / R;  // = G
+  constexpr int BATCH = ROUNDS < 4 ? ROUNDS : 4;
+  const int lane = threadIdx.x & 63;
+  const int g = lane % G, q = lane / G;
+  const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t start = blk * SEG;
+  if (start >= n_items) return;
+  const int64_t end = start + SEG < n_items ? start + SEG : n_items;
+  const uint32_t first_key = keys[start];
+  const bool first_is_head = start == 0 || keys[start - 1] != first_key;
+  float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t carry_key = NO_KEY;
+  uint32_t recorded = NO_KEY;      // key of the run that starts in this block and leaves it
+  for (int r0 = 0; r0 < ROUNDS; r0 += BATCH) {
+    uint32_t key[BATCH], nkey[BATCH];
+    float4 val[BATCH];
+    float sc[BATCH];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t q = j + u < n_items ? j + u : n_items - 1;
-      kk[u] = keys[q];
-      sj[u] = src[q];
+    for (int u = 0; u < BATCH; ++u) {
+      const int64_t item = start + (int64_t)(r0 + u) * R + q;
+      const bool ok = item < end;
+      key[u] = ok ? keys[item] : NO_KEY;
+      nkey[u] = ok && item + 1 < n_items ? keys[item + 1] : NO_KEY;
+      const uint32_t s = ok ? src[item] : 0u;
+      val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      sc[u] = 1.f;
+      if (ok && (int64_t)key[u] < total_rows) {
+        const int64_t b = s / (uint32_t)N;
+        const int64_t n = s % (uint32_t)N;
+        val[u] = *reinterpret_cast<const float4*>(dz + b * dz_ld + n * E + g * 4);
+        if (src_scale) sc[u] = src_scale[s];
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t b = sj[u] / (uint32_t)N;
-      const int64_t n = sj[u] % (uint32_t)N;
-      v[u] = *reinterpret_cast<const float4*>(dz + b * dz_ld + n * E + g * 4);
-      sc[u] = src_scale ? src_scale[sj[u]] : 1.f;
-    }
+    for (int u = 0; u < BATCH; ++u) {
+      const int64_t item = start + (int64_t)(r0 + u) * R + q;
+      float4 v = make_float4(val[u].x * sc[u], val[u].y * sc[u], val[u].z * sc[u], val[u].w * sc[u]);
+      const uint32_t k = key[u];
+      if (q == 0 && k == carry_key) { v.x += carry.x; v.y += carry.y; v.z += carry.z; v.w += carry.w; }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const bool inside = j + u < piece_end;
-      if (inside && kk[u] != key) more = false;          // the run ends inside this piece
-      if (more && inside) { acc.x += v[u].x * sc[u]; acc.y += v[u].y * sc[u]; acc.z += v[u].z * sc[u]; acc.w += v[u].w * sc[u]; }
+      for (int d = 1; d < R; d <<= 1) {
+        const float4 pv = shfl_up4(v, d * G);
+        const uint32_t pk = __shfl_up(k, d * G);
+        if (q >= d && pk == k) { v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w; }
+      }
+      carry = shfl4(v, (R - 1) * G + g);
+      carry_key = __shfl(k, (R - 1) * G);
+      const bool last = item == end - 1;
+      if (item < end && (int64_t)k < total_rows && (nkey[u] != k || last)) {
+        const bool leaves = last && nkey[u] == k;
+        const bool open = k == first_key && !first_is_head;
+        if (open) {
+          *reinterpret_cast<float4*>(part + blk * E + g * 4) = v;
+        } else if (leaves) {
+          *reinterpret_cast<float4*>(part_head + blk * E + g * 4) = v;
+          recorded = k;
+        } else {
+          const int64_t off = (int64_t)k * E + g * 4;
+          opt_apply4(opt, v, reinterpret_cast<float4*>(tables + off),
+                     slot0 ? reinterpret_cast<float4*>(slot0 + off) : nullptr,
+                     slot1 ? reinterpret_cast<float4*>(slot1 + off) : nullptr);
+        }
+      }
+      if (last && g == 0) head_key[blk] = recorded;
     }
-    j += 4;
-  }
-  // does the run continue past this piece?
-  more = more && piece_end < n_items && keys[piece_end] == key;
-  const int64_t blk = item / SEG;
-  if (run_head && !more) {
-    const int64_t off = (int64_t)key * E + g * 4;
-    opt_apply4(opt, acc, reinterpret_cast<float4*>(tables + off),
-               slot0 ? reinterpret_cast<float4*>(slot0 + off) : nullptr,
-               slot1 ? reinterpret_cast<float4*>(slot1 + off) : nullptr);
-  } else if (run_head) {
-    *reinterpret_cast<float4*>(part_head + blk * E + g * 4) = acc;
-    if (g == 0) head_key[blk] = key;
-  } else {
-    *reinterpret_cast<float4*>(part + blk * E + g * 4) = acc;
   }
 }
 
@@ -217,9 +242,7 @@ extern "C" int ctr_emb_sparse_apply(const uint32_t* keys_sorted, const uint32_t*
   float* part = (float*)wsp; wsp += align_up((size_t)nb * E * sizeof(float), 256);
   float* part_head = (float*)wsp; wsp += align_up((size_t)nb * E * sizeof(float), 256);
   uint32_t* head_key = (uint32_t*)wsp;
-  hipError_t me = hipMemsetAsync(head_key, 0xFF, (size_t)nb * sizeof(uint32_t), st);
-  if (me != hipSuccess) { set_error("ctr_emb_sparse_apply: memset failed: %s", hipGetErrorString(me)); return (int)me; }
-  const dim3 grid((unsigned)cdiv(n_items, 256 / G)), block(256);
+  const dim3 grid((unsigned)cdiv(nb, 4)), block(256);  // one wave per block of SEG pairs; it also sets head_key
   const dim3 grid2((unsigned)cdiv(nb, 4));
   // GRAD_ONLY writes through slot0 only; give the kernel a non-null table pointer it never uses.
   float* tab = tables ? tables : slot0;
