@@ -37,7 +37,8 @@ __device__ static inline float epilogue(const Epi& e, float v, int m, int n, int
 // Fetch this thread's share of an R x BK operand tile (R = 32..256) as float4 slots.
 //   KCONTIG: element (r, k) at P[r*ld + k]   (rows = the M or N index); slot -> (r = s/(BK/4), k = 4*(s%(BK/4)))
 //   else:    element (r, k) at P[k*ld + r];                            slot -> (k = s/(R/4), r = 4*(s%(R/4)))
-template <bool KCONTIG, int R>
+// FULLK: the whole k range [k0, k0 + BK) is inside the matrix (no k bound checks on the fast path).
+template <bool KCONTIG, int R, bool FULLK>
 __device__ static inline void tile_load(const float* __restrict__ P, int64_t ld, bool vec, int r0, int rmax,
                                         int k0, int kend, int t, float (&reg)[(R * (BK / 4) + 255) / 256 * 4]) {
   constexpr int SLOTS = R * (BK / 4);
@@ -50,7 +51,7 @@ __device__ static inline void tile_load(const float* __restrict__ P, int64_t ld,
         const int r = r0 + s / (BK / 4);
         const int k = k0 + (s % (BK / 4)) * 4;
         const float* p = P + (int64_t)r * ld + k;
-        if (r < rmax && vec && k + 3 < kend) {
+        if (r < rmax && vec && (FULLK || k + 3 < kend)) {
           const float4 v = *reinterpret_cast<const float4*>(p);
           v0 = v.x; v1 = v.y; v2 = v.z; v3 = v.w;
         } else if (r < rmax) {
@@ -63,7 +64,7 @@ __device__ static inline void tile_load(const float* __restrict__ P, int64_t ld,
         const int k = k0 + s / (R / 4);
         const int r = r0 + (s % (R / 4)) * 4;
         const float* p = P + (int64_t)k * ld + r;
-        if (k < kend && vec && r + 3 < rmax) {
+        if ((FULLK || k < kend) && vec && r + 3 < rmax) {
           const float4 v = *reinterpret_cast<const float4*>(p);
           v0 = v.x; v1 = v.y; v2 = v.z; v3 = v.w;
         } else if (k < kend) {
@@ -104,7 +105,7 @@ __device__ static inline void tile_store(float* __restrict__ S, int t, const flo
 // A_K: A stored [M,K] (k contiguous).  B_K: B stored [N,K] (k contiguous).
 // Tile TBM x TBN x BK, four waves as WGM x (4/WGM); a wave owns TM x TN MFMA tiles of 32x32.
 template <bool A_K, bool B_K, int TBM, int TBN, int WGM>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A,
+__global__ __launch_bounds__(256, 4) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A,
                                                       int64_t lda, bool vecA, const float* __restrict__ Bm,
                                                       int64_t ldb, bool vecB, float* __restrict__ C,
                                                       int64_t ldc, Epi epi, int k_chunk,
@@ -114,8 +115,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
   constexpr int SA = A_K ? TBM + 2 : TBM + 4;
   constexpr int SB = B_K ? TBN + 2 : TBN + 4;
   constexpr int RA = (TBM * (BK / 4) + 255) / 256 * 4, RB = (TBN * (BK / 4) + 255) / 256 * 4;
-  __shared__ __attribute__((aligned(16))) float As[BK * SA];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * SB];
+  constexpr int CS = 36;  // row stride of the per-wave 32 x 32 staging tile of the epilogue
+  constexpr int SMEM = BK * (SA + SB) > 4 * 32 * CS ? BK * (SA + SB) : 4 * 32 * CS;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+  float* As = smem;
+  float* Bs = smem + BK * SA;
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
@@ -132,8 +136,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float ra[RA], rb[RB];
-  tile_load<A_K, TBM>(A, lda, vecA, m0, M, kbeg, kend, t, ra);
-  tile_load<B_K, TBN>(Bm, ldb, vecB, n0, N, kbeg, kend, t, rb);
+  if (kbeg + BK <= kend) {
+    tile_load<A_K, TBM, true>(A, lda, vecA, m0, M, kbeg, kend, t, ra);
+    tile_load<B_K, TBN, true>(Bm, ldb, vecB, n0, N, kbeg, kend, t, rb);
+  } else {
+    tile_load<A_K, TBM, false>(A, lda, vecA, m0, M, kbeg, kend, t, ra);
+    tile_load<B_K, TBN, false>(Bm, ldb, vecB, n0, N, kbeg, kend, t, rb);
+  }
 
   const int lr = lane & 31, lk = lane >> 5;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
@@ -141,9 +150,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
     tile_store<A_K, TBM>(As, t, ra);
     tile_store<B_K, TBN>(Bs, t, rb);
     __syncthreads();
-    if (k0 + BK < kend) {  // prefetch the next tile while this one is multiplied
-      tile_load<A_K, TBM>(A, lda, vecA, m0, M, k0 + BK, kend, t, ra);
-      tile_load<B_K, TBN>(Bm, ldb, vecB, n0, N, k0 + BK, kend, t, rb);
+    // prefetch the next tile while this one is multiplied; only the last tile of a ragged K takes
+    // the bound-checked path
+    if (k0 + 2 * BK <= kend) {
+      tile_load<A_K, TBM, true>(A, lda, vecA, m0, M, k0 + BK, kend, t, ra);
+      tile_load<B_K, TBN, true>(Bm, ldb, vecB, n0, N, k0 + BK, kend, t, rb);
+    } else if (k0 + BK < kend) {
+      tile_load<A_K, TBM, false>(A, lda, vecA, m0, M, k0 + BK, kend, t, ra);
+      tile_load<B_K, TBN, false>(Bm, ldb, vecB, n0, N, k0 + BK, kend, t, rb);
     }
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
@@ -161,24 +175,77 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
     }
   }
 
-  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+  // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+  // Each 32 x 32 tile goes through a per-wave LDS tile and leaves as 16-byte stores (8 rows x 128 bytes per
+  // wave instruction): a quarter of the store instructions of the register layout.
+  __syncthreads();  // every wave is done with As / Bs
+  float* S = smem + wave * (32 * CS);
+  float* out = partial ? partial + (int64_t)blockIdx.z * M * N : C;
+  const int64_t ldo = partial ? N : ldc;
+  const bool vec_out = (ldo % 4 == 0) && ((uintptr_t)out % 16 == 0);
+  const bool vec_mask = epi.mask_src && (epi.mask_ld % 4 == 0) && ((uintptr_t)epi.mask_src % 16 == 0);
+  const int srow = lane >> 3, sc4 = (lane & 7) * 4;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (32 * TM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        const int n = n0 + wn * (32 * TN) + j * 32 + lr;
-        if (m < M && n < N) {
-          if (partial) {
-            partial[((int64_t)blockIdx.z * M + m) * N + n] = acc[i][j][r];
-          } else {
-            float* cp = C + (int64_t)m * ldc + n;
-            *cp = epilogue(epi, acc[i][j][r], m, n, N, cp);
+      for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * lk) * CS + lr] = acc[i][j][r];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + srow;
+        const float4 v4 = *reinterpret_cast<const float4*>(&S[row * CS + sc4]);
+        const int m = m0 + wm * (32 * TM) + i * 32 + row;
+        const int n = n0 + wn * (32 * TN) + j * 32 + sc4;
+        if (m >= M || n >= N) continue;
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        float* cp = out + (int64_t)m * ldo + n;
+        const bool full = n + 3 < N;
+        if (!partial) {
+          float cold[4] = {0.f, 0.f, 0.f, 0.f}, mk[4] = {1.f, 1.f, 1.f, 1.f};
+          if (epi.accumulate) {
+            if (full && vec_out) {
+              const float4 c4 = *reinterpret_cast<const float4*>(cp);
+              cold[0] = c4.x; cold[1] = c4.y; cold[2] = c4.z; cold[3] = c4.w;
+            } else {
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                if (n + u < N) cold[u] = cp[u];
+            }
+          }
+          if (epi.mask_src) {
+            const float* mp = epi.mask_src + (int64_t)m * epi.mask_ld + n;
+            if (full && vec_mask) {
+              const float4 m4 = *reinterpret_cast<const float4*>(mp);
+              mk[0] = m4.x; mk[1] = m4.y; mk[2] = m4.z; mk[3] = m4.w;
+            } else {
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                if (n + u < N) mk[u] = mp[u];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (n + u >= N) break;
+            float x = v[u];
+            if (epi.bias) x += epi.bias[n + u];
+            if (epi.accumulate) x += cold[u];
+            if (epi.relu == 1) x = fmaxf(x, 0.f);
+            else if (epi.relu == 2) x = 1.f / (1.f + expf(-x));
+            if (epi.drop.on) x *= drop_mul(epi.drop, (uint64_t)m * (uint64_t)N + (uint64_t)(n + u));
+            if (epi.mask_src) x = mk[u] > 0.f ? x * epi.mask_scale : 0.f;
+            v[u] = x;
           }
         }
+        if (full && vec_out) {
+          *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (n + u < N) cp[u] = v[u];
+        }
       }
+    }
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splits,

@@ -1,7 +1,7 @@
-// Stable LSD radix sort of (uint32 key, uint32 value) pairs, 8 bits per pass, and the
+// Stable LSD radix sort of (uint32 key, uint32 value) pairs, 9 bits per pass, and the
 // (key, src) pair builder of the embedding backward.  Each pass is three launches:
 // per-tile digit histogram -> exclusive scan of the [digit][tile] counts -> stable scatter.
-// Stability inside a tile comes from wave-level peer masks (ballots over the 8 digit bits)
+// Stability inside a tile comes from wave-level peer masks (ballots over the digit bits)
 // plus per-wave running digit counters in LDS, so the result is bitwise reproducible.
 #include "common.h"
 
@@ -9,8 +9,11 @@ namespace ctr {
 
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_WAVES = SORT_THREADS / 64;
-constexpr int SORT_CHUNKS = 16;                      // 64-key chunks per wave
-constexpr int SORT_TILE = SORT_THREADS * SORT_CHUNKS;  // 4096 keys per block
+constexpr int SORT_CHUNKS = 8;                       // 64-key chunks per wave
+constexpr int SORT_TILE = SORT_THREADS * SORT_CHUNKS;  // 2048 keys per block
+constexpr int RBITS = 9;                             // digit width: 26-bit row keys sort in 3 passes
+constexpr int RBINS = 1 << RBITS;
+constexpr int BINS_PER_THREAD = RBINS / SORT_THREADS;
 
 __global__ __launch_bounds__(256) void build_pairs_kernel(
     const int32_t* __restrict__ idx, const int64_t* __restrict__ row_offset, int B, int F, int N,
@@ -39,16 +42,23 @@ __global__ __launch_bounds__(256) void build_pairs_kernel(
 
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(
     const uint32_t* __restrict__ keys, int64_t n, int shift, int nblocks, uint32_t* __restrict__ counts) {
-  __shared__ uint32_t hist[256];
-  hist[threadIdx.x] = 0;
+  __shared__ uint32_t hist[RBINS];
+  for (int d = threadIdx.x; d < RBINS; d += SORT_THREADS) hist[d] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
-  for (int i = threadIdx.x; i < SORT_TILE; i += SORT_THREADS) {
-    const int64_t p = base + i;
-    if (p < n) atomicAdd(&hist[(keys[p] >> shift) & 255u], 1u);
+  uint32_t k[SORT_CHUNKS];
+#pragma unroll
+  for (int c = 0; c < SORT_CHUNKS; ++c) {
+    const int64_t p = base + c * SORT_THREADS + threadIdx.x;
+    k[c] = p < n ? keys[p] : 0u;
+  }
+#pragma unroll
+  for (int c = 0; c < SORT_CHUNKS; ++c) {
+    const int64_t p = base + c * SORT_THREADS + threadIdx.x;
+    if (p < n) atomicAdd(&hist[(k[c] >> shift) & (RBINS - 1)], 1u);
   }
   __syncthreads();
-  counts[(int64_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
+  for (int d = threadIdx.x; d < RBINS; d += SORT_THREADS) counts[(int64_t)d * nblocks + blockIdx.x] = hist[d];
 }
 
 // Block d turns row d of counts[digit][tile] into its exclusive prefix over the tiles and
@@ -59,10 +69,16 @@ __global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t* row = counts + (int64_t)blockIdx.x * nblocks;
   uint32_t carry = 0;
-  for (int base = 0; base < nblocks; base += 256) {
-    const int i = base + threadIdx.x;
-    const uint32_t c = i < nblocks ? row[i] : 0u;
-    uint32_t incl = c;
+  for (int base = 0; base < nblocks; base += 1024) {
+    // four consecutive tiles per thread, then a scan over the threads
+    uint32_t c[4], loc = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + 4 * threadIdx.x + u;
+      c[u] = i < nblocks ? row[i] : 0u;
+      loc += c[u];
+    }
+    uint32_t incl = loc;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const uint32_t v = __shfl_up(incl, o);
@@ -76,7 +92,13 @@ __global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ 
       if (w < wave) woff += wsum[w];
       tot += wsum[w];
     }
-    if (i < nblocks) row[i] = carry + woff + incl - c;
+    uint32_t run = carry + woff + incl - loc;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + 4 * threadIdx.x + u;
+      if (i < nblocks) row[i] = run;
+      run += c[u];
+    }
     carry += tot;
     __syncthreads();
   }
@@ -87,31 +109,14 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t n, int shift,
     int nblocks, const uint32_t* __restrict__ scanned, const uint32_t* __restrict__ totals,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
-  __shared__ uint32_t whist[SORT_WAVES][256];
-  __shared__ uint32_t dbase[256];
-  {  // exclusive prefix of the digit totals (256 values, one per thread)
-    const uint32_t tv = totals[threadIdx.x];
-    uint32_t incl = tv;
-    const int ln = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t v = __shfl_up(incl, o);
-      if (ln >= o) incl += v;
-    }
-    dbase[threadIdx.x] = incl;          // inclusive within the wave for now
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += dbase[w * 64 + 63];
-    __syncthreads();
-    dbase[threadIdx.x] = woff + incl - tv;
-  }
+  __shared__ uint32_t whist[SORT_WAVES][RBINS];
+  __shared__ uint32_t dbase[RBINS];
+  __shared__ uint32_t wtot[SORT_WAVES];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < SORT_WAVES * 256; i += SORT_THREADS) (&whist[0][0])[i] = 0;
-  __syncthreads();
+  // the tile's keys first: their loads overlap the prefix work below
   const int64_t wbase = (int64_t)blockIdx.x * SORT_TILE + (int64_t)wave * SORT_CHUNKS * 64;
   uint32_t key[SORT_CHUNKS], val[SORT_CHUNKS], rank[SORT_CHUNKS];
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
   for (int c = 0; c < SORT_CHUNKS; ++c) {
     const int64_t p = wbase + c * 64 + lane;
@@ -119,14 +124,39 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     key[c] = valid ? keys_in[p] : 0u;
     val[c] = valid ? vals_in[p] : 0u;
   }
+  {  // exclusive prefix of the digit totals; thread t owns digits BINS_PER_THREAD*t ...
+    uint32_t tv[BINS_PER_THREAD], loc = 0;
+#pragma unroll
+    for (int u = 0; u < BINS_PER_THREAD; ++u) {
+      tv[u] = totals[BINS_PER_THREAD * threadIdx.x + u];
+      loc += tv[u];
+    }
+    uint32_t incl = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    for (int i = threadIdx.x; i < SORT_WAVES * RBINS; i += SORT_THREADS) (&whist[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t run = incl - loc;
+    for (int w = 0; w < wave; ++w) run += wtot[w];
+#pragma unroll
+    for (int u = 0; u < BINS_PER_THREAD; ++u) {
+      dbase[BINS_PER_THREAD * threadIdx.x + u] = run;
+      run += tv[u];
+    }
+  }
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
   for (int c = 0; c < SORT_CHUNKS; ++c) {
     const int64_t p = wbase + c * 64 + lane;
     const bool valid = p < n;
-    const uint32_t d = (key[c] >> shift) & 255u;
+    const uint32_t d = (key[c] >> shift) & (RBINS - 1);
     unsigned long long peers = __ballot(valid);
 #pragma unroll
-    for (int bit = 0; bit < 8; ++bit) {
+    for (int bit = 0; bit < RBITS; ++bit) {
       const bool set = (d >> bit) & 1u;
       const unsigned long long m = __ballot(valid && set);
       peers &= set ? m : ~m;
@@ -139,8 +169,8 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     if (valid && in_chunk == 0) whist[wave][d] = prior + (uint32_t)__popcll(peers);
   }
   __syncthreads();
-  {  // per digit: exclusive prefix over the waves + this tile's global base
-    const int d = threadIdx.x;
+  // per digit: exclusive prefix over the waves + this tile's global base
+  for (int d = threadIdx.x; d < RBINS; d += SORT_THREADS) {
     uint32_t run = dbase[d] + scanned[(int64_t)d * nblocks + blockIdx.x];
 #pragma unroll
     for (int w = 0; w < SORT_WAVES; ++w) {
@@ -154,7 +184,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
   for (int c = 0; c < SORT_CHUNKS; ++c) {
     const int64_t p = wbase + c * 64 + lane;
     if (p < n) {
-      const uint32_t d = (key[c] >> shift) & 255u;
+      const uint32_t d = (key[c] >> shift) & (RBINS - 1);
       const uint32_t dst = whist[wave][d] + rank[c];
       keys_out[dst] = key[c];
       vals_out[dst] = val[c];
@@ -175,7 +205,7 @@ struct SortWs {
 
 static size_t sort_ws_bytes(int64_t n) {
   const int64_t nblocks = cdiv(n > 0 ? n : 1, SORT_TILE);
-  return align_up((size_t)n * 4, 256) * 2 + align_up((size_t)nblocks * 256 * 4, 256) + 1024;
+  return align_up((size_t)n * 4, 256) * 2 + align_up((size_t)nblocks * RBINS * 4, 256) + RBINS * 4;
 }
 
 static SortWs carve(void* ws, int64_t n) {
@@ -184,7 +214,7 @@ static SortWs carve(void* ws, int64_t n) {
   w.nblocks = (int)cdiv(n > 0 ? n : 1, SORT_TILE);
   w.keys_tmp = (uint32_t*)p; p += align_up((size_t)n * 4, 256);
   w.vals_tmp = (uint32_t*)p; p += align_up((size_t)n * 4, 256);
-  w.counts = (uint32_t*)p; p += align_up((size_t)w.nblocks * 256 * 4, 256);
+  w.counts = (uint32_t*)p; p += align_up((size_t)w.nblocks * RBINS * 4, 256);
   w.totals = (uint32_t*)p;
   return w;
 }
@@ -194,10 +224,10 @@ static SortWs carve(void* ws, int64_t n) {
 static int run_passes(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, int64_t n, int passes,
                       const SortWs& w, hipStream_t st) {
   for (int p = 0; p < passes; ++p) {
-    const int shift = 8 * p;
+    const int shift = RBITS * p;
     hipLaunchKernelGGL(radix_hist_kernel, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, n, shift,
                        w.nblocks, w.counts);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(256), 0, st, w.counts, w.nblocks, w.totals);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(RBINS), dim3(256), 0, st, w.counts, w.nblocks, w.totals);
     hipLaunchKernelGGL(radix_scatter_kernel, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, va, n,
                        shift, w.nblocks, w.counts, w.totals, kb, vb);
     uint32_t* t;
@@ -228,7 +258,7 @@ extern "C" int ctr_emb_sort(const int32_t* idx, const int64_t* row_offset, int B
   }
   hipStream_t st = (hipStream_t)stream;
   const SortWs w = carve(workspace, n);
-  const int passes = (bits_for((uint64_t)total_rows) + 7) / 8;
+  const int passes = (bits_for((uint64_t)total_rows) + RBITS - 1) / RBITS;
   uint32_t* ka = (passes % 2 == 0) ? keys_out : w.keys_tmp;
   uint32_t* va = (passes % 2 == 0) ? src_out : w.vals_tmp;
   uint32_t* kb = (passes % 2 == 0) ? w.keys_tmp : keys_out;
@@ -253,7 +283,7 @@ extern "C" int ctr_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, 
   }
   hipStream_t st = (hipStream_t)stream;
   const SortWs w = carve(workspace, n);
-  const int passes = (key_bits + 7) / 8;
+  const int passes = (key_bits + RBITS - 1) / RBITS;
   uint32_t* ka = (passes % 2 == 0) ? keys_out : w.keys_tmp;
   uint32_t* va = (passes % 2 == 0) ? vals_out : w.vals_tmp;
   uint32_t* kb = (passes % 2 == 0) ? w.keys_tmp : keys_out;

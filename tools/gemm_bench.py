@@ -8,12 +8,17 @@ from recommendation_amd import ops
 sess = ra.Session('cuda:0')
 ws = sess.ws
 B = 65536
-shapes = [  # (name, M, N, K, ta, tb)
+if len(sys.argv) > 1 and sys.argv[1] == 'ksweep':   # time = a + b*K: fixed cost (prologue + C store) vs per-k-step cost
+    shapes = [('k%d' % k, B, 256, k, 0, 0) for k in (16, 32, 64, 128, 256, 432, 864, 1728)]
+    shapes += [('t%d' % k, B, 256, k, 0, 1) for k in (16, 128, 432)]
+    shapes += [('k%d' % k, B, 256, k, 0, 0) for k in (416, 428, 429, 430, 431, 432, 433, 448)]
+else:
+  shapes = [  # (name, M, N, K, ta, tb)
     ('fwd0', B, 256, 429, 0, 0), ('fwd1', B, 128, 256, 0, 0), ('fwd2', B, 64, 128, 0, 0), ('fwd3', B, 32, 64, 0, 0),
     ('dx0', B, 429, 256, 0, 1), ('dx1', B, 256, 128, 0, 1), ('dx2', B, 128, 64, 0, 1), ('dx3', B, 64, 32, 0, 1),
     ('dw0', 429, 256, B, 1, 0), ('dw1', 256, 128, B, 1, 0), ('dw2', 128, 64, B, 1, 0), ('dw3', 64, 32, B, 1, 0),
     ('sq4k', 4096, 4096, 4096, 0, 0),
-]
+  ]
 for name, M, N, K, ta, tb in shapes:
     def mk(r, c):
         ld = (c + 3) // 4 * 4
@@ -34,6 +39,8 @@ for name, M, N, K, ta, tb in shapes:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     print('%-6s M=%6d N=%5d K=%6d  %8.1f us  %6.1f TF' % (name, M, N, K, us, 2.0 * M * N * K / us / 1e6))
+if len(sys.argv) > 1:
+    sys.exit(0)
 print('--- dense_wgrad')
 for name, M, N, K in [('dw0', 429, 256, B), ('dw1', 256, 128, B), ('dw2', 128, 64, B), ('dw3', 64, 32, B), ('dwo', 74, 1, B)]:
     x = torch.randn(K, (M + 3) // 4 * 4, device='cuda')[:, :M]
