@@ -35,29 +35,37 @@ import torch
 
 # ----------------------------------------------------------------------------
 # Deterministic keep-mask generator shared (bit for bit) with the device code.
-# splitmix64 finalizer over (element index, seed, stream id); 24 random bits
-# compared with floor(keep_prob * 2^24).
+# 32-bit multiply/xorshift finalizer over (element index, seed, stream id); 24 random
+# bits compared with floor(keep_prob * 2^24).
 # ----------------------------------------------------------------------------
-_M1 = np.uint64(0x9E3779B97F4A7C15)
-_M2 = np.uint64(0xBF58476D1CE4E5B9)
-_M3 = np.uint64(0x94D049BB133111EB)
 
 
 def keep_threshold(keep_prob: float) -> int:
     return int(math.floor(float(keep_prob) * float(1 << 24)))
 
 
+def hash24(seed: int, stream: int, index: np.ndarray) -> np.ndarray:
+    """The counter hash shared with the HIP kernels (csrc/common.h hash24), vectorised over index."""
+    m64 = (1 << 64) - 1
+    k = (int(seed) * 0xBF58476D1CE4E5B9 + int(stream) * 0x94D049BB133111EB) & m64
+    k ^= k >> 29
+    k0, k1 = np.uint32(k & 0xFFFFFFFF), np.uint32(k >> 32)
+    with np.errstate(over="ignore"):
+        i = np.asarray(index, dtype=np.uint64)
+        lo = (i & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        hi = (i >> np.uint64(32)).astype(np.uint32)
+        h = (lo ^ k0) * np.uint32(0x9E3779B1)
+        h ^= h >> np.uint32(15)
+        h = (h ^ k1 ^ (hi * np.uint32(0x85EBCA77))) * np.uint32(0x85EBCA6B)
+        h ^= h >> np.uint32(13)
+        h *= np.uint32(0xC2B2AE35)
+        h ^= h >> np.uint32(16)
+    return (h >> np.uint32(8)).astype(np.int64)
+
+
 def keep_mask(seed: int, stream: int, n: int, keep_prob: float) -> np.ndarray:
     """0/1 float32 mask of n elements; element i kept iff hash24(i) < thr."""
-    with np.errstate(over="ignore"):
-        i = np.arange(n, dtype=np.uint64)
-        x = i * _M1 + np.uint64(seed) * _M2 + np.uint64(stream) * _M3
-        x ^= x >> np.uint64(30)
-        x *= _M2
-        x ^= x >> np.uint64(27)
-        x *= _M3
-        x ^= x >> np.uint64(31)
-        u = (x >> np.uint64(40)).astype(np.int64)
+    u = hash24(seed, stream, np.arange(n, dtype=np.uint64))
     return (u < keep_threshold(keep_prob)).astype(np.float32)
 
 

@@ -40,14 +40,21 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // splitmix64-finalizer hash -> 24 random bits. Same function on host and device.
+// 24-bit counter hash of (seed, stream, element index).  The (seed, stream) half is uniform over a
+// launch and folds into scalar registers; per element it is three to four 32-bit multiplies and a
+// few shifts (murmur3-style finaliser), which matters in the GEMM epilogues that drop every output.
 __host__ __device__ static inline uint32_t hash24(uint64_t seed, uint64_t stream_id, uint64_t index) {
-  uint64_t x = index * 0x9E3779B97F4A7C15ull + seed * 0xBF58476D1CE4E5B9ull + stream_id * 0x94D049BB133111EBull;
-  x ^= x >> 30;
-  x *= 0xBF58476D1CE4E5B9ull;
-  x ^= x >> 27;
-  x *= 0x94D049BB133111EBull;
-  x ^= x >> 31;
-  return (uint32_t)(x >> 40);
+  uint64_t k = seed * 0xBF58476D1CE4E5B9ull + stream_id * 0x94D049BB133111EBull;
+  k ^= k >> 29;
+  const uint32_t k0 = (uint32_t)k, k1 = (uint32_t)(k >> 32);
+  const uint32_t lo = (uint32_t)index, hi = (uint32_t)(index >> 32);
+  uint32_t h = (lo ^ k0) * 0x9E3779B1u;
+  h ^= h >> 15;
+  h = (h ^ k1 ^ (hi * 0x85EBCA77u)) * 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h >> 8;
 }
 
 struct Drop {

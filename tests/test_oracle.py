@@ -140,7 +140,15 @@ def test_keep_mask_matches_the_library_hash():
     thr = O.keep_threshold(0.7)
     ref = np.array([lib.ctr_keep_hash24(12345, 7, i) < thr for i in range(200)], dtype=np.float32)
     assert np.array_equal(m, ref)
-    assert abs(O.keep_mask(1, 2, 200000, 0.8).mean() - 0.8) < 5e-3
+    # indices beyond 32 bits and large seeds take the same path on both sides
+    big = np.array([(1 << 32) + 5, (1 << 40) + 12345, (1 << 63) + 1], dtype=np.uint64)
+    assert [int(v) for v in O.hash24(2 ** 60 + 3, 99, big)] == [lib.ctr_keep_hash24(2 ** 60 + 3, 99, int(i)) for i in big]
+    # keep rate, and independence of neighbouring elements / streams (no visible lattice)
+    a = O.keep_mask(1, 2, 200000, 0.8)
+    b = O.keep_mask(1, 3, 200000, 0.8)
+    assert abs(a.mean() - 0.8) < 5e-3 and abs(b.mean() - 0.8) < 5e-3
+    assert abs((a[1:] * a[:-1]).mean() - 0.64) < 5e-3
+    assert abs((a * b).mean() - 0.64) < 5e-3
 
 
 def test_din_attention_masks_padding_and_auc():
