@@ -145,6 +145,11 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(int M, int N, int K, c
   }
 
   const int lr = lane & 31, lk = lane >> 5;
+  // number of this wave's 32-row / 32-column tiles that reach into the matrix
+  const int mrem = M - (m0 + wm * (32 * TM)), nrem = N - (n0 + wn * (32 * TN));
+  const int tm_live = mrem <= 0 ? 0 : (mrem + 31) / 32 < TM ? (mrem + 31) / 32 : TM;
+  const int tn_live = nrem <= 0 ? 0 : (nrem + 31) / 32 < TN ? (nrem + 31) / 32 : TN;
+  const bool whole = tm_live == TM && tn_live == TN;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();  // previous tile fully consumed
     tile_store<A_K, TBM>(As, t, ra);
@@ -159,19 +164,39 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(int M, int N, int K, c
       tile_load<A_K, TBM, false>(A, lda, vecA, m0, M, k0 + BK, kend, t, ra);
       tile_load<B_K, TBN, false>(Bm, ldb, vecB, n0, N, k0 + BK, kend, t, rb);
     }
+    if (whole) {
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      const int k = 2 * kk + lk;
-      float a[TM], b[TN];
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const int k = 2 * kk + lk;
+        float a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[k * SA + wm * (32 * TM) + i * 32 + lr];
+        for (int i = 0; i < TM; ++i) a[i] = As[k * SA + wm * (32 * TM) + i * 32 + lr];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[k * SB + wn * (32 * TN) + j * 32 + lr];
+        for (int j = 0; j < TN; ++j) b[j] = Bs[k * SB + wn * (32 * TN) + j * 32 + lr];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // edge block: 32 x 32 tiles that lie wholly outside the matrix are skipped, which frees their
+      // matrix-core slots for the other blocks resident on the SIMD
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const int k = 2 * kk + lk;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          if (i >= tm_live) break;
+          const float a = As[k * SA + wm * (32 * TM) + i * 32 + lr];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if (j >= tn_live) break;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[k * SB + wn * (32 * TN) + j * 32 + lr], acc[i][j],
+                                                             0, 0, 0);
+          }
+        }
+      }
     }
   }
 
@@ -246,6 +271,132 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(int M, int N, int K, c
         }
       }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Tall-skinny GEMM for the narrow tower layers: C[M,N] = A[M,K] B, M = batch (huge), K <= 256 and a
+// chunk of NC = 16*NT <= 128 output columns per block (grid.y walks the chunks).  Such a layer moves
+// far more bytes than flops: the B chunk (K x NC) sits in LDS for the whole kernel, the A rows stream
+// straight from global memory into MFMA operands (no LDS staging, no barrier in the loop): lane
+// (row l16, k-quad kq) loads A[row][16j + 4kq .. +3] as one float4 and feeds element u to MFMA step u,
+// whose B operand is B[16j + 4kq + u][n].  Persistent waves walk 32-row strips.
+// B_K: B stored [N,K] (k contiguous), else [K,N].
+// ---------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <int NT, bool B_K>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(int M, int N, int K, const float* __restrict__ A,
+                                                         int64_t lda, const float* __restrict__ Bm, int64_t ldb,
+                                                         float* __restrict__ C, int64_t ldc, Epi epi) {
+  extern __shared__ float Ws[];  // [K][SN]
+  constexpr int NC = 16 * NT, SN = NC + 4;
+  const int n0 = blockIdx.y * NC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l16 = lane & 15, kq = lane >> 4;
+  for (int q = threadIdx.x; q < K * NC; q += 256) {
+    int k, c;
+    if (B_K) { c = q / K; k = q % K; } else { k = q / NC; c = q % NC; }
+    const int n = n0 + c;
+    float v = 0.f;
+    if (n < N) v = B_K ? Bm[(int64_t)n * ldb + k] : Bm[(int64_t)k * ldb + n];
+    Ws[k * SN + c] = v;
+  }
+  __syncthreads();
+  const int strips = (M + 31) / 32;
+  const int ksteps = K / 16;
+  constexpr int KC = 2;  // k-steps fetched per batch: 4 float4 loads in flight per lane, 4 more prefetched
+  const int nchunks = (ksteps + KC - 1) / KC;
+  const bool vec_out = (ldc % 4 == 0) && ((uintptr_t)C % 16 == 0);
+  const bool vec_mask = epi.mask_src && (epi.mask_ld % 4 == 0) && ((uintptr_t)epi.mask_src % 16 == 0);
+  for (int strip = blockIdx.x * 4 + wave; strip < strips; strip += gridDim.x * 4) {
+    const int r0 = strip * 32;
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[0][t] = acc[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ra = r0 + l16 < M ? r0 + l16 : M - 1, rb = r0 + 16 + l16 < M ? r0 + 16 + l16 : M - 1;
+    const float* a0p = A + (int64_t)ra * lda + 4 * kq;
+    const float* a1p = A + (int64_t)rb * lda + 4 * kq;
+    float4 cur[KC][2], nxt[KC][2];
+#pragma unroll
+    for (int s4 = 0; s4 < KC; ++s4) {
+      cur[s4][0] = cur[s4][1] = nxt[s4][0] = nxt[s4][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (s4 < ksteps) {
+        cur[s4][0] = *reinterpret_cast<const float4*>(a0p + 16 * s4);
+        cur[s4][1] = *reinterpret_cast<const float4*>(a1p + 16 * s4);
+      }
+    }
+    for (int c = 0; c < nchunks; ++c) {
+      if (c + 1 < nchunks) {
+#pragma unroll
+        for (int s4 = 0; s4 < KC; ++s4) {
+          const int j = (c + 1) * KC + s4;
+          if (j < ksteps) {
+            nxt[s4][0] = *reinterpret_cast<const float4*>(a0p + 16 * j);
+            nxt[s4][1] = *reinterpret_cast<const float4*>(a1p + 16 * j);
+          }
+        }
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < KC; ++s4) {
+        const int j = c * KC + s4;
+        if (j >= ksteps) break;
+        const float av0[4] = {cur[s4][0].x, cur[s4][0].y, cur[s4][0].z, cur[s4][0].w};
+        const float av1[4] = {cur[s4][1].x, cur[s4][1].y, cur[s4][1].z, cur[s4][1].w};
+        const float* wrow = Ws + (16 * j + 4 * kq) * SN + l16;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const float b = wrow[u * SN + 16 * t];
+            // B fragment as the first operand: the accumulator then holds C transposed, four consecutive
+            // columns of one row per lane
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, av0[u], acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, av1[u], acc[1][t], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < KC; ++s4) { cur[s4][0] = nxt[s4][0]; cur[s4][1] = nxt[s4][1]; }
+    }
+    // element r of lane (kq, l16) of tile (rt, t): row r0 + 16 rt + l16, column n0 + 16 t + 4 kq + r
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int m = r0 + 16 * rt + l16;
+      if (m >= M) continue;
+      // relu/dropout-backward masks of the whole row segment first (independent 16-byte loads)
+      float4 mk[NT];
+      if (vec_mask) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int n = n0 + 16 * t + 4 * kq;
+          mk[t] = n + 3 < N ? *reinterpret_cast<const float4*>(epi.mask_src + (int64_t)m * epi.mask_ld + n)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int n = n0 + 16 * t + 4 * kq;
+        if (n >= N) continue;
+        float* cp = C + (int64_t)m * ldc + n;
+        float v[4];
+        if (vec_mask && n + 3 < N && !epi.bias && !epi.accumulate && !epi.relu && !epi.drop.on) {
+          const float mv[4] = {mk[t].x, mk[t].y, mk[t].z, mk[t].w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = mv[r] > 0.f ? acc[rt][t][r] * epi.mask_scale : 0.f;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = n + r < N ? epilogue(epi, acc[rt][t][r], m, n + r, N, cp + r) : 0.f;
+        }
+        if (vec_out && n + 3 < N) {
+          *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < N) cp[r] = v[r];
+        }
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splits,
@@ -498,6 +649,34 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
     e.mask_src = epi->mask_src; e.mask_ld = epi->mask_ld; e.mask_scale = epi->mask_scale;
     CTR_REQUIRE(!e.mask_src || e.mask_ld >= N, "ctr_gemm_f32: mask_ld too small");
   }
+  hipStream_t st = (hipStream_t)stream;
+  // narrow tower layers: the whole B chunk in LDS, A streamed (see skinny_gemm_kernel)
+  if (!trans_a && M >= 4096 && K <= 256 && K % 16 == 0 && N <= 256 && lda % 4 == 0 && ((uintptr_t)A % 16) == 0) {
+    int nc = N <= 32 ? 32 : N <= 64 ? 64 : 128;
+    if ((size_t)K * (nc + 4) * sizeof(float) > 72 * 1024 && nc == 128) nc = 64;
+    const size_t lds = (size_t)K * (nc + 4) * sizeof(float);
+    const int chunks = (int)cdiv(N, nc);
+    if (lds <= 72 * 1024 && chunks == 1 && !trans_b && N <= 64) {
+      const int strips = (int)cdiv(M, 32);
+      int blocks = (int)cdiv(strips, 4);
+      const int cap = 256 * (lds > 40 * 1024 ? 2 : 4) / chunks;  // resident blocks the LDS allows
+      if (blocks > cap) blocks = cap > 0 ? cap : 1;
+      const dim3 sgrid(blocks, chunks), sblock(256);
+#define SK(NT_, BK_)                                                                                        \
+  do {                                                                                                      \
+    if (lds > 64 * 1024)                                                                                    \
+      CTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<NT_, BK_>),             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+    hipLaunchKernelGGL((skinny_gemm_kernel<NT_, BK_>), sgrid, sblock, lds, st, M, N, K, A, lda, B, ldb, C,   \
+                       ldc, e);                                                                             \
+  } while (0)
+      if (trans_b) { if (nc == 32) SK(2, true); else if (nc == 64) SK(4, true); else SK(8, true); }
+      else { if (nc == 32) SK(2, false); else if (nc == 64) SK(4, false); else SK(8, false); }
+#undef SK
+      CTR_LAUNCH_CHECK();
+      return CTR_OK;
+    }
+  }
   const Plan p = make_plan(M, N, K);
   float* partial = nullptr;
   if (p.splits > 1) {
@@ -511,7 +690,6 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
   const bool vecA = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0);
   const bool vecB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
   const dim3 grid(p.tiles_n, p.tiles_m, p.splits), block(256);
-  hipStream_t st = (hipStream_t)stream;
 #define LAUNCH3(AK, BK_, TBM, TBN, WGM)                                                                     \
   hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, TBM, TBN, WGM>), grid, block, 0, st, M, N, K, A, lda, vecA, B, ldb, \
                      vecB, C, ldc, e, p.k_chunk, partial)
