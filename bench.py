@@ -39,6 +39,8 @@ def parse():
                     help='DeepFM is the headline workload; the others time the same step for their family')
     ap.add_argument('--comm', default='rccl', choices=['rccl', 'host-staged'],
                     help='host-staged: gloo through host memory, to rehearse N>1 with all ranks on one GPU')
+    ap.add_argument('--shard', default='table', choices=['table', 'row'],
+                    help='N>1: whole tables per rank, or row r of every table on rank r %% N')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timers', action='store_true')
     return ap.parse_args()
@@ -67,7 +69,7 @@ def build_model(args, sess, cards, rank, world):
                             decay_rate=0.99, mode='S', adam_mode='lazy', init_std=0.01, **MODEL_ARGS[args.model])
     cls = getattr(importlib.import_module('%s.%s' % (name, name)), name)
     if world > 1:
-        margs.world_size, margs.rank = world, rank
+        margs.world_size, margs.rank, margs.shard = world, rank, args.shard
         if args.comm == 'host-staged':
             from recommendation_amd.distributed import HostStagedComm
             margs.comm = HostStagedComm()
@@ -198,7 +200,7 @@ def main():
                                     'embed dim %d, per-GPU batch %d, Zipf(%.2f) ids, fwd+bwd+Adam (sparse rows: '
                                     'row-wise Adam on touched rows), dropout at the reference rates'
                                     % (args.model, shape_name, int(np.sum(cards)), args.embed, B, args.alpha),
-                           global_batch=world * B, parallelism='dp%d' % world if world > 1 else 'single'),
+                           global_batch=world * B, parallelism='dp%d + %s-sharded tables' % (world, args.shard) if world > 1 else 'single'),
                final_loss=loss if np.isfinite(loss) else None)
     if timer is not None:
         ks = timer.summary()

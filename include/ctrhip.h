@@ -322,6 +322,25 @@ int ctr_afm_attn_bwd(const float* z, int64_t z_ld, const float* dx, int B, int N
                      size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Row-wise sharding of the embedding tables over W ranks (new design: the reference is
+ * single-process; the single-device numerics it must reproduce are DeepFM/DeepFM.py:43-53 in
+ * the standard-lookup form of Wide_Deep/Wide_Deep.py:51).  Row r of field f lives on rank
+ * r mod W at local row r / W of that rank's shard of field f.
+ *   ctr_shard_route   per lookup p = b*F + f: dest[p] = owner rank, lkey[p] = row inside the owner's
+ *                     concatenated shard (local_offset[W,F] int32 = first local row of each field on
+ *                     each rank); an id outside [0, V_f) gets key -1 (zero row) on rank f mod W.
+ *   ctr_rows_gather   out[s, 0:E] = src[b, f*E:(f+1)*E], (b, f) = divmod(perm[s], F): packs rows of the
+ *                     strided [B, ld] layout in send order (32-bit words of any type; E = 1 packs ids).
+ *   ctr_rows_scatter  the inverse: dst[b, f*E:(f+1)*E] = rows[s, 0:E].
+ * ---------------------------------------------------------------------------------- */
+int ctr_shard_route(const int32_t* idx, const int64_t* row_offset, const int32_t* local_offset, int B, int F,
+                    int W, uint32_t* dest_out, int32_t* lkey_out, void* stream);
+int ctr_rows_gather(const void* src, int64_t ld, const uint32_t* perm, int64_t n, int F, int E, void* out,
+                    void* stream);
+int ctr_rows_scatter(const void* rows, const uint32_t* perm, int64_t n, int F, int E, void* dst, int64_t ld,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------
  * DIN pieces (DIN/DIN.py:17-71,149-196).  The dense layers of the attention MLP and of the
  * FCN are ctr_gemm_f32 calls over all B*T (resp. B) rows; these are the rest.
  *   ctr_din_build_idx   out[k] = (ids[k], cate_list[ids[k]]) as int32 pairs: with the item and

@@ -80,6 +80,9 @@ SIGNATURES = {
     'ctr_vec_op': (i, [i, vp, vp, vp, i, vp]),
     'ctr_afm_pair_fwd': (i, [vp, i64, i, i, i, DP, vp, vp]),
     'ctr_afm_pair_bwd': (i, [vp, i64, vp, i, i, i, DP, vp, i64, vp]),
+    'ctr_shard_route': (i, [vp, vp, vp, i, i, i, vp, vp, vp]),
+    'ctr_rows_gather': (i, [vp, i64, vp, i64, i, i, vp, vp]),
+    'ctr_rows_scatter': (i, [vp, vp, i64, i, i, vp, i64, vp]),
     'ctr_afm_attn_fwd': (i, [vp, i64, i, i, i, i, vp, vp, vp, DP, vp, vp]),
     'ctr_afm_attn_bwd_workspace_bytes': (sz, [i, i, i]),
     'ctr_afm_attn_bwd': (i, [vp, i64, vp, i, i, i, i, vp, vp, vp, DP, vp, i64, vp, vp, vp, vp, sz, vp]),

@@ -1,0 +1,98 @@
+// Row-wise sharding helpers of the multi-GPU embedding exchange: route every lookup to the rank that
+// owns its table row, and move E-float rows between the strided [B, ld] activation layout and the
+// packed send/receive buffers in the order a stable sort by destination rank produced.
+#include "common.h"
+
+namespace ctr {
+
+// lookup p = b*F + f with id x:  dest = x mod W,  local key = local_offset[dest][f] + x / W
+// (local_offset[j][f] = first row of field f inside rank j's concatenated shard).  An id outside
+// [0, V_f) keeps the zero-row semantics of the single-GPU gather: it goes to rank f mod W with key -1.
+__global__ __launch_bounds__(256) void shard_route_kernel(const int32_t* __restrict__ idx,
+                                                         const int64_t* __restrict__ row_offset,
+                                                         const int32_t* __restrict__ local_offset, int64_t n, int F,
+                                                         int W, uint32_t* __restrict__ dest,
+                                                         int32_t* __restrict__ lkey) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(p % F);
+    const int x = idx[p];
+    const int64_t V = row_offset[f + 1] - row_offset[f];
+    if (x >= 0 && x < V) {
+      const int d = x % W;
+      dest[p] = (uint32_t)d;
+      lkey[p] = local_offset[d * F + f] + x / W;
+    } else {
+      dest[p] = (uint32_t)(f % W);
+      lkey[p] = -1;
+    }
+  }
+}
+
+// out[s, 0:E] = src[b, f*E : (f+1)*E] with (b, f) = divmod(perm[s], F); 32-bit words, any payload
+__global__ __launch_bounds__(256) void rows_gather_kernel(const uint32_t* __restrict__ src, int64_t ld,
+                                                         const uint32_t* __restrict__ perm, int64_t n, int F, int E,
+                                                         uint32_t* __restrict__ out) {
+  const int64_t total = n * E;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = q / E;
+    const int e = (int)(q % E);
+    const uint32_t p = perm[s];
+    out[q] = src[(int64_t)(p / (uint32_t)F) * ld + (int64_t)(p % (uint32_t)F) * E + e];
+  }
+}
+
+// dst[b, f*E : (f+1)*E] = rows[s, 0:E] with (b, f) = divmod(perm[s], F)
+__global__ __launch_bounds__(256) void rows_scatter_kernel(const uint32_t* __restrict__ rows,
+                                                          const uint32_t* __restrict__ perm, int64_t n, int F, int E,
+                                                          uint32_t* __restrict__ dst, int64_t ld) {
+  const int64_t total = n * E;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = q / E;
+    const int e = (int)(q % E);
+    const uint32_t p = perm[s];
+    dst[(int64_t)(p / (uint32_t)F) * ld + (int64_t)(p % (uint32_t)F) * E + e] = rows[q];
+  }
+}
+
+static unsigned grid_of(int64_t total) {
+  const int64_t b = (total + 255) / 256;
+  return (unsigned)(b < 8192 ? (b > 0 ? b : 1) : 8192);
+}
+
+}  // namespace ctr
+
+using namespace ctr;
+
+extern "C" int ctr_shard_route(const int32_t* idx, const int64_t* row_offset, const int32_t* local_offset, int B,
+                               int F, int W, uint32_t* dest_out, int32_t* lkey_out, void* stream) {
+  CTR_REQUIRE(B >= 0 && F >= 0 && W >= 1, "ctr_shard_route: bad size");
+  const int64_t n = (int64_t)B * F;
+  if (n == 0) return CTR_OK;
+  CTR_REQUIRE(idx && row_offset && local_offset && dest_out && lkey_out, "ctr_shard_route: null pointer");
+  hipLaunchKernelGGL(shard_route_kernel, dim3(grid_of(n)), dim3(256), 0, (hipStream_t)stream, idx, row_offset,
+                     local_offset, n, F, W, dest_out, lkey_out);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_rows_gather(const void* src, int64_t ld, const uint32_t* perm, int64_t n, int F, int E, void* out,
+                               void* stream) {
+  CTR_REQUIRE(n >= 0 && F >= 1 && E >= 1 && ld >= (int64_t)F * E, "ctr_rows_gather: bad size / ld");
+  if (n == 0) return CTR_OK;
+  CTR_REQUIRE(src && perm && out, "ctr_rows_gather: null pointer");
+  hipLaunchKernelGGL(rows_gather_kernel, dim3(grid_of(n * E)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint32_t*)src, ld, perm, n, F, E, (uint32_t*)out);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_rows_scatter(const void* rows, const uint32_t* perm, int64_t n, int F, int E, void* dst, int64_t ld,
+                                void* stream) {
+  CTR_REQUIRE(n >= 0 && F >= 1 && E >= 1 && ld >= (int64_t)F * E, "ctr_rows_scatter: bad size / ld");
+  if (n == 0) return CTR_OK;
+  CTR_REQUIRE(rows && perm && dst, "ctr_rows_scatter: null pointer");
+  hipLaunchKernelGGL(rows_scatter_kernel, dim3(grid_of(n * E)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint32_t*)rows, perm, n, F, E, (uint32_t*)dst, ld);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}

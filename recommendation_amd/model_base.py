@@ -84,6 +84,10 @@ class CTRModel:
         self.world = int(getattr(args, 'world_size', 1))
         self.rank = int(getattr(args, 'rank', 0))
         self.comm = getattr(args, 'comm', None)
+        # 'table': a field's whole table on one rank; 'row': row r of every field on rank r % world
+        self.shard = getattr(args, 'shard', 'table')
+        if self.shard not in ('table', 'row'):
+            raise ValueError("shard must be 'table' or 'row'")
         if self.world > 1 and self.mode != 'S':
             raise ValueError("multi-GPU runs use mode 'S' (the dense R-mode block exists only at parity sizes)")
         self.global_step = 0
@@ -124,12 +128,13 @@ class CTRModel:
         self.session = session
         self.dense = DenseParams(self.dense_shapes, dev)
         if self.world > 1:
-            from .distributed import ShardedFront, TorchComm
+            from .distributed import RowShardedFront, ShardedFront, TorchComm
             if self.comm is None:
                 self.comm = TorchComm()
-            self.front = ShardedFront(self.cate_list, self.embed_size, self.cont_num, self.CONT_EMBED, self.comm, dev)
+            cls = RowShardedFront if self.shard == 'row' else ShardedFront
+            self.front = cls(self.cate_list, self.embed_size, self.cont_num, self.CONT_EMBED, self.comm, dev)
             self.tables = self.front.t                      # this rank's shard
-            self._own = (self.front.a, self.front.b)
+            self._own = (0, self.cate_num) if self.shard == 'row' else (self.front.a, self.front.b)
         else:
             self.tables = EmbeddingTables(self.cate_list, self.embed_size, dev)
             self.front = EmbedFront(self.tables, self.mode, self.cont_num, self.CONT_EMBED)
@@ -167,7 +172,11 @@ class CTRModel:
             t = torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32))
             if k.startswith('embedding/embed_cate_w_'):
                 f = int(k.rsplit('_', 1)[1])
-                if self._own[0] <= f < self._own[1]:
+                if self.world > 1 and self.shard == 'row':
+                    if t.shape[0] == self.cate_list[f]:     # a full table: keep this rank's rows
+                        t = t[self.rank::self.world]
+                    self.tables.table(f).copy_(t)
+                elif self._own[0] <= f < self._own[1]:
                     self.tables.table(f - self._own[0]).copy_(t)
             else:
                 self.dense.p(k).copy_(t.reshape(self.dense.shapes[k]))

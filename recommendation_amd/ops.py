@@ -98,11 +98,11 @@ def _ptr(t, dtype=None, name='tensor'):
     return C.c_void_p(t.data_ptr())
 
 
-def _rows(t, name):
+def _rows(t, name, dtype=torch.float32):
     """(pointer, leading dimension) of a 2-D view whose last dim is contiguous."""
     if t.dim() != 2 or t.stride(1) != 1:
         raise ValueError('%s must be 2-D with a contiguous last dimension' % name)
-    return _ptr(t, torch.float32, name), int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), t.shape[1])
+    return _ptr(t, dtype, name), int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), t.shape[1])
 
 
 def make_dropout(rate, seed, stream_id):
@@ -252,6 +252,43 @@ def sort_pairs(keys, vals, key_bits, ws):
     check(lib().ctr_sort_pairs(_ptr(keys), _ptr(vals), n, int(key_bits), _ptr(ko), _ptr(vo), wp, wn, _stream()),
           'ctr_sort_pairs')
     return ko, vo
+
+
+@_timed
+def shard_route(idx, row_offset, local_offset, W, dest_out, lkey_out):
+    B, F = idx.shape
+    if idx.dtype != torch.int32 or local_offset.dtype != torch.int32 or tuple(local_offset.shape) != (W, F):
+        raise TypeError('shard_route wants int32 idx [B,F] and int32 local_offset [W,F]')
+    if dest_out.numel() < B * F or lkey_out.numel() < B * F or dest_out.dtype != torch.int32 or lkey_out.dtype != torch.int32:
+        raise ValueError('shard_route outputs must be int32 with B*F elements')
+    check(lib().ctr_shard_route(_ptr(idx), _ptr(row_offset, torch.int64), _ptr(local_offset), B, F, int(W),
+                                _ptr(dest_out), _ptr(lkey_out), _stream()), 'ctr_shard_route')
+
+
+def _words(t):
+    if t.element_size() != 4:
+        raise TypeError('rows_gather / rows_scatter move 32-bit words')
+    return t
+
+
+@_timed
+def rows_gather(src, perm, n, out, *, F, E):
+    """out[s, :E] = src[b, f*E:(f+1)*E] with (b, f) = divmod(perm[s], F)."""
+    sp, ld = _rows(_words(src), 'src', dtype=None)
+    if perm.dtype != torch.int32 or perm.numel() < n or out.numel() < n * E or not out.is_contiguous():
+        raise ValueError('rows_gather: perm must be int32 [n], out contiguous with n*E words')
+    check(lib().ctr_rows_gather(sp, ld, _ptr(perm), int(n), int(F), int(E), _ptr(_words(out)), _stream()),
+          'ctr_rows_gather')
+
+
+@_timed
+def rows_scatter(rows, perm, n, dst, *, F, E):
+    """dst[b, f*E:(f+1)*E] = rows[s, :E] with (b, f) = divmod(perm[s], F)."""
+    dp, ld = _rows(_words(dst), 'dst', dtype=None)
+    if perm.dtype != torch.int32 or perm.numel() < n or rows.numel() < n * E or not rows.is_contiguous():
+        raise ValueError('rows_scatter: perm must be int32 [n], rows contiguous with n*E words')
+    check(lib().ctr_rows_scatter(_ptr(_words(rows)), _ptr(perm), int(n), int(F), int(E), dp, ld, _stream()),
+          'ctr_rows_scatter')
 
 
 def make_opt(kind, lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8):

@@ -31,7 +31,7 @@ class StagedComm:
         t.copy_(c)
 
 
-def main(model_name):
+def main(model_name, shard='table'):
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     import recommendation_amd as ra
@@ -60,7 +60,7 @@ def main(model_name):
     sess = ra.Session('cuda:0', seed=3)
     import copy
     dcfg = copy.copy(cfg)
-    dcfg.world_size, dcfg.rank, dcfg.comm = world, rank, StagedComm()
+    dcfg.world_size, dcfg.rank, dcfg.comm, dcfg.shard = world, rank, StagedComm(), shard
     m = cls(dcfg, 5, 3, cfg.cate_list)
     m.build()
     m.initialize(sess, params=P)
@@ -76,14 +76,18 @@ def main(model_name):
     got = m.get_params()
     n_tab = 0
     for k, v in got.items():
-        assert rel_err(v, ref[k]) < 2e-5, (rank, k, rel_err(v, ref[k]))
+        want = ref[k]
+        if shard == 'row' and k.startswith('embedding/embed_cate_w_'):
+            want = want[rank::world]                       # this rank holds rows r with r % world == rank
+        assert v.shape == want.shape, (rank, k, v.shape, want.shape)
+        assert rel_err(v, want) < 2e-5, (rank, k, rel_err(v, want))
         n_tab += k.startswith('embedding/embed_cate_w_')
-    assert n_tab == m.front.nf_own
+    assert n_tab == (5 if shard == 'row' else m.front.nf_own)
     dist.barrier()
     if rank == 0:
-        print('DIST_OK %s' % model_name)
+        print('DIST_OK %s %s' % (model_name, shard))
     dist.destroy_process_group()
 
 
 if __name__ == '__main__':
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else 'table')

@@ -35,6 +35,37 @@ class TorchBackend:
             rows = tables[off + torch.where(ok, x, torch.zeros_like(x))] * ok.float().view(-1, 1)
             z_out[:, f * E:(f + 1) * E] = rows
 
+    class Workspace:
+        def __init__(self, device):
+            self.device = device
+
+    def shard_route(self, idx, row_offset, local_offset, W, dest_out, lkey_out):
+        B, F = idx.shape
+        x = idx.long()
+        V = (row_offset[1:] - row_offset[:-1]).view(1, F)
+        ok = (x >= 0) & (x < V)
+        d = torch.where(ok, x % W, torch.arange(F).view(1, F).expand(B, F) % W)
+        key = torch.where(ok, local_offset.long()[d, torch.arange(F).view(1, F).expand(B, F)] + x // W,
+                          torch.full_like(x, -1))
+        dest_out[:B * F] = d.reshape(-1).int()
+        lkey_out[:B * F] = key.reshape(-1).int()
+
+    def sort_pairs(self, keys, vals, key_bits, ws):
+        order = torch.sort(keys.long(), stable=True).indices
+        return keys[order], vals[order]
+
+    def rows_gather(self, src, perm, n, out, *, F, E):
+        p = perm[:n].long()
+        flat = out.view(-1)
+        for e in range(E):
+            flat[torch.arange(n) * E + e] = src[p // F, (p % F) * E + e]
+
+    def rows_scatter(self, rows, perm, n, dst, *, F, E):
+        p = perm[:n].long()
+        r = rows.reshape(-1, E)
+        for e in range(E):
+            dst[p // F, (p % F) * E + e] = r[:n, e]
+
     def copy2d(self, src, dst, accumulate=False):
         dst[:, :src.shape[1]] = src
 
@@ -49,7 +80,8 @@ class TorchBackend:
         idx = self._idx
         for f in range(idx.shape[1]):
             off = int(self._off[f])
-            tables.index_add_(0, off + idx[:, f].long(), -opt.lr * dz[:, f * E:(f + 1) * E])
+            ok = idx[:, f] >= 0
+            tables.index_add_(0, off + idx[ok, f].long(), -opt.lr * dz[ok, f * E:(f + 1) * E])
 
 
 def p2p_all_to_all(out, inp, out_splits, in_splits, rank, world):
@@ -111,6 +143,58 @@ def _worker(rank, world, port, ret):
         assert torch.allclose(got, exp, atol=1e-6), (rank, f)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _row_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from recommendation_amd.distributed import RowShardedFront, row_shard_layout
+
+    class Comm:
+        def __init__(self):
+            self.world, self.rank = world, rank
+
+        def all_to_all(self, out, inp, out_splits, in_splits):
+            p2p_all_to_all(out, inp, out_splits, in_splits, rank, world)
+
+    cards, E, C, B = [5, 9, 1, 7, 3], 4, 2, 6               # field 2 has one row: rank 1 owns none of it
+    rng = np.random.default_rng(0)
+    full = [torch.tensor(rng.standard_normal((v, E)), dtype=torch.float32) for v in cards]
+    front = RowShardedFront(cards, E, C, False, Comm(), torch.device('cpu'), backend=TorchBackend())
+    loc_cards, _ = row_shard_layout(cards, world)
+    assert [sum(c[f] for c in loc_cards) for f in range(5)] == cards
+    for f in range(5):
+        assert list(front.local_rows(f)) == list(range(rank, cards[f], world))
+        front.t.table(f).copy_(full[f][rank::world])
+    r2 = np.random.default_rng(100 + rank)
+    idx = torch.tensor(np.stack([r2.integers(0, v, B) for v in cards], 1), dtype=torch.int32)
+    idx[0, 1] = 99                                           # out of range: zero row, no update
+    xc = torch.tensor(r2.standard_normal((B, C)), dtype=torch.float32)
+    z = torch.zeros(B, len(cards) * E + C)
+    front.forward(idx, xc, z_out=z, cont_tail=True)
+    safe = idx.clone()
+    safe[0, 1] = 0
+    ref = torch.cat([full[f][safe[:, f].long()] for f in range(5)] + [xc], dim=1)
+    ref[0, E:2 * E] = 0
+    assert torch.equal(z, ref)
+    dz = torch.tensor(r2.standard_normal((B, len(cards) * E)), dtype=torch.float32)
+    front.backward_tables(idx, dz, None, None, None, TorchBackend._Opt(3, lr=0.5), lazy=True)
+    all_idx = [torch.zeros_like(idx) for _ in range(world)]
+    all_dz = [torch.zeros_like(dz) for _ in range(world)]
+    dist.all_gather(all_idx, idx)
+    dist.all_gather(all_dz, dz)
+    for f in range(5):
+        exp = full[f].clone()
+        for i2, d2 in zip(all_idx, all_dz):
+            ok = i2[:, f] < cards[f]
+            exp.index_add_(0, i2[ok, f].long(), -0.5 * d2[ok, f * E:(f + 1) * E])
+        assert torch.allclose(front.t.table(f), exp[rank::world], atol=1e-6), (rank, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_front_plan_world2():
+    mp.spawn(_row_worker, args=(2, 29743, None), nprocs=2, join=True)
 
 
 def test_sharded_front_plan_world2():
