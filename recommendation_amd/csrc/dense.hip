@@ -20,7 +20,18 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   float acc = 0.f;
   if (j < K) {
     const int wj = w ? j / w_group : 0;
-    for (int64_t r = r0 + ty; r < r1; r += 4) {
+    int64_t r = r0 + ty;
+    for (; r + 12 < r1; r += 16) {   // four independent row loads in flight, added in row order
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = X[(r + 4 * u) * ld + j];
+        if (w) v[u] *= w[(r + 4 * u) * w_ld + wj];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc += v[u];
+    }
+    for (; r < r1; r += 4) {
       float v = X[r * ld + j];
       if (w) v *= w[r * w_ld + wj];
       acc += v;
@@ -38,8 +49,17 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + tx;
   float acc = 0.f;
-  if (j < K)
-    for (int c = ty; c < nchunks; c += 4) acc += part[(int64_t)c * K + j];
+  if (j < K) {
+    int c = ty;
+    for (; c + 12 < nchunks; c += 16) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = part[(int64_t)(c + 4 * u) * K + j];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc += v[u];
+    }
+    for (; c < nchunks; c += 4) acc += part[(int64_t)c * K + j];
+  }
   red[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && j < K) {
@@ -215,7 +235,7 @@ static unsigned grid_for(int64_t total) {
 static int cs_chunks(int B) {
   int64_t n = cdiv(B, CS_ROWS);
   if (n < 1) n = 1;
-  if (n > 128) n = 128;
+  if (n > 1024) n = 1024;
   return (int)n;
 }
 

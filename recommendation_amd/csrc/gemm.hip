@@ -715,8 +715,8 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
   return CTR_OK;
 }
 
-// Stream path is used when the output is small next to K: M*N <= 8192, N <= 128, K >= 2048.
-static bool wgrad_streams(int M, int N, int K) { return (int64_t)M * N <= 8192 && N <= 128 && K >= 2048; }
+// Stream path is used when the output is small next to K: M*N <= 16384, N <= 128, K >= 2048.
+static bool wgrad_streams(int M, int N, int K) { return (int64_t)M * N <= 16384 && N <= 128 && K >= 2048; }
 
 extern "C" size_t ctr_dense_wgrad_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;

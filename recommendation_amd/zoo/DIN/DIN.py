@@ -214,7 +214,15 @@ class DIN(object):
         i = self._dev_i32(uij[1])
         hist = self._dev_i32(uij[3])
         sl = self._dev_i32(uij[4])
-        y = torch.as_tensor(np.asarray(uij[2], dtype=np.float32)).to(sess.device)
+        y = uij[2]
+        if not (isinstance(y, torch.Tensor) and y.is_cuda):
+            y = torch.as_tensor(np.asarray(y, dtype=np.float32)).to(sess.device)
+        return np.float32(self.train_step(i, y.to(torch.float32), hist, sl, l).item())
+
+    def train_step(self, i, y, hist, sl, l):
+        """The same step on device tensors (int32 ids / lengths, float32 labels); returns the device
+        scalar loss without a host sync."""
+        sess = self.session
         B, T = hist.shape
         if i.numel() != B or sl.numel() != B or y.numel() != B:
             raise ValueError('DIN.train: batch sizes disagree')
@@ -234,21 +242,18 @@ class DIN(object):
         ops.dense_wgrad(b['a2'], dl.view(B, 1), d.g('fcn/f3/kernel'), d.g('fcn/f3/bias'), ws=ws)
         ops.dice_bwd(b['f2'], d.p('fcn/alphadice_2_i'), b['da2'], b['df2'], b['t40'], BN_EPS)
         ops.colsum(b['t40'], d.g('fcn/alphadice_2_i'), ws=ws)
-        ops.gemm(b['a1'], b['df2'], d.g('fcn/f2/kernel'), trans_a=True, ws=ws)
-        ops.colsum(b['df2'], d.g('fcn/f2/bias'), ws=ws)
+        ops.dense_wgrad(b['a1'], b['df2'], d.g('fcn/f2/kernel'), d.g('fcn/f2/bias'), ws=ws)
         ops.gemm(b['df2'], d.p('fcn/f2/kernel'), b['da1'], trans_b=True, ws=ws)
         ops.dice_bwd(b['f1'], d.p('fcn/alphadice_1_i'), b['da1'], b['df1'], b['t80'], BN_EPS)
         ops.colsum(b['t80'], d.g('fcn/alphadice_1_i'), ws=ws)
-        ops.gemm(b['din_bn'], b['df1'], d.g('fcn/f1/kernel'), trans_a=True, ws=ws)
-        ops.colsum(b['df1'], d.g('fcn/f1/bias'), ws=ws)
+        ops.dense_wgrad(b['din_bn'], b['df1'], d.g('fcn/f1/kernel'), d.g('fcn/f1/bias'), ws=ws)
         ops.gemm(b['df1'], d.p('fcn/f1/kernel'), b['ddin_bn'], trans_b=True, ws=ws)
         ops.colsum(b['ddin_bn'], d.g('fcn/b1/gamma'), w=b['xhat2'], w_group=1, ws=ws)
         ops.colsum(b['ddin_bn'], d.g('fcn/b1/beta'), ws=ws)
         ops.bn_infer(b['ddin_bn'], b['ddin'], gamma=d.p('fcn/b1/gamma'), var=d.p('fcn/b1/moving_variance'), eps=BN_EPS)
         # backward: dense H, batch norm, attention pooling
         du = b['ddin'][:, :H]
-        ops.gemm(b['hist_bn'], du, d.g('embedding/dense/kernel'), trans_a=True, ws=ws)
-        ops.colsum(du, d.g('embedding/dense/bias'), ws=ws)
+        ops.dense_wgrad(b['hist_bn'], du, d.g('embedding/dense/kernel'), d.g('embedding/dense/bias'), ws=ws)
         ops.gemm(du, d.p('embedding/dense/kernel'), b['dhist_bn'], trans_b=True, ws=ws)
         p = 'embedding/batch_normalization/'
         ops.colsum(b['dhist_bn'], d.g(p + 'gamma'), w=b['xhat1'], w_group=1, ws=ws)
@@ -262,12 +267,10 @@ class DIN(object):
         ops.rowdot_bwd_x(ds, d.p('embedding/f3_att/kernel').reshape(-1), b['g2'])
         ops.dense_wgrad(b['d2'], ds.view(B * T, 1), d.g('embedding/f3_att/kernel'), d.g('embedding/f3_att/bias'), ws=ws)
         ops.dsigmoid_apply(b['g2'], b['d2'])
-        ops.gemm(b['d1'], b['g2'], d.g('embedding/f2_att/kernel'), trans_a=True, ws=ws)
-        ops.colsum(b['g2'], d.g('embedding/f2_att/bias'), ws=ws)
+        ops.dense_wgrad(b['d1'], b['g2'], d.g('embedding/f2_att/kernel'), d.g('embedding/f2_att/bias'), ws=ws)
         ops.gemm(b['g2'], d.p('embedding/f2_att/kernel'), b['g1'], trans_b=True, ws=ws)
         ops.dsigmoid_apply(b['g1'], b['d1'])
-        ops.gemm(b['din_all'], b['g1'], d.g('embedding/f1_att/kernel'), trans_a=True, ws=ws)
-        ops.colsum(b['g1'], d.g('embedding/f1_att/bias'), ws=ws)
+        ops.dense_wgrad(b['din_all'], b['g1'], d.g('embedding/f1_att/kernel'), d.g('embedding/f1_att/bias'), ws=ws)
         ops.gemm(b['g1'], d.p('embedding/f1_att/kernel'), b['din_all'], trans_b=True, ws=ws)   # d(din_all), in place
         ops.din_concat_bwd(b['din_all'], i_emb, h_emb, dq, dk, B=B, T=T, H=H, acc_q=False, acc_k=True)
         ops.copy2d(b['ddin'][:, H:], dq, accumulate=True)                                # i_emb also feeds the FCN
@@ -287,7 +290,7 @@ class DIN(object):
                              tables=bt.weight, ws=ws)
         # dense variables (the reference never passes global_step to minimize(): it stays 0, DIN/DIN.py:110)
         self.dense.apply(sgd)
-        return np.float32(self._loss_dev.item())
+        return self._loss_dev
 
     def eval(self, sess, uij):
         """uij = (u, i, j, hist_i, sl) -> (mf_auc, p_and_n[B,2]) (DIN/DIN.py:91-97,123-131)."""
