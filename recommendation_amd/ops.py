@@ -62,15 +62,8 @@ def _timed(fn):
 
     @functools.wraps(fn)
     def wrap(*a, **k):
-        if _TIMER is None or (_TIMER.only is not None and fn.__name__ not in _TIMER.only):
+        if _TIMER is None:
             return fn(*a, **k)
-        ev = _TIMER.pair()
-        if ev is None:
-            return fn(*a, **k)
-        e0, e1 = ev
-        e0.record()
-        r = fn(*a, **k)
-        e1.record()
         name = fn.__name__
         if name == 'gemm':                      # one bucket per GEMM shape
             A, Cout = a[0], a[2]
@@ -79,6 +72,15 @@ def _timed(fn):
                                             'T' if ta else 'N', 'T' if k.get('trans_b', False) else 'N')
         elif name == 'dense_wgrad':             # and per weight-gradient shape (M x N x K)
             name = 'wgrad_%dx%dx%d' % (a[0].shape[1], a[1].shape[1], a[0].shape[0])
+        if _TIMER.only is not None and name not in _TIMER.only and fn.__name__ not in _TIMER.only:
+            return fn(*a, **k)
+        ev = _TIMER.pair()
+        if ev is None:
+            return fn(*a, **k)
+        e0, e1 = ev
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
         _TIMER.records.append((name, e0, e1))
         return r
     return wrap
