@@ -180,6 +180,15 @@ typedef struct {
   float mask_scale;
 } ctr_epilogue_t;
 
+/* Arithmetic of the tiled GEMM (process-wide; default CTR_GEMM_SPLIT_BF16):
+ *   CTR_GEMM_FP32_MFMA   v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain.
+ *   CTR_GEMM_SPLIT_BF16  every fp32 operand split exactly into three bf16 terms and the product
+ *                        accumulated in fp32 from six bf16 MFMAs: fp32-level accuracy (~1e-7
+ *                        relative, different rounding order) at 2.7x the matrix-core rate. */
+#define CTR_GEMM_FP32_MFMA 0
+#define CTR_GEMM_SPLIT_BF16 1
+int ctr_set_gemm_mode(int mode);
+int ctr_get_gemm_mode(void);
 size_t ctr_gemm_f32_workspace_bytes(int M, int N, int K);
 int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K,
                  const float* A, int64_t lda, const float* B, int64_t ldb,

@@ -80,6 +80,8 @@ SIGNATURES = {
     'ctr_vec_op': (i, [i, vp, vp, vp, i, vp]),
     'ctr_afm_pair_fwd': (i, [vp, i64, i, i, i, DP, vp, vp]),
     'ctr_afm_pair_bwd': (i, [vp, i64, vp, i, i, i, DP, vp, i64, vp]),
+    'ctr_set_gemm_mode': (i, [i]),
+    'ctr_get_gemm_mode': (i, []),
     'ctr_shard_route': (i, [vp, vp, vp, i, i, i, vp, vp, vp]),
     'ctr_rows_gather': (i, [vp, i64, vp, i64, i, i, vp, vp]),
     'ctr_rows_scatter': (i, [vp, vp, i64, i, i, vp, i64, vp]),

@@ -6,6 +6,7 @@
 // (weight gradients) are split along K into fixed-order partial slabs, reduced by a second
 // kernel: no atomics, bitwise reproducible.
 #include "common.h"
+#include <type_traits>
 
 namespace ctr {
 
@@ -100,6 +101,87 @@ __device__ static inline void tile_store(float* __restrict__ S, int t, const flo
       }
     }
   }
+}
+
+// Epilogue shared by the tiled kernels.  C/D layout of the 32x32 MFMA: col = lane & 31,
+// row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).  Each 32 x 32 tile goes through a per-wave LDS tile and
+// leaves as 16-byte stores (8 rows x 128 bytes per wave instruction): a quarter of the store
+// instructions of the register layout.  smem must hold 4 * 32 * 36 floats and no longer be in use.
+template <int TM, int TN>
+__device__ static inline void tile_epilogue(f32x16 (&acc)[TM][TN], float* smem, int M, int N, int m0, int n0, int wm,
+                                            int wn, float* __restrict__ C, int64_t ldc, const Epi& epi,
+                                            float* __restrict__ partial) {
+  constexpr int CS = 36;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 31, lk = lane >> 5;
+  __syncthreads();  // every wave is done with As / Bs
+  float* S = smem + wave * (32 * CS);
+  float* out = partial ? partial + (int64_t)blockIdx.z * M * N : C;
+  const int64_t ldo = partial ? N : ldc;
+  const bool vec_out = (ldo % 4 == 0) && ((uintptr_t)out % 16 == 0);
+  const bool vec_mask = epi.mask_src && (epi.mask_ld % 4 == 0) && ((uintptr_t)epi.mask_src % 16 == 0);
+  const int srow = lane >> 3, sc4 = (lane & 7) * 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * lk) * CS + lr] = acc[i][j][r];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + srow;
+        const float4 v4 = *reinterpret_cast<const float4*>(&S[row * CS + sc4]);
+        const int m = m0 + wm * (32 * TM) + i * 32 + row;
+        const int n = n0 + wn * (32 * TN) + j * 32 + sc4;
+        if (m >= M || n >= N) continue;
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        float* cp = out + (int64_t)m * ldo + n;
+        const bool full = n + 3 < N;
+        if (!partial) {
+          float cold[4] = {0.f, 0.f, 0.f, 0.f}, mk[4] = {1.f, 1.f, 1.f, 1.f};
+          if (epi.accumulate) {
+            if (full && vec_out) {
+              const float4 c4 = *reinterpret_cast<const float4*>(cp);
+              cold[0] = c4.x; cold[1] = c4.y; cold[2] = c4.z; cold[3] = c4.w;
+            } else {
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                if (n + u < N) cold[u] = cp[u];
+            }
+          }
+          if (epi.mask_src) {
+            const float* mp = epi.mask_src + (int64_t)m * epi.mask_ld + n;
+            if (full && vec_mask) {
+              const float4 m4 = *reinterpret_cast<const float4*>(mp);
+              mk[0] = m4.x; mk[1] = m4.y; mk[2] = m4.z; mk[3] = m4.w;
+            } else {
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                if (n + u < N) mk[u] = mp[u];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (n + u >= N) break;
+            float x = v[u];
+            if (epi.bias) x += epi.bias[n + u];
+            if (epi.accumulate) x += cold[u];
+            if (epi.relu == 1) x = fmaxf(x, 0.f);
+            else if (epi.relu == 2) x = 1.f / (1.f + expf(-x));
+            if (epi.drop.on) x *= drop_mul(epi.drop, (uint64_t)m * (uint64_t)N + (uint64_t)(n + u));
+            if (epi.mask_src) x = mk[u] > 0.f ? x * epi.mask_scale : 0.f;
+            v[u] = x;
+          }
+        }
+        if (full && vec_out) {
+          *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (n + u < N) cp[u] = v[u];
+        }
+      }
+    }
 }
 
 // A_K: A stored [M,K] (k contiguous).  B_K: B stored [N,K] (k contiguous).
@@ -200,77 +282,240 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(int M, int N, int K, c
     }
   }
 
-  // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
-  // Each 32 x 32 tile goes through a per-wave LDS tile and leaves as 16-byte stores (8 rows x 128 bytes per
-  // wave instruction): a quarter of the store instructions of the register layout.
-  __syncthreads();  // every wave is done with As / Bs
-  float* S = smem + wave * (32 * CS);
-  float* out = partial ? partial + (int64_t)blockIdx.z * M * N : C;
-  const int64_t ldo = partial ? N : ldc;
-  const bool vec_out = (ldo % 4 == 0) && ((uintptr_t)out % 16 == 0);
-  const bool vec_mask = epi.mask_src && (epi.mask_ld % 4 == 0) && ((uintptr_t)epi.mask_src % 16 == 0);
-  const int srow = lane >> 3, sc4 = (lane & 7) * 4;
+  tile_epilogue<TM, TN>(acc, smem, M, N, m0, n0, wm, wn, C, ldc, epi, partial);
+}
+
+// ---------------------------------------------------------------------------------------
+// The same tiled GEMM on the bf16 matrix cores with fp32-level accuracy.  Every fp32 operand is
+// split exactly into three bf16 terms x = hi + mid + lo (8 + 8 + 8 significant bits), and the
+// product is accumulated from the six term pairs of order <= 2^-16:
+//   hi*hi + hi*mid + mid*hi + hi*lo + mid*mid + lo*hi           (dropped pairs are <= 2^-25 relative)
+// Each bf16 x bf16 product is exact in fp32 and the MFMA accumulates in fp32, so the result differs
+// from an fp32 FMA chain only in rounding order (~1e-7 relative), while six 32x32x16 bf16 MFMAs cost
+// 192 matrix-core cycles per 16 values of k against 512 for eight 32x32x2 fp32 MFMAs.
+// The split happens once, on the way from global memory into LDS; LDS holds three bf16 planes per
+// operand, k-contiguous with a 48-byte row stride (conflict-free 16-byte fragment reads).
+// A non-finite input turns into NaN (inf - inf in the split).
+// ---------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int SK = 16;    // k per stage = one bf16 MFMA step
+constexpr int SROW = SK + 8;  // bf16 elements per LDS row: 48- or 80-byte stride, conflict-free 16-byte reads
+constexpr int SKG = SK / 8;   // groups of 8 k per row
+
+// eight consecutive-k elements (k0 .. k0+7) of row r; KCONTIG: element (r, k) at P[r*ld + k], else P[k*ld + r].
+// FAST (whole stage inside K, vector loads allowed): no bound checks at all; a row past the end is
+// clamped to the last row, whose products only reach output rows that are never stored.
+template <bool KCONTIG, bool FAST>
+__device__ static inline void split_load8(const float* __restrict__ P, int64_t ld, bool vec, int r, int rmax, int k0,
+                                          int kend, float (&v)[8]) {
+  if (FAST) {
+    const int rc = r < rmax ? r : rmax - 1;
+    if (KCONTIG) {
+      const float* p = P + (int64_t)rc * ld + k0;
+      const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+      const float* p = P + (int64_t)k0 * ld + rc;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = p[(int64_t)j * ld];
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  if (r >= rmax || k0 >= kend) return;
+  const float* p = KCONTIG ? P + (int64_t)r * ld + k0 : P + (int64_t)k0 * ld + r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (k0 + j < kend) v[j] = KCONTIG ? p[j] : p[(int64_t)j * ld];
+}
+
+// S: three planes [3][R][SROW] of bf16; writes the hi / mid / lo terms of v at (row, 8*kg .. 8*kg+7)
+__device__ static inline void split_store8(__bf16* __restrict__ S, int R, int row, int kg, const float (&v)[8]) {
+  bf16x8 hi, mid, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)v[j];
+    const float r1 = v[j] - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    hi[j] = h; mid[j] = m; lo[j] = (__bf16)r2;
+  }
+  __bf16* p = S + row * SROW + kg * 8;
+  *reinterpret_cast<bf16x8*>(p) = hi;
+  *reinterpret_cast<bf16x8*>(p + R * SROW) = mid;
+  *reinterpret_cast<bf16x8*>(p + 2 * R * SROW) = lo;
+}
+
+// Pipeline: LDS holds two stages.  In iteration s a wave (1) issues the global loads of stage s+2 into one
+// register set, (2) multiplies stage s out of LDS buffer s%2 while it splits the registers of stage s+1 and
+// writes them to buffer (s+1)%2 - the split's VALU and LDS writes fill the issue slots between MFMAs - and
+// (3) meets the block at ONE barrier.  The loop is unrolled by two so the register sets alternate without
+// moves.
+template <bool A_K, bool B_K, int TBM, int TBN, int WGM>
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K, const float* __restrict__ A,
+                                                           int64_t lda, bool vecA, const float* __restrict__ Bm,
+                                                           int64_t ldb, bool vecB, float* __restrict__ C,
+                                                           int64_t ldc, Epi epi, int k_chunk,
+                                                           float* __restrict__ partial) {
+  constexpr int WGN = 4 / WGM;
+  constexpr int TM = TBM / WGM / 32, TN = TBN / WGN / 32;
+  constexpr int GA = TBM * SKG, GB = TBN * SKG;          // groups of 8 k per operand tile
+  constexpr int NA = (GA + 255) / 256, NB = (GB + 255) / 256;
+  constexpr int STAGE = 3 * (TBM + TBN) * SROW;          // bf16 elements of one stage (A planes, then B planes)
+  constexpr int OPER = 2 * STAGE * 2;                    // bytes
+  constexpr int SMEM = OPER > 4 * 32 * 36 * 4 ? OPER : 4 * 32 * 36 * 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* S0 = reinterpret_cast<__bf16*>(smem_raw);
+  static_assert(SMEM <= 160 * 1024, "tile too large for the LDS");
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
+  const int kbeg = blockIdx.z * k_chunk;
+  const int kend = kbeg + k_chunk < K ? kbeg + k_chunk : K;
+  const int nstages = (kend - kbeg + SK - 1) / SK;
+
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * lk) * CS + lr] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // group g of an operand tile with R rows: k-contiguous operands walk (row, kg) = (g / SKG, g % SKG) so a
+  // row's bytes sit in neighbouring threads; the others walk (g % R, g / R) so lanes read consecutive rows
+  auto load_stage = [&](int st, float (&va)[NA][8], float (&vb)[NB][8]) {
+    const int k0 = kbeg + st * SK;
+    // k-contiguous operands need 16-byte alignment for the unchecked path; the others never do
+    const bool fast = k0 + SK <= kend && (!A_K || vecA) && (!B_K || vecB);
+    if (fast) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + srow;
-        const float4 v4 = *reinterpret_cast<const float4*>(&S[row * CS + sc4]);
-        const int m = m0 + wm * (32 * TM) + i * 32 + row;
-        const int n = n0 + wn * (32 * TN) + j * 32 + sc4;
-        if (m >= M || n >= N) continue;
-        float v[4] = {v4.x, v4.y, v4.z, v4.w};
-        float* cp = out + (int64_t)m * ldo + n;
-        const bool full = n + 3 < N;
-        if (!partial) {
-          float cold[4] = {0.f, 0.f, 0.f, 0.f}, mk[4] = {1.f, 1.f, 1.f, 1.f};
-          if (epi.accumulate) {
-            if (full && vec_out) {
-              const float4 c4 = *reinterpret_cast<const float4*>(cp);
-              cold[0] = c4.x; cold[1] = c4.y; cold[2] = c4.z; cold[3] = c4.w;
-            } else {
+      for (int q = 0; q < NA; ++q) {
+        const int g = t + 256 * q;
+        if (GA % 256 == 0 || g < GA)
+          split_load8<A_K, true>(A, lda, vecA, m0 + (A_K ? g / SKG : g % TBM), M, k0 + 8 * (A_K ? g % SKG : g / TBM), kend,
+                                 va[q]);
+      }
 #pragma unroll
-              for (int u = 0; u < 4; ++u)
-                if (n + u < N) cold[u] = cp[u];
-            }
-          }
-          if (epi.mask_src) {
-            const float* mp = epi.mask_src + (int64_t)m * epi.mask_ld + n;
-            if (full && vec_mask) {
-              const float4 m4 = *reinterpret_cast<const float4*>(mp);
-              mk[0] = m4.x; mk[1] = m4.y; mk[2] = m4.z; mk[3] = m4.w;
-            } else {
+      for (int q = 0; q < NB; ++q) {
+        const int g = t + 256 * q;
+        if (GB % 256 == 0 || g < GB)
+          split_load8<B_K, true>(Bm, ldb, vecB, n0 + (B_K ? g / SKG : g % TBN), N, k0 + 8 * (B_K ? g % SKG : g / TBN), kend,
+                                 vb[q]);
+      }
+    } else {
 #pragma unroll
-              for (int u = 0; u < 4; ++u)
-                if (n + u < N) mk[u] = mp[u];
-            }
-          }
+      for (int q = 0; q < NA; ++q) {
+        const int g = t + 256 * q;
+        if (GA % 256 == 0 || g < GA)
+          split_load8<A_K, false>(A, lda, vecA, m0 + (A_K ? g / SKG : g % TBM), M, k0 + 8 * (A_K ? g % SKG : g / TBM), kend,
+                                  va[q]);
+      }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (n + u >= N) break;
-            float x = v[u];
-            if (epi.bias) x += epi.bias[n + u];
-            if (epi.accumulate) x += cold[u];
-            if (epi.relu == 1) x = fmaxf(x, 0.f);
-            else if (epi.relu == 2) x = 1.f / (1.f + expf(-x));
-            if (epi.drop.on) x *= drop_mul(epi.drop, (uint64_t)m * (uint64_t)N + (uint64_t)(n + u));
-            if (epi.mask_src) x = mk[u] > 0.f ? x * epi.mask_scale : 0.f;
-            v[u] = x;
-          }
-        }
-        if (full && vec_out) {
-          *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (n + u < N) cp[u] = v[u];
-        }
+      for (int q = 0; q < NB; ++q) {
+        const int g = t + 256 * q;
+        if (GB % 256 == 0 || g < GB)
+          split_load8<B_K, false>(Bm, ldb, vecB, n0 + (B_K ? g / SKG : g % TBN), N, k0 + 8 * (B_K ? g % SKG : g / TBN), kend,
+                                  vb[q]);
       }
     }
+  };
+  auto store_stage = [&](__bf16* S, const float (&va)[NA][8], const float (&vb)[NB][8]) {
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int g = t + 256 * q;
+      if (GA % 256 == 0 || g < GA) split_store8(S, TBM, A_K ? g / SKG : g % TBM, A_K ? g % SKG : g / TBM, va[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int g = t + 256 * q;
+      if (GB % 256 == 0 || g < GB)
+        split_store8(S + 3 * TBM * SROW, TBN, B_K ? g / SKG : g % TBN, B_K ? g % SKG : g / TBN, vb[q]);
+    }
+  };
+  const int lr = lane & 31, lk = lane >> 5;
+  // STORE: also split the register set (va, vb) into buffer Snext; the scheduling hints at the end ask
+  // for one MFMA followed by a handful of the split's VALU instructions, LDS writes spread in between
+  auto multiply = [&](const __bf16* S, auto store_tag, __bf16* Snext, const float (&va)[NA][8],
+                      const float (&vb)[NB][8]) {
+    constexpr bool STORE = decltype(store_tag)::value;
+    const __bf16* As = S;
+    const __bf16* Bs = S + 3 * TBM * SROW;
+    // fragments: lane (row lr, k half lk) holds 8 consecutive k of its row, one 16-byte read per plane
+    bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        a[i][p] = *reinterpret_cast<const bf16x8*>(As + (p * TBM + wm * (32 * TM) + i * 32 + lr) * SROW + lk * 8);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        b[j][p] = *reinterpret_cast<const bf16x8*>(Bs + (p * TBN + wn * (32 * TN) + j * 32 + lr) * SROW + lk * 8);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        f32x16 c = acc[i][j];                       // small terms first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+    if (STORE) {
+      store_stage(Snext, va, vb);
+      constexpr int NMFMA = TM * TN * 6;
+      __builtin_amdgcn_sched_group_barrier(0x100, 3 * (TM + TN), 0);   // the fragment reads first
+#pragma unroll
+      for (int q = 0; q < NMFMA; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);             // five VALU of the split
+        if (q % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // an LDS write now and then
+      }
+    }
+  };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
+
+  float xa[NA][8], xb[NB][8], ya[NA][8], yb[NB][8];
+  __bf16* S1 = S0 + STAGE;
+  load_stage(0, xa, xb);
+  store_stage(S0, xa, xb);
+  if (nstages > 1) load_stage(1, xa, xb);          // x holds stage 1
+  __syncthreads();
+  // loop invariant: buffer 0 holds stage st (st even), x holds stage st+1
+  int st = 0;
+  while (st + 3 < nstages) {
+    load_stage(st + 2, ya, yb);
+    multiply(S0, yes{}, S1, xa, xb);               // stage st out of buffer 0, stage st+1 into buffer 1
+    __syncthreads();
+    load_stage(st + 3, xa, xb);
+    multiply(S1, yes{}, S0, ya, yb);               // stage st+1 out of buffer 1, stage st+2 into buffer 0
+    __syncthreads();
+    st += 2;
+  }
+  const int left = nstages - st;                   // 1, 2 or 3 stages remain
+  if (left == 3) {
+    load_stage(st + 2, ya, yb);
+    multiply(S0, yes{}, S1, xa, xb);
+    __syncthreads();
+    multiply(S1, yes{}, S0, ya, yb);
+    __syncthreads();
+    multiply(S0, no{}, S1, xa, xb);
+  } else if (left == 2) {
+    multiply(S0, yes{}, S1, xa, xb);
+    __syncthreads();
+    multiply(S1, no{}, S0, xa, xb);
+  } else {
+    multiply(S0, no{}, S1, xa, xb);
+  }
+  tile_epilogue<TM, TN>(acc, reinterpret_cast<float*>(smem_raw), M, N, m0, n0, wm, wn, C, ldc, epi, partial);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -613,7 +858,7 @@ static Plan make_plan(int M, int N, int K) {
     if (splits > 128) splits = 128;
     if (splits < 1) splits = 1;
   }
-  int k_chunk = (int)cdiv(cdiv(K, splits), BK) * BK;
+  int k_chunk = (int)cdiv(cdiv(K, splits), 32) * 32;  // whole stages of either kernel
   if (k_chunk < BK) k_chunk = BK;
   p.splits = (int)cdiv(K > 0 ? K : 1, k_chunk);
   p.k_chunk = k_chunk;
@@ -623,6 +868,22 @@ static Plan make_plan(int M, int N, int K) {
 }  // namespace ctr
 
 using namespace ctr;
+
+static int g_gemm_mode = CTR_GEMM_SPLIT_BF16;
+
+static size_t split_lds_bytes(int tbm, int tbn) {
+  const size_t oper = (size_t)2 * 3 * (tbm + tbn) * ctr::SROW * 2;
+  const size_t epi = (size_t)4 * 32 * 36 * 4;
+  return oper > epi ? oper : epi;
+}
+
+extern "C" int ctr_set_gemm_mode(int mode) {
+  CTR_REQUIRE(mode == CTR_GEMM_FP32_MFMA || mode == CTR_GEMM_SPLIT_BF16, "ctr_set_gemm_mode: unknown mode %d", mode);
+  g_gemm_mode = mode;
+  return CTR_OK;
+}
+
+extern "C" int ctr_get_gemm_mode(void) { return g_gemm_mode; }
 
 extern "C" size_t ctr_gemm_f32_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -691,8 +952,19 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
   const bool vecB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
   const dim3 grid(p.tiles_n, p.tiles_m, p.splits), block(256);
 #define LAUNCH3(AK, BK_, TBM, TBN, WGM)                                                                     \
-  hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, TBM, TBN, WGM>), grid, block, 0, st, M, N, K, A, lda, vecA, B, ldb, \
-                     vecB, C, ldc, e, p.k_chunk, partial)
+  do {                                                                                                      \
+    if (g_gemm_mode == CTR_GEMM_SPLIT_BF16) {                                                               \
+      const size_t lds_ = split_lds_bytes(TBM, TBN);                                                        \
+      if (lds_ > 64 * 1024)                                                                                 \
+        CTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<AK, BK_, TBM, TBN, WGM>), \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));                \
+      hipLaunchKernelGGL((gemm_split_kernel<AK, BK_, TBM, TBN, WGM>), grid, block, lds_, st, M, N, K, A, lda, vecA, \
+                         B, ldb, vecB, C, ldc, e, p.k_chunk, partial);                                      \
+    }                                                                                                       \
+    else                                                                                                    \
+      hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, TBM, TBN, WGM>), grid, block, 0, st, M, N, K, A, lda, vecA, B,  \
+                         ldb, vecB, C, ldc, e, p.k_chunk, partial);                                         \
+  } while (0)
 #define LAUNCH(AK, BK_)                                    \
   do {                                                     \
     if (p.bn == 32) LAUNCH3(AK, BK_, 256, 32, 4);          \
