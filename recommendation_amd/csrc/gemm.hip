@@ -792,11 +792,17 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(int M, int N, int K, 
 
 // out[j] (+)= sum over slabs of part[s*cols + j]; block (64,4): slab phase ty takes slabs ty, ty+4, ...
 // eight loads in flight per thread; the four phases are added in a fixed order
+// A second problem (part2, cols2, out2) rides in the same launch on the blocks past the first one's.
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ part, int nslabs, int cols,
-                                                      float* __restrict__ out, int accumulate) {
+                                                      float* __restrict__ out, int accumulate,
+                                                      const float* __restrict__ part2, int cols2,
+                                                      float* __restrict__ out2) {
   __shared__ float red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + tx;
+  int bx = blockIdx.x;
+  const int nb1 = (cols + 63) / 64;
+  if (bx >= nb1) { bx -= nb1; part = part2; cols = cols2; out = out2; }
+  const int j = bx * 64 + tx;
   float acc = 0.f;
   if (j < cols) {
     int s = ty;
@@ -1077,7 +1083,8 @@ extern "C" int ctr_dense_wgrad(int M, int N, int K, const float* A, int64_t lda,
     else
       hipLaunchKernelGGL(wgrad_colsum_partial<false>, dim3((unsigned)cdiv(N, 64), nchunks), dim3(256), 0, st, B, ldb,
                          K, N, rows_per_chunk, part);
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, part, nchunks, N, db, 0);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, part, nchunks, N, db, 0,
+                       (const float*)nullptr, 0, (float*)nullptr);
     CTR_LAUNCH_CHECK();
     return CTR_OK;
   }
@@ -1094,9 +1101,9 @@ extern "C" int ctr_dense_wgrad(int M, int N, int K, const float* A, int64_t lda,
   else if (p.tm == 1 && p.tn == 2) WLAUNCH(1, 2);
   else WLAUNCH(1, 1);
 #undef WLAUNCH
-  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv((int64_t)M * N, 64)), dim3(256), 0, st, part, p.nkb, M * N,
-                     dW, 0);
-  if (db) hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, bias_part, p.nkb, N, db, 0);
+  // one launch adds the dW slabs and, on its last blocks, the bias slabs
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)(cdiv((int64_t)M * N, 64) + (db ? cdiv(N, 64) : 0))), dim3(256), 0,
+                     st, part, p.nkb, M * N, dW, 0, (const float*)bias_part, N, db);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
