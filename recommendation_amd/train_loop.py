@@ -14,6 +14,7 @@ import os
 import time
 
 import numpy as np
+import torch
 
 CATE_COLS = ['user_type', 'item_type']
 DROP_COLS = ['userid', 'itemid', 'label', 'type']
@@ -99,9 +100,14 @@ def fit(model_cls, args, data=None, session=None, log=print):
     for epoch in range(args.epoch):
         t0 = time.time()
         losses = []
-        for s, e in batches(Xtr_c.shape[0], args.batch_size):
-            losses.append(model.run(sess, Xtr_c[s:e], Xtr_f[s:e], ytr[s:e], True, step))
+        # pinned, double-buffered feed; the loss of every step stays on the device until the epoch ends
+        from recommendation_amd.feeder import Feeder
+        model._ensure_initialized(sess)
+        dev_losses = []
+        for idx, xc, yy in Feeder(sess, Xtr_c, Xtr_f, ytr, batches(Xtr_c.shape[0], args.batch_size)):
+            dev_losses.append(model.train_step(idx, xc, yy).clone())
             step += 1
+        losses = [float(v) for v in torch.cat(dev_losses).cpu()] if dev_losses else []
         took = time.strftime('%H: %M: %S', time.gmtime(time.time() - t0))
         log('Epoch %d training: loss = %.4f, took: %s' % (epoch + 1, np.mean(losses) if losses else float('nan'), took))
         actuals, predicts, probs = [], [], []

@@ -92,3 +92,26 @@ def test_n_step_auc_logloss_parity(sess, name):
     assert abs(tl.log_loss(y, p_g) - tl.log_loss(y, p_o)) < 1e-3
     assert abs(tl.auc_score(y, p_g) - tl.auc_score(y, p_o)) < 1e-3
     assert tl.auc_score(y, p_g) > 0.7
+
+
+def test_feeder_delivers_the_reference_batches_in_order(sess):
+    """Pinned, multi-slot host -> device feed: same ranges as the reference loop, narrowed dtypes,
+    exact values, more batches than staging slots (slots are reused)."""
+    from recommendation_amd.feeder import Feeder
+    from recommendation_amd.train_loop import batches
+    rng = np.random.default_rng(3)
+    n, F, C = 1003, 5, 3
+    Xc = rng.integers(0, 1 << 20, (n, F))                  # int64, as pandas delivers it
+    Xf = rng.standard_normal((n, C))                       # float64
+    y = rng.integers(0, 2, n)
+    ranges = batches(n, 100)
+    assert ranges[-1] == (900, 1000) or ranges[-1][1] <= n
+    got = []
+    for idx, xc, yy in Feeder(sess, Xc, Xf, y, ranges, depth=2):
+        assert idx.dtype == torch.int32 and xc.dtype == torch.float32 and yy.dtype == torch.float32
+        got.append((idx.cpu().numpy().copy(), xc.cpu().numpy().copy(), yy.cpu().numpy().copy()))
+    assert len(got) == len(ranges)
+    for (s, e), (a, b, c) in zip(ranges, got):
+        assert np.array_equal(a, Xc[s:e].astype(np.int32))
+        assert np.array_equal(b, Xf[s:e].astype(np.float32))
+        assert np.array_equal(c, y[s:e].astype(np.float32))
