@@ -133,6 +133,10 @@ int ctr_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, int64_t n, 
 #define CTR_OPT_ADAM 1      /* row-wise Adam on rows that received a gradient           */
 #define CTR_OPT_ADAGRAD 2   /* tf.train.AdagradOptimizer semantics (AFM/AFM.py:29)      */
 #define CTR_OPT_SGD 3       /* tf.train.GradientDescentOptimizer (DIN/DIN.py:110)       */
+#define CTR_OPT_FTRL 4      /* tf.train.FtrlOptimizer, lr_power -0.5 (Wide_Deep/Wide_Deep.py:107-108):
+                             * slot0 = accumulator n (initial 0.1), slot1 = linear z (initial 0);
+                             * n' = n + g^2; z += g - (sqrt(n') - sqrt(n))/lr * w;
+                             * w = |z| <= l1 ? 0 : -(z - sign(z) l1) / (sqrt(n')/lr + 2 l2)        */
 
 typedef struct {
   int kind;     /* CTR_OPT_*                                            */
@@ -140,6 +144,8 @@ typedef struct {
   float beta1;  /* Adam                                                 */
   float beta2;  /* Adam                                                 */
   float eps;    /* Adam (outside the sqrt, TF-1.x)                      */
+  float l1;     /* FTRL l1_regularization_strength                      */
+  float l2;     /* FTRL l2_regularization_strength                      */
 } ctr_opt_t;
 
 /* For every run of equal keys in the sorted pairs: g = sum (in sorted order, so bitwise

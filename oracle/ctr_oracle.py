@@ -573,6 +573,143 @@ class SGD:
             params[k] = params[k] - lr * g
 
 
+class FtrlTF1:
+    """tf.train.FtrlOptimizer(lr, l1) with its defaults lr_power=-0.5, initial accumulator 0.1, l2=0
+    (Wide_Deep/Wide_Deep.py:107-108).  `rows[k]` (bool per row) restricts the update to the rows an
+    embedding_lookup touched: the gradient of a lookup is sparse and TF applies it row-wise, so an
+    untouched row keeps its weight even where that weight is not the closed form of (z, n)."""
+
+    def __init__(self, params, l1=0.1, l2=0.0, init_acc=0.1):
+        self.l1, self.l2 = l1, l2
+        self.n = {k: torch.full_like(v, init_acc) for k, v in params.items()}
+        self.z = {k: torch.zeros_like(v) for k, v in params.items()}
+
+    def apply(self, params, grads, lr, rows=None):
+        for k, g in grads.items():
+            w, n, z = params[k], self.n[k], self.z[k]
+            nn = n + g * g
+            zz = z + g - (torch.sqrt(nn) - torch.sqrt(n)) / lr * w
+            ww = torch.where(zz.abs() <= self.l1, torch.zeros_like(zz),
+                             -(zz - torch.sign(zz) * self.l1) / (torch.sqrt(nn) / lr + 2.0 * self.l2))
+            if rows is not None and k in rows:
+                m = rows[k].view(-1, 1)
+                ww, nn, zz = torch.where(m, ww, w), torch.where(m, nn, n), torch.where(m, zz, z)
+            params[k], self.n[k], self.z[k] = ww, nn, zz
+
+
+# ----------------------------------------------------------------------------
+# Wide & Deep (Wide_Deep/Wide_Deep.py:34-118): standard lookups; wide = concat of E-wide rows of the
+# cross and category tables -> one linear unit; deep = category embeddings + dense -> relu tower.
+# ----------------------------------------------------------------------------
+def wide_deep_param_shapes(cfg):
+    E = cfg.embed_size
+    sh = OrderedDict()
+    for i, v in enumerate(cfg.cross_list):
+        sh['wide_net/wide_cross_w_%d' % i] = (int(v), E)
+        sh['wide_net/wide_cross_b_%d' % i] = (E,)           # declared, never used (Wide_Deep/Wide_Deep.py:49-50)
+    for i, v in enumerate(cfg.cate_list):
+        sh['wide_net/wide_cate_w_%d' % i] = (int(v), E)
+    sh['wide_net/wide_output_w'] = ((len(cfg.cross_list) + len(cfg.cate_list)) * E, 1)
+    sh['wide_net/wide_output_b'] = (1,)
+    for i, v in enumerate(cfg.cate_list):
+        sh['deep_net/deep_cate_w_%d' % i] = (int(v), E)
+    d_in = len(cfg.cate_list) * E + cfg.cont_num
+    for i, L in enumerate(cfg.hidden_layers):
+        sh['deep_net/deep_hidden_w_%d' % i] = (d_in, L)
+        sh['deep_net/deep_hidden_b_%d' % i] = (1, L)
+        d_in = L
+    sh['deep_net/deep_output_w'] = (d_in, 1)
+    sh['deep_net/deep_output_b'] = (1,)
+    return sh
+
+
+def wide_deep_init_params(cfg, seed=0, std=0.01):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return OrderedDict((k, truncated_normal(rng, s, std)) for k, s in wide_deep_param_shapes(cfg).items())
+
+
+def wide_deep_forward(P, cfg, X_cross, X_cate, X_cont, masks=None):
+    masks = masks or {}
+    wide = [P['wide_net/wide_cross_w_%d' % i] for i in range(len(cfg.cross_list))] + \
+           [P['wide_net/wide_cate_w_%d' % i] for i in range(len(cfg.cate_list))]
+    Zw = embed_block_smode(wide, torch.cat([X_cross, X_cate], dim=1))            # [B, Fw, E]
+    wide_out = Zw.reshape(Zw.shape[0], -1) @ P['wide_net/wide_output_w'] + P['wide_net/wide_output_b']
+    Zd = embed_block_smode([P['deep_net/deep_cate_w_%d' % i] for i in range(len(cfg.cate_list))], X_cate)
+    x = torch.cat([Zd.reshape(Zd.shape[0], -1), X_cont], dim=1)
+    n = len(cfg.hidden_layers)
+    for i in range(n):
+        x = torch.relu(x @ P['deep_net/deep_hidden_w_%d' % i] + P['deep_net/deep_hidden_b_%d' % i])
+        x = dropout(x, cfg.dropout, masks.get('deep_%d' % i))
+    deep_out = x @ P['deep_net/deep_output_w'] + P['deep_net/deep_output_b']
+    logit = (wide_out + deep_out).reshape(-1)
+    return SimpleNamespace(logit=logit, y_out=torch.sigmoid(logit), Zw=Zw, Zd=Zd)
+
+
+class OracleWideDeep:
+    """Wide & Deep graph + its two optimizers (FTRL with l1=0.1 on wide_net, Adagrad on deep_net;
+    Wide_Deep/Wide_Deep.py:98-118).  The loss is sigmoid cross-entropy applied to y_out, which is already
+    a probability (as written).  Both minimize() calls advance the one global_step, so it grows by two
+    per step; the learning rate of a step is taken at its value before the step."""
+
+    def __init__(self, cfg, params, dtype=torch.float64):
+        self.cfg, self.dtype = cfg, dtype
+        self.P = OrderedDict((k, torch.as_tensor(np.asarray(v), dtype=dtype).clone()) for k, v in params.items())
+        self.wide = [k for k in self.P if k.startswith('wide_net/')]
+        self.deep = [k for k in self.P if k.startswith('deep_net/')]
+        self.ftrl = FtrlTF1({k: self.P[k] for k in self.wide})
+        self.adagrad = AdagradTF1({k: self.P[k] for k in self.deep})
+        self.global_step = 0
+
+    def _inputs(self, X_cross, X_cate, X_cont, y):
+        i64 = lambda a: torch.as_tensor(np.asarray(a).astype(np.int32).astype(np.int64))
+        return (i64(X_cross), i64(X_cate), torch.as_tensor(np.asarray(X_cont).astype(np.float32)).to(self.dtype),
+                torch.as_tensor(np.asarray(y).astype(np.float32)).to(self.dtype))
+
+    def forward(self, X_cross, X_cate, X_cont):
+        xr, xc, xf, _ = self._inputs(X_cross, X_cate, X_cont, np.zeros(len(X_cate)))
+        with torch.no_grad():
+            return wide_deep_forward(self.P, self.cfg, xr, xc, xf)
+
+    def loss_and_grads(self, X_cross, X_cate, X_cont, y, masks=None):
+        xr, xc, xf, yy = self._inputs(X_cross, X_cate, X_cont, y)
+        P = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in self.P.items())
+        out = wide_deep_forward(P, self.cfg, xr, xc, xf, masks)
+        loss = sigmoid_ce_with_logits(yy, out.y_out).mean()
+        grads = torch.autograd.grad(loss, list(P.values()), allow_unused=True)
+        g = OrderedDict((k, torch.zeros_like(v) if gi is None else gi.detach()) for (k, v), gi in zip(P.items(), grads))
+        return loss.detach(), g, out
+
+    def _touched(self, X_cross, X_cate):
+        """rows of every wide table that the batch looks up (in range)."""
+        rows = {}
+        xr = np.asarray(X_cross).astype(np.int64)
+        xc = np.asarray(X_cate).astype(np.int64)
+        for name, ids, cards in (('wide_net/wide_cross_w_%d', xr, self.cfg.cross_list),
+                                 ('wide_net/wide_cate_w_%d', xc, self.cfg.cate_list)):
+            for i, v in enumerate(cards):
+                m = torch.zeros(int(v), dtype=torch.bool)
+                col = ids[:, i]
+                m[torch.as_tensor(col[(col >= 0) & (col < v)])] = True
+                rows[name % i] = m
+        return rows
+
+    def run(self, X_cross, X_cate, X_cont, y, is_train=False, masks=None):
+        if is_train:
+            loss, g, _ = self.loss_and_grads(X_cross, X_cate, X_cont, y, masks)
+            c = self.cfg
+            lr = exponential_decay(c.learning_rate, self.global_step, c.decay_steps, c.decay_rate)
+            pw = {k: self.P[k] for k in self.wide if not k.startswith('wide_net/wide_cross_b_')}
+            self.ftrl.apply(pw, {k: g[k] for k in pw}, lr, rows=self._touched(X_cross, X_cate))
+            pd_ = {k: self.P[k] for k in self.deep}
+            self.adagrad.apply(pd_, {k: g[k] for k in pd_}, lr)
+            self.P.update(pw)
+            self.P.update(pd_)
+            self.global_step += 2
+            return np.float32(loss.item())
+        out = self.forward(X_cross, X_cate, X_cont)
+        return np.asarray(y, dtype=np.float32), tf_round(out.y_out).to(torch.float32).numpy()
+
+
 _OPT = dict(adam=AdamTF1, adagrad=AdagradTF1, sgd=SGD)
 
 
@@ -681,6 +818,9 @@ def default_cfg(model, **kw):
         c.update(inner_product=True, product_size=50, hidden_layers=[32, 64, 128], dropout=0.2)
     if model == 'ESMM':
         c.update(dropout=0.2)
+    if model == 'Wide_Deep':
+        c = dict(embed_size=8, hidden_layers=[32, 64, 128], batch_size=128, epoch=10, regular_rate=0.1,
+                 learning_rate=0.001, dropout=0.2, decay_steps=10000, decay_rate=0.99)
     if model == 'DIN':
         c = dict(train_batch_size=32, test_batch_size=512, hidden_units=32, epoch=10, learning_rate=0.1)
     c.update(kw)

@@ -25,7 +25,7 @@ class Dropout(C.Structure):
 
 class Opt(C.Structure):
     _fields_ = [('kind', C.c_int), ('lr', C.c_float), ('beta1', C.c_float),
-                ('beta2', C.c_float), ('eps', C.c_float)]
+                ('beta2', C.c_float), ('eps', C.c_float), ('l1', C.c_float), ('l2', C.c_float)]
 
 
 class Epilogue(C.Structure):
@@ -34,7 +34,7 @@ class Epilogue(C.Structure):
                 ('mask_ld', C.c_int64), ('mask_scale', C.c_float)]
 
 
-OPT_GRAD_ONLY, OPT_ADAM, OPT_ADAGRAD, OPT_SGD = 0, 1, 2, 3
+OPT_GRAD_ONLY, OPT_ADAM, OPT_ADAGRAD, OPT_SGD, OPT_FTRL = 0, 1, 2, 3, 4
 LOSS_SIGMOID_LOGLOSS, LOSS_IDENTITY_LOGLOSS, LOSS_SIGMOID_SCE_PROB, LOSS_SCE_LOGIT, LOSS_PROB_SCE = 0, 1, 2, 3, 4
 
 i, i64, sz, f = C.c_int, C.c_int64, C.c_size_t, C.c_float

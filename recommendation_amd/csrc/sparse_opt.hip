@@ -8,8 +8,16 @@ namespace ctr {
 
 struct Opt {
   int kind;
-  float lr, b1, b2, eps;
+  float lr, b1, b2, eps, l1, l2;
 };
+
+__device__ static inline void ftrl1(const Opt& o, float g, float& w, float& n, float& z) {
+  const float nn = n + g * g;
+  z += g - (sqrtf(nn) - sqrtf(n)) / o.lr * w;
+  const float sgn = z > 0.f ? 1.f : (z < 0.f ? -1.f : 0.f);
+  w = fabsf(z) <= o.l1 ? 0.f : -(z - sgn * o.l1) / (sqrtf(nn) / o.lr + 2.f * o.l2);
+  n = nn;
+}
 
 __device__ static inline void opt_apply4(const Opt& o, float4 g, float4* w, float4* s0, float4* s1) {
   if (o.kind == CTR_OPT_ADAM) {
@@ -31,6 +39,11 @@ __device__ static inline void opt_apply4(const Opt& o, float4 g, float4* w, floa
     float4 p = *w;
     p.x -= o.lr * g.x; p.y -= o.lr * g.y; p.z -= o.lr * g.z; p.w -= o.lr * g.w;
     *w = p;
+  } else if (o.kind == CTR_OPT_FTRL) {
+    float4 p = *w, n = *s0, z = *s1;
+    ftrl1(o, g.x, p.x, n.x, z.x); ftrl1(o, g.y, p.y, n.y, z.y);
+    ftrl1(o, g.z, p.z, n.z, z.z); ftrl1(o, g.w, p.w, n.w, z.w);
+    *w = p; *s0 = n; *s1 = z;
   } else {
     *s0 = g;
   }
@@ -187,6 +200,10 @@ __global__ __launch_bounds__(256) void dense_update_kernel(float* __restrict__ p
       const float a = s0[i] + gi * gi;
       s0[i] = a;
       p[i] -= o.lr * gi / sqrtf(a);
+    } else if (o.kind == CTR_OPT_FTRL) {
+      float w = p[i], n = s0[i], z = s1[i];
+      ftrl1(o, gi, w, n, z);
+      p[i] = w; s0[i] = n; s1[i] = z;
     } else {
       p[i] -= o.lr * gi;
     }
@@ -195,7 +212,7 @@ __global__ __launch_bounds__(256) void dense_update_kernel(float* __restrict__ p
 
 static Opt make_opt(const ctr_opt_t* o) {
   Opt r;
-  r.kind = o->kind; r.lr = o->lr; r.b1 = o->beta1; r.b2 = o->beta2; r.eps = o->eps;
+  r.kind = o->kind; r.lr = o->lr; r.b1 = o->beta1; r.b2 = o->beta2; r.eps = o->eps; r.l1 = o->l1; r.l2 = o->l2;
   return r;
 }
 
@@ -228,6 +245,7 @@ extern "C" int ctr_emb_sparse_apply(const uint32_t* keys_sorted, const uint32_t*
     case CTR_OPT_ADAM: CTR_REQUIRE(tables && slot0 && slot1, "ctr_emb_sparse_apply: Adam needs tables, m, v"); break;
     case CTR_OPT_ADAGRAD: CTR_REQUIRE(tables && slot0, "ctr_emb_sparse_apply: Adagrad needs tables, acc"); break;
     case CTR_OPT_SGD: CTR_REQUIRE(tables, "ctr_emb_sparse_apply: SGD needs tables"); break;
+    case CTR_OPT_FTRL: CTR_REQUIRE(tables && slot0 && slot1, "ctr_emb_sparse_apply: FTRL needs tables, n, z"); break;
     default: CTR_REQUIRE(false, "ctr_emb_sparse_apply: unknown optimizer kind %d", opt->kind);
   }
   if (!workspace || workspace_bytes < apply_ws_bytes(n_items, E)) {
@@ -270,9 +288,11 @@ extern "C" int ctr_dense_update(float* param, const float* grad, float* slot0, f
   CTR_REQUIRE(opt && n >= 0, "ctr_dense_update: bad argument");
   if (n == 0) return CTR_OK;
   CTR_REQUIRE(param && grad, "ctr_dense_update: null pointer");
-  CTR_REQUIRE(opt->kind == CTR_OPT_ADAM || opt->kind == CTR_OPT_ADAGRAD || opt->kind == CTR_OPT_SGD,
+  CTR_REQUIRE(opt->kind == CTR_OPT_ADAM || opt->kind == CTR_OPT_ADAGRAD || opt->kind == CTR_OPT_SGD ||
+                  opt->kind == CTR_OPT_FTRL,
               "ctr_dense_update: unknown optimizer kind %d", opt->kind);
   CTR_REQUIRE(opt->kind != CTR_OPT_ADAM || (slot0 && slot1), "ctr_dense_update: Adam needs m and v");
+  CTR_REQUIRE(opt->kind != CTR_OPT_FTRL || (slot0 && slot1), "ctr_dense_update: FTRL needs n and z");
   CTR_REQUIRE(opt->kind != CTR_OPT_ADAGRAD || slot0, "ctr_dense_update: Adagrad needs the accumulator");
   const int64_t blocks = cdiv(n, 256) < 8192 ? cdiv(n, 256) : 8192;
   hipLaunchKernelGGL(dense_update_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param,

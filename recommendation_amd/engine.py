@@ -83,6 +83,9 @@ class DenseParams:
         elif kind == 'adagrad':
             self.slot0 = torch.full_like(self.flat, 0.1)   # tf.train.AdagradOptimizer initial accumulator
             self.slot1 = None
+        elif kind == 'ftrl':
+            self.slot0 = torch.full_like(self.flat, 0.1)   # tf.train.FtrlOptimizer initial accumulator
+            self.slot1 = torch.zeros_like(self.flat)       # linear term
 
     def apply(self, opt):
         ops.dense_update(self.flat, self.grad, opt, self.slot0, self.slot1)
@@ -118,6 +121,9 @@ class EmbeddingTables:
                 self.grad = torch.zeros_like(self.weight)
         elif kind == 'adagrad':
             self.slot0 = torch.full_like(self.weight, 0.1)
+        elif kind == 'ftrl':
+            self.slot0 = torch.full_like(self.weight, 0.1)
+            self.slot1 = torch.zeros_like(self.weight)
 
 
 class EmbedFront:

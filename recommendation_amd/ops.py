@@ -293,8 +293,9 @@ def rows_scatter(rows, perm, n, dst, *, F, E):
           'ctr_rows_scatter')
 
 
-def make_opt(kind, lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
-    return Opt(kind=int(kind), lr=float(lr), beta1=float(beta1), beta2=float(beta2), eps=float(eps))
+def make_opt(kind, lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8, l1=0.0, l2=0.0):
+    return Opt(kind=int(kind), lr=float(lr), beta1=float(beta1), beta2=float(beta2), eps=float(eps),
+               l1=float(l1), l2=float(l2))
 
 
 @_timed

@@ -79,3 +79,35 @@ def test_auc_score_matches_pair_counting():
     pos, neg = p[y == 1], p[y == 0]
     exact = np.mean([(a > b) + 0.5 * (a == b) for a in pos for b in neg])
     assert abs(tl.auc_score(y, p) - exact) < 1e-12
+
+
+def test_wide_deep_loader_builds_the_cross_feature(tmp_path):
+    """Wide_Deep/main.py:32-85: cross id = index of the '-'-joined type strings in sorted order,
+    cardinalities = distinct + 1, numeric columns standardised over train + test."""
+    import importlib.util
+    import pandas as pd
+    rng = np.random.default_rng(0)
+
+    def frame(n):
+        return pd.DataFrame(dict(userid=rng.integers(0, 50, n), itemid=rng.integers(0, 80, n),
+                                 label=rng.integers(0, 2, n), user_type=rng.integers(0, 3, n),
+                                 item_type=rng.integers(0, 4, n), f0=rng.standard_normal(n) * 3 + 1,
+                                 f1=rng.standard_normal(n)))
+    tr, te = frame(40), frame(15)
+    tr.to_csv(tmp_path / 'train.csv', index=False)
+    te.to_csv(tmp_path / 'test.csv', index=False)
+    spec = importlib.util.spec_from_file_location(
+        'wd_main', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'recommendation_amd',
+                                'zoo', 'Wide_Deep', 'main.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    Xr, Xc, Xf, y, Xr2, Xc2, Xf2, y2, cross_list, cate_list = mod.load_dataset(str(tmp_path))
+    assert Xr.shape == (40, 1) and Xc.shape == (40, 2) and Xf.shape == (40, 2) and Xr2.shape == (15, 1)
+    both = pd.concat([tr, te])
+    joined = (both['user_type'].astype(str) + '-' + both['item_type'].astype(str)).values
+    uniq = np.unique(joined)
+    assert cross_list == [len(uniq) + 1] and cate_list == [both['user_type'].nunique() + 1, both['item_type'].nunique() + 1]
+    assert np.array_equal(Xr[:, 0], np.searchsorted(uniq, joined[:40]))
+    allf = np.concatenate([Xf, Xf2])
+    assert np.allclose(allf.mean(0), 0, atol=1e-9) and np.allclose(allf.std(0), 1, atol=1e-9)
+    assert mod.make_parser().parse_args([]).hidden_layers in ('[32, 64, 128]', [32, 64, 128])

@@ -193,3 +193,45 @@ def test_oracle_reproduces_golden(path):
         P = {k[6:]: old[k] for k in old.files if k.startswith('param/')}
         m32 = O.OracleModel(model, cfg, P, dtype=torch.float32)
         assert rel_err(m32.forward(old['X_cate'], old['X_cont']).y_out.numpy(), old['y_out']) < 1e-5
+
+
+def test_ftrl_matches_the_closed_form_and_touches_only_looked_up_rows():
+    w = {'t': torch.tensor([[0.3, -0.2], [0.1, 0.4], [0.05, 0.0]], dtype=torch.float64)}
+    opt = O.FtrlTF1(w, l1=0.1)
+    g = {'t': torch.tensor([[2.0, -3.0], [0.0, 0.0], [1.0, 1.0]], dtype=torch.float64)}
+    rows = {'t': torch.tensor([True, True, False])}
+    w0 = w['t'].clone()
+    opt.apply(w, g, 0.5, rows=rows)
+    n0, lr = 0.1, 0.5
+    for r in (0, 1):
+        for c in (0, 1):
+            gi, wi = float(g['t'][r, c]), float(w0[r, c])
+            nn = n0 + gi * gi
+            z = gi - (nn ** 0.5 - n0 ** 0.5) / lr * wi
+            ref = 0.0 if abs(z) <= 0.1 else -(z - np.sign(z) * 0.1) / (nn ** 0.5 / lr)
+            assert abs(float(w['t'][r, c]) - ref) < 1e-12
+    assert torch.equal(w['t'][2], w0[2]) and float(opt.n['t'][2, 0]) == 0.1     # untouched row
+    assert float(w['t'][1, 0]) == 0.0                                           # touched, zero gradient: |z| <= l1
+
+
+def test_wide_deep_oracle_gradients_match_finite_differences():
+    cfg = O.default_cfg('Wide_Deep', embed_size=2, hidden_layers=[3], dropout=0.0)
+    cfg.cross_list, cfg.cate_list, cfg.cont_num = [4], [3, 2], 1
+    P = O.wide_deep_init_params(cfg, seed=0, std=0.5)
+    m = O.OracleWideDeep(cfg, P)
+    rng = np.random.default_rng(0)
+    B = 5
+    Xr, Xc = rng.integers(0, 4, (B, 1)), np.stack([rng.integers(0, 3, B), rng.integers(0, 2, B)], 1)
+    Xf, y = rng.standard_normal((B, 1)), rng.integers(0, 2, B)
+    loss, g, _ = m.loss_and_grads(Xr, Xc, Xf, y)
+    assert torch.count_nonzero(g['wide_net/wide_cross_b_0']) == 0               # never enters the graph
+    for k in ('wide_net/wide_output_w', 'deep_net/deep_hidden_w_0', 'wide_net/wide_cate_w_1'):
+        idx = tuple(0 for _ in m.P[k].shape)
+        eps = 1e-6
+        old = m.P[k][idx].item()
+        m.P[k][idx] = old + eps
+        lp = m.loss_and_grads(Xr, Xc, Xf, y)[0]
+        m.P[k][idx] = old - eps
+        lm = m.loss_and_grads(Xr, Xc, Xf, y)[0]
+        m.P[k][idx] = old
+        assert abs((lp - lm).item() / (2 * eps) - g[k][idx].item()) < 1e-7, k
