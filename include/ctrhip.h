@@ -398,6 +398,9 @@ int ctr_relu_mask_apply(float* g, int64_t g_ld, const float* act, int64_t act_ld
 /* Small strided 2-D helpers (concat/slice plumbing of the graphs). */
 int ctr_copy2d(const float* src, int64_t src_ld, float* dst, int64_t dst_ld,
                int rows, int cols, int accumulate, void* stream);
+/* out[r,c] = a[r,c] * b[r,c] on strided 2-D views: the GMF product of NCF (NCF/NCF.py:66) and its gradient */
+int ctr_mul2d(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int rows, int cols,
+              void* stream);
 int ctr_dropout_apply(float* x, int64_t ld, int rows, int cols, const ctr_dropout_t* drop,
                       void* stream);
 

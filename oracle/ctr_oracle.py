@@ -710,6 +710,92 @@ class OracleWideDeep:
         return np.asarray(y, dtype=np.float32), tf_round(out.y_out).to(torch.float32).numpy()
 
 
+# ----------------------------------------------------------------------------
+# NCF (NCF/NCF.py:29-120): tf.layers.dense over one-hot ids = row lookup + bias, with relu; GMF
+# product; three relu+dropout layers on the MLP embeddings; dense(1) WITH relu; sigmoid; and
+# sigmoid cross-entropy applied to that probability.  Adam (dense kernels: every row decays).
+# ----------------------------------------------------------------------------
+def ncf_param_shapes(cfg):
+    E = cfg.embed_size
+    sh = OrderedDict()
+    for n, v in (('user_embed_GMF', cfg.user_size), ('item_embed_GMF', cfg.item_size),
+                 ('user_embed_MLP', cfg.user_size), ('item_embed_MLP', cfg.item_size)):
+        sh['embedding/%s/kernel' % n] = (int(v), E)
+        sh['embedding/%s/bias' % n] = (E,)
+    for i, (a, b) in enumerate(((2 * E, 2 * E), (2 * E, E), (E, E // 2))):
+        sh['MLP/MLP_layer%d/kernel' % (i + 1)] = (a, b)
+        sh['MLP/MLP_layer%d/bias' % (i + 1)] = (b,)
+    sh['concat/logits/kernel'] = (E + E // 2, 1)
+    sh['concat/logits/bias'] = (1,)
+    return sh
+
+
+def ncf_init_params(cfg, seed=0, std=0.01):
+    """kernels ~ truncated normal; tf.layers.dense biases start at zero."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return OrderedDict((k, truncated_normal(rng, s, std) if k.endswith('kernel') else np.zeros(s))
+                       for k, s in ncf_param_shapes(cfg).items())
+
+
+def _onehot_dense(P, name, ids, size):
+    """relu(one_hot(ids, size) @ kernel + bias): an id outside [0, size) gives the all-zero one-hot row."""
+    ok = (ids >= 0) & (ids < size)
+    rows = P['embedding/%s/kernel' % name][torch.where(ok, ids, torch.zeros_like(ids))] * ok.to(P['embedding/%s/kernel' % name].dtype).view(-1, 1)
+    return torch.relu(rows + P['embedding/%s/bias' % name])
+
+
+def ncf_forward(P, cfg, X_user, X_item, masks=None):
+    masks = masks or {}
+    uG = _onehot_dense(P, 'user_embed_GMF', X_user, cfg.user_size)
+    iG = _onehot_dense(P, 'item_embed_GMF', X_item, cfg.item_size)
+    uM = _onehot_dense(P, 'user_embed_MLP', X_user, cfg.user_size)
+    iM = _onehot_dense(P, 'item_embed_MLP', X_item, cfg.item_size)
+    x = torch.cat([uM, iM], dim=1)
+    for i in (1, 2, 3):
+        x = torch.relu(x @ P['MLP/MLP_layer%d/kernel' % i] + P['MLP/MLP_layer%d/bias' % i])
+        x = dropout(x, cfg.dropout, masks.get('mlp_%d' % i))
+    concat = torch.cat([uG * iG, x], dim=1)
+    logits = torch.relu(concat @ P['concat/logits/kernel'] + P['concat/logits/bias']).reshape(-1)
+    return SimpleNamespace(logit=logits, y_out=torch.sigmoid(logits))
+
+
+class OracleNCF:
+    def __init__(self, cfg, params, dtype=torch.float64):
+        self.cfg, self.dtype = cfg, dtype
+        self.P = OrderedDict((k, torch.as_tensor(np.asarray(v), dtype=dtype).clone()) for k, v in params.items())
+        self.opt = AdamTF1(self.P)
+        self.global_step = 0
+
+    def _ids(self, X):
+        X = np.asarray(X).astype(np.int32).astype(np.int64)
+        return torch.as_tensor(X[:, 0]), torch.as_tensor(X[:, 1])
+
+    def forward(self, X):
+        u, i = self._ids(X)
+        with torch.no_grad():
+            return ncf_forward(self.P, self.cfg, u, i)
+
+    def loss_and_grads(self, X, y, masks=None):
+        u, i = self._ids(X)
+        yy = torch.as_tensor(np.asarray(y).astype(np.float32)).to(self.dtype)
+        P = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in self.P.items())
+        out = ncf_forward(P, self.cfg, u, i, masks)
+        loss = sigmoid_ce_with_logits(yy, out.y_out).mean()
+        grads = torch.autograd.grad(loss, list(P.values()), allow_unused=True)
+        g = OrderedDict((k, torch.zeros_like(v) if gi is None else gi.detach()) for (k, v), gi in zip(P.items(), grads))
+        return loss.detach(), g, out
+
+    def run(self, X, y, is_train=False, masks=None):
+        if is_train:
+            loss, g, _ = self.loss_and_grads(X, y, masks)
+            c = self.cfg
+            self.opt.apply(self.P, g, exponential_decay(c.learning_rate, self.global_step, c.decay_steps, c.decay_rate))
+            self.global_step += 1
+            return np.float32(loss.item())
+        out = self.forward(X)
+        return np.asarray(y, dtype=np.float32), tf_round(out.y_out).to(torch.float32).numpy()
+
+
 _OPT = dict(adam=AdamTF1, adagrad=AdagradTF1, sgd=SGD)
 
 
@@ -821,6 +907,9 @@ def default_cfg(model, **kw):
     if model == 'Wide_Deep':
         c = dict(embed_size=8, hidden_layers=[32, 64, 128], batch_size=128, epoch=10, regular_rate=0.1,
                  learning_rate=0.001, dropout=0.2, decay_steps=10000, decay_rate=0.99)
+    if model == 'NCF':
+        c = dict(embed_size=16, batch_size=128, epoch=10, regular_rate=0.1, learning_rate=0.001, dropout=0.2,
+                 decay_steps=10000, decay_rate=0.99)
     if model == 'DIN':
         c = dict(train_batch_size=32, test_batch_size=512, hidden_units=32, epoch=10, learning_rate=0.1)
     c.update(kw)

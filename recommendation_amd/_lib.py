@@ -99,6 +99,7 @@ SIGNATURES = {
     'ctr_dsigmoid_apply': (i, [vp, i64, vp, i64, i, i, vp]),
     'ctr_mean_positive_diff': (i, [vp, vp, i, vp, vp]),
     'ctr_copy2d': (i, [vp, i64, vp, i64, i, i, i, vp]),
+    'ctr_mul2d': (i, [vp, i64, vp, i64, vp, i64, i, i, vp]),
     'ctr_dropout_apply': (i, [vp, i64, i, i, DP, vp]),
 }
 

@@ -326,6 +326,30 @@ extern "C" int ctr_copy2d(const float* src, int64_t src_ld, float* dst, int64_t 
   return CTR_OK;
 }
 
+namespace ctr {
+__global__ __launch_bounds__(256) void mul2d_kernel(const float* __restrict__ a, int64_t lda,
+                                                   const float* __restrict__ b, int64_t ldb, float* __restrict__ out,
+                                                   int64_t ldo, int rows, int cols) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = p / cols;
+    const int c = (int)(p % cols);
+    out[r * ldo + c] = a[r * lda + c] * b[r * ldb + c];
+  }
+}
+}  // namespace ctr
+
+extern "C" int ctr_mul2d(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int rows,
+                         int cols, void* stream) {
+  CTR_REQUIRE(rows >= 0 && cols >= 0, "ctr_mul2d: bad size");
+  if ((int64_t)rows * cols == 0) return CTR_OK;
+  CTR_REQUIRE(a && b && out, "ctr_mul2d: null pointer");
+  hipLaunchKernelGGL(mul2d_kernel, dim3(grid_for((int64_t)rows * cols)), dim3(256), 0, (hipStream_t)stream, a, lda, b,
+                     ldb, out, ldo, rows, cols);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
 extern "C" int ctr_dropout_apply(float* x, int64_t ld, int rows, int cols, const ctr_dropout_t* drop,
                                  void* stream) {
   CTR_REQUIRE(rows >= 0 && cols >= 0, "ctr_dropout_apply: bad size");

@@ -481,6 +481,17 @@ def copy2d(src, dst, accumulate=False):
 
 
 @_timed
+def mul2d(a, b, out):
+    rows, cols = out.shape
+    ap, ald = _rows(a, 'a')
+    bp, bld = _rows(b, 'b')
+    op, old = _rows(out, 'out')
+    if tuple(a.shape) != (rows, cols) or tuple(b.shape) != (rows, cols):
+        raise ValueError('mul2d shape mismatch')
+    check(lib().ctr_mul2d(ap, ald, bp, bld, op, old, rows, cols, _stream()), 'ctr_mul2d')
+
+
+@_timed
 def dropout_apply(x, drop):
     if drop is None:
         return

@@ -111,3 +111,23 @@ def test_wide_deep_loader_builds_the_cross_feature(tmp_path):
     allf = np.concatenate([Xf, Xf2])
     assert np.allclose(allf.mean(0), 0, atol=1e-9) and np.allclose(allf.std(0), 1, atol=1e-9)
     assert mod.make_parser().parse_args([]).hidden_layers in ('[32, 64, 128]', [32, 64, 128])
+
+
+def test_ncf_loader_reindexes_in_first_appearance_order(tmp_path):
+    """NCF/main.py:12-50: ids are mapped to their rank of first appearance over train then test."""
+    import importlib.util
+    import pandas as pd
+    tr = pd.DataFrame(dict(userid=[30, 10, 30, 20], itemid=[5, 5, 9, 7], label=[1, 0, 1, 0]))
+    te = pd.DataFrame(dict(userid=[20, 40], itemid=[9, 1], label=[0, 1]))
+    tr.to_csv(tmp_path / 'train.csv', index=False)
+    te.to_csv(tmp_path / 'test.csv', index=False)
+    spec = importlib.util.spec_from_file_location(
+        'ncf_main', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'recommendation_amd',
+                                 'zoo', 'NCF', 'main.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    Xtr, ytr, Xte, yte, nu, ni = mod.load_dataset(str(tmp_path))
+    assert (nu, ni) == (4, 4)
+    assert Xtr.tolist() == [[0, 0], [1, 0], [0, 1], [2, 2]] and Xte.tolist() == [[2, 1], [3, 3]]
+    assert ytr.tolist() == [1, 0, 1, 0] and yte.tolist() == [0, 1]
+    assert mod.make_parser().parse_args([]).embed_size == 16
