@@ -337,6 +337,17 @@ int ctr_afm_attn_bwd(const float* z, int64_t z_ld, const float* dx, int B, int N
                      size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Evaluation metrics on the device (the reference round-trips predictions to the host:
+ * DeepFM/main.py:105-126, DIN/main.py:12-61).  auc_out[0] = area under the ROC curve of
+ * (score, label > 0.5) with average ranks for tied scores (NaN when one class is absent);
+ * logloss_out[0] = mean of -y log(p + 1e-7) - (1-y) log(1 - p + 1e-7) (tf.losses.log_loss).
+ * Either output may be NULL.  Sums are double precision in a fixed order.
+ * ---------------------------------------------------------------------------------- */
+size_t ctr_auc_workspace_bytes(int64_t n);
+int ctr_auc(const float* score, const float* label, int64_t n, float* auc_out, float* logloss_out,
+            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Row-wise sharding of the embedding tables over W ranks (new design: the reference is
  * single-process; the single-device numerics it must reproduce are DeepFM/DeepFM.py:43-53 in
  * the standard-lookup form of Wide_Deep/Wide_Deep.py:51).  Row r of field f lives on rank

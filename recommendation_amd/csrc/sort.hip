@@ -237,9 +237,104 @@ static int run_passes(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, in
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// Evaluation metrics on the device: AUC with average ranks for ties (sort the scores with the radix
+// sort above, then every positive finds its tie group by two binary searches) and the log loss of
+// tf.losses.log_loss; double-precision sums in a fixed order.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void auc_keys_kernel(const float* __restrict__ score, const float* __restrict__ label,
+                                                      int64_t n, uint32_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ vals) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t u = __float_as_uint(score[i] + 0.f);            // -0 -> +0 so equal scores get equal keys
+    keys[i] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);    // unsigned order == float order
+    vals[i] = label[i] > 0.5f ? 1u : 0u;
+  }
+}
+
+constexpr int AUC_BLOCKS = 256;
+
+// part[blk] = (sum of average ranks of the positives, #positives, sum of log-loss terms) over the block's slice
+__global__ __launch_bounds__(256) void auc_partial_kernel(const uint32_t* __restrict__ keys,
+                                                         const uint32_t* __restrict__ vals, int64_t n,
+                                                         const float* __restrict__ score,
+                                                         const float* __restrict__ label, double* __restrict__ part) {
+  __shared__ double red[3][256];
+  double rs = 0.0, np_ = 0.0, ll = 0.0;
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo0 = (int64_t)blockIdx.x * per, hi0 = lo0 + per < n ? lo0 + per : n;
+  for (int64_t i = lo0 + threadIdx.x; i < hi0; i += 256) {
+    if (vals[i]) {
+      const uint32_t k = keys[i];
+      int64_t a = 0, b = i;                 // first index with key >= k
+      while (a < b) { const int64_t m = (a + b) >> 1; if (keys[m] < k) a = m + 1; else b = m; }
+      const int64_t first = a;
+      a = i; b = n;                         // first index with key > k
+      while (a < b) { const int64_t m = (a + b) >> 1; if (keys[m] <= k) a = m + 1; else b = m; }
+      rs += 0.5 * (double)(first + a - 1) + 1.0;   // ranks first+1 .. a, averaged
+      np_ += 1.0;
+    }
+    const double p = (double)score[i], y = label[i] > 0.5f ? 1.0 : 0.0;
+    ll += -y * log(p + 1e-7) - (1.0 - y) * log(1.0 - p + 1e-7);
+  }
+  red[0][threadIdx.x] = rs; red[1][threadIdx.x] = np_; red[2][threadIdx.x] = ll;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int c = 0; c < 3; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    for (int c = 0; c < 3; ++c) part[blockIdx.x * 3 + c] = red[c][0];
+}
+
+__global__ void auc_final_kernel(const double* __restrict__ part, int nblocks, int64_t n, float* __restrict__ auc_out,
+                                 float* __restrict__ logloss_out) {
+  double rs = 0.0, np_ = 0.0, ll = 0.0;
+  for (int b = 0; b < nblocks; ++b) { rs += part[3 * b]; np_ += part[3 * b + 1]; ll += part[3 * b + 2]; }
+  const double nn = (double)n - np_;
+  if (auc_out) auc_out[0] = (np_ == 0.0 || nn == 0.0) ? __uint_as_float(0x7FC00000u)
+                                                      : (float)((rs - np_ * (np_ + 1.0) / 2.0) / (np_ * nn));
+  if (logloss_out) logloss_out[0] = (float)(ll / (double)n);
+}
+
 }  // namespace ctr
 
 using namespace ctr;
+
+extern "C" size_t ctr_auc_workspace_bytes(int64_t n) {
+  return sort_ws_bytes(n) + 2 * align_up((size_t)(n > 0 ? n : 1) * 4, 256) + AUC_BLOCKS * 3 * sizeof(double);
+}
+
+extern "C" int ctr_auc(const float* score, const float* label, int64_t n, float* auc_out, float* logloss_out,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  CTR_REQUIRE(n > 0 && n < 0x7FFFFFFFll, "ctr_auc: n must be in (0, 2^31)");
+  CTR_REQUIRE(score && label && workspace && (auc_out || logloss_out), "ctr_auc: null pointer");
+  if (workspace_bytes < ctr_auc_workspace_bytes(n)) {
+    set_error("ctr_auc: workspace %zu < %zu", workspace_bytes, ctr_auc_workspace_bytes(n));
+    return CTR_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  char* p = (char*)workspace;
+  uint32_t* keys = (uint32_t*)p; p += align_up((size_t)n * 4, 256);
+  uint32_t* vals = (uint32_t*)p; p += align_up((size_t)n * 4, 256);
+  double* part = (double*)p; p += AUC_BLOCKS * 3 * sizeof(double);
+  const SortWs w = carve(p, n);
+  const int64_t blocks = cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048;
+  const int passes = (32 + RBITS - 1) / RBITS;
+  // the pass count decides which buffer pair the sort starts from so that it ends in (keys, vals)
+  uint32_t* ka = (passes % 2 == 0) ? keys : w.keys_tmp;
+  uint32_t* va = (passes % 2 == 0) ? vals : w.vals_tmp;
+  uint32_t* kb = (passes % 2 == 0) ? w.keys_tmp : keys;
+  uint32_t* vb = (passes % 2 == 0) ? w.vals_tmp : vals;
+  hipLaunchKernelGGL(auc_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, st, score, label, n, ka, va);
+  run_passes(ka, va, kb, vb, n, passes, w, st);
+  const int nb = (int)(cdiv(n, 256) < AUC_BLOCKS ? cdiv(n, 256) : AUC_BLOCKS);
+  hipLaunchKernelGGL(auc_partial_kernel, dim3(nb), dim3(256), 0, st, keys, vals, n, score, label, part);
+  hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(1), 0, st, part, nb, n, auc_out, logloss_out);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
 
 extern "C" size_t ctr_emb_sort_workspace_bytes(int64_t n_items) { return sort_ws_bytes(n_items); }
 

@@ -257,6 +257,19 @@ def sort_pairs(keys, vals, key_bits, ws):
 
 
 @_timed
+def auc_logloss(score, label, ws):
+    """(auc, logloss) device scalars of float32 scores / labels (AUC with average ranks for ties)."""
+    n = score.numel()
+    if label.numel() != n or not score.is_contiguous() or not label.is_contiguous():
+        raise ValueError('auc_logloss wants contiguous score and label of equal length')
+    out = torch.empty(2, dtype=torch.float32, device=score.device)
+    wp, wn = ws.get(lib().ctr_auc_workspace_bytes(n))
+    check(lib().ctr_auc(_ptr(score, torch.float32), _ptr(label, torch.float32), n, C.c_void_p(out.data_ptr()),
+                        C.c_void_p(out.data_ptr() + 4), wp, wn, _stream()), 'ctr_auc')
+    return out[0], out[1]
+
+
+@_timed
 def shard_route(idx, row_offset, local_offset, W, dest_out, lkey_out):
     B, F = idx.shape
     if idx.dtype != torch.int32 or local_offset.dtype != torch.int32 or tuple(local_offset.shape) != (W, F):

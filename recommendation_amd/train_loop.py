@@ -110,20 +110,22 @@ def fit(model_cls, args, data=None, session=None, log=print):
         losses = [float(v) for v in torch.cat(dev_losses).cpu()] if dev_losses else []
         took = time.strftime('%H: %M: %S', time.gmtime(time.time() - t0))
         log('Epoch %d training: loss = %.4f, took: %s' % (epoch + 1, np.mean(losses) if losses else float('nan'), took))
-        actuals, predicts, probs = [], [], []
-        for s, e in batches(Xte_c.shape[0], args.batch_size):
-            a, p = model.run(sess, Xte_c[s:e], Xte_f[s:e], yte[s:e], False)
-            actuals.append(a)
-            predicts.append(p)
-            probs.append(model.predict_proba(sess, Xte_c[s:e], Xte_f[s:e]))
+        # evaluation stays on the device: one forward per test batch, then AUC (radix sort + average
+        # ranks) and log loss in one call; only three scalars come back to the host
+        dev_y, dev_p = [], []
+        for idx, xc, yy in Feeder(sess, Xte_c, Xte_f, yte, batches(Xte_c.shape[0], args.batch_size)):
+            dev_p.append(model.predict_step(idx, xc).clone())
+            dev_y.append(yy.clone())
         took = time.strftime('%H: %M: %S', time.gmtime(time.time() - t0))
-        if actuals:
-            actuals, predicts, probs = np.concatenate(actuals), np.concatenate(predicts), np.concatenate(probs)
-            accuracy = float(len(actuals == predicts)) / float(len(actuals))     # == 1.0, as in the reference
+        if dev_y:
+            actual, prob = torch.cat(dev_y), torch.cat(dev_p)
+            predict = torch.round(prob)                                           # tf.round: half to even
+            accuracy = float(len(actual == predict)) / float(len(actual))        # == 1.0, as in the reference
             log('Epoch %d testing: Accuracy = %.4f, took: %s' % (epoch + 1, accuracy, took))
+            from recommendation_amd import ops
+            auc, ll = ops.auc_logloss(prob.clamp(0.0, 1.0).contiguous(), actual.contiguous(), sess.ws)
             log('Epoch %d testing: logloss = %.6f, AUC = %.6f, accuracy(true) = %.4f'
-                % (epoch + 1, log_loss(actuals, np.clip(probs, 0, 1)), auc_score(actuals, probs),
-                   float(np.mean(actuals == predicts))))
+                % (epoch + 1, float(ll), float(auc), float((actual == predict).float().mean())))
         model.saver.save(sess, os.path.join(ckpt_dir, args.model_name))
     return model
 

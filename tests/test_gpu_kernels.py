@@ -378,3 +378,22 @@ def test_bad_arguments_are_rejected(ops_ws):
         ops.gemm(torch.zeros(4, 5, device=DEV), torch.zeros(6, 3, device=DEV), torch.zeros(4, 3, device=DEV), ws=ws)
     with pytest.raises(ValueError):     # CPU tensors are refused: there is no CPU path
         ops.gemm(torch.zeros(4, 5), torch.zeros(5, 3), torch.zeros(4, 3), ws=ws)
+
+
+@pytest.mark.parametrize('n,ties', [(1, False), (1000, False), (70001, True), (300000, True)])
+def test_device_auc_and_logloss_match_the_host_metrics(ops_ws, n, ties):
+    from recommendation_amd import train_loop as tl
+    ops, ws = ops_ws
+    rng = np.random.default_rng(n)
+    p = rng.random(n).astype(np.float32)
+    if ties:
+        p = np.round(p, 2)                       # many equal scores
+        p[:5] = [0.0, -0.0, 1.0, 0.5, 0.5]
+    y = (rng.random(n) < 0.3).astype(np.float32)
+    auc, ll = ops.auc_logloss(dev(p), dev(y), ws)
+    ref = tl.auc_score(y, p)
+    if np.isnan(ref):
+        assert np.isnan(auc.item())
+    else:
+        assert abs(auc.item() - ref) < 1e-6
+    assert abs(ll.item() - tl.log_loss(y, np.asarray(p, np.float64))) < 1e-5 * max(1.0, abs(tl.log_loss(y, p)))
