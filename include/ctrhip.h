@@ -337,6 +337,23 @@ int ctr_afm_attn_bwd(const float* z, int64_t z_ld, const float* dx, int B, int N
                      size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Two or three consecutive narrow tower layers in one launch (DeepFM/DeepFM.py:65-80 for the layers
+ * after the first):  h_i = dropout_i(relu(h_{i-1} W_i + b_i)),  h_0 = x [M, K0].
+ * Every h_i is written once (the backward reads them) and never read back: a layer's output stays
+ * in the registers that are the next layer's matrix-core operands.  Dropout element index of h_i is
+ * m * N_i + n, as in ctr_gemm_f32.  Covered widths: ctr_mlp_chain_supported (K0 % 16 == 0, K0 <= 256,
+ * (N1, N2, N3) = (64, 32, 16 | 0)); N3 = 0 chains two layers.
+ * Rows of x and of every output but the last must be 16-byte aligned (the last may be any column
+ * range of a wider buffer).
+ * ---------------------------------------------------------------------------------- */
+int ctr_mlp_chain_supported(int K0, int N1, int N2, int N3);
+int ctr_mlp_chain_fwd(int M, int K0, const float* X, int64_t ldx,
+                      int N1, const float* W1, const float* b1, const ctr_dropout_t* drop1, float* H1, int64_t ld1,
+                      int N2, const float* W2, const float* b2, const ctr_dropout_t* drop2, float* H2, int64_t ld2,
+                      int N3, const float* W3, const float* b3, const ctr_dropout_t* drop3, float* H3, int64_t ld3,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Evaluation metrics on the device (the reference round-trips predictions to the host:
  * DeepFM/main.py:105-126, DIN/main.py:12-61).  auc_out[0] = area under the ROC curve of
  * (score, label > 0.5) with average ranks for tied scores (NaN when one class is absent);

@@ -82,6 +82,8 @@ SIGNATURES = {
     'ctr_afm_pair_bwd': (i, [vp, i64, vp, i, i, i, DP, vp, i64, vp]),
     'ctr_set_gemm_mode': (i, [i]),
     'ctr_get_gemm_mode': (i, []),
+    'ctr_mlp_chain_supported': (i, [i, i, i, i]),
+    'ctr_mlp_chain_fwd': (i, [i, i, vp, i64, i, vp, vp, DP, vp, i64, i, vp, vp, DP, vp, i64, i, vp, vp, DP, vp, i64, vp]),
     'ctr_auc_workspace_bytes': (sz, [i64]),
     'ctr_auc': (i, [vp, vp, i64, vp, vp, vp, sz, vp]),
     'ctr_shard_route': (i, [vp, vp, vp, i, i, i, vp, vp, vp]),

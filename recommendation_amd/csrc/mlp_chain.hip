@@ -1,0 +1,191 @@
+// Chained narrow tower layers in one kernel: h1 = act(x W1 + b1), h2 = act(h1 W2 + b2), h3 = act(h2 W3 + b3)
+// with act = dropout(relu(.)), every h written once (the backward needs them) and never read back.
+//
+// A wave owns a 16-row strip.  Layer 1 streams its rows of x from global memory straight into
+// 16x16x4 fp32 MFMA operands (lane (row l16, k-quad kq) loads x[row][16j + 4kq .. +3]) against W1 held
+// in LDS.  The accumulators are kept transposed (weights as the first MFMA operand), so lane (l16, kq)
+// ends with h[row l16][16t + 4kq + r], r = 0..3 - which is exactly the A-operand fragment of k-step t of
+// the next layer.  Layers 2 and 3 therefore take their input from registers with no data movement;
+// their weights (small) come from L2 as B fragments.
+#include "common.h"
+
+namespace ctr {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ static inline f32x4 act4(f32x4 v, const float* __restrict__ bias, int n, const Drop& d, int64_t m, int N) {
+  f32x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float x = fmaxf(v[r] + bias[n + r], 0.f);
+    if (d.on) x *= drop_mul(d, (uint64_t)m * (uint64_t)N + (uint64_t)(n + r));
+    o[r] = x;
+  }
+  return o;
+}
+
+// the last layer's output may sit at any column of a wider buffer (a concat input of the output unit)
+__device__ static inline void store4(float* p, f32x4 v, bool scalar) {
+  if (scalar) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] = v[r];
+  } else {
+    *reinterpret_cast<f32x4*>(p) = v;
+  }
+}
+
+// widths N1 = 16*NT1, N2 = 16*NT2, N3 = 16*NT3 (NT3 = 0: two layers); a wave owns 16 rows
+template <int NT1, int NT2, int NT3>
+__global__ __launch_bounds__(512) void mlp_chain_fwd_kernel(int M, int K0, const float* __restrict__ X, int64_t ldx,
+                                                           const float* __restrict__ W1, const float* __restrict__ b1,
+                                                           const float* __restrict__ W2, const float* __restrict__ b2,
+                                                           const float* __restrict__ W3, const float* __restrict__ b3,
+                                                           Drop d1, Drop d2, Drop d3, float* __restrict__ H1, int64_t ld1,
+                                                           float* __restrict__ H2, int64_t ld2, float* __restrict__ H3,
+                                                           int64_t ld3, int last_scalar) {
+  extern __shared__ float Ws[];  // W1 as [K0][N1 + 4]
+  constexpr int N1 = 16 * NT1, N2 = 16 * NT2, N3 = 16 * NT3, SN = N1 + 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l16 = lane & 15, kq = lane >> 4;
+  for (int q = threadIdx.x; q < K0 * N1; q += 512) Ws[(q / N1) * SN + q % N1] = W1[q];
+  __syncthreads();
+  const int strips = (M + 15) / 16;
+  const int ksteps = K0 / 16;
+  for (int strip = blockIdx.x * 8 + wave; strip < strips; strip += gridDim.x * 8) {
+    const int r0 = strip * 16;
+    const int64_t m = r0 + l16;
+    const bool live = m < M;
+    const float* x0 = X + (live ? m : (int64_t)M - 1) * ldx + 4 * kq;
+    // ---- layer 1: x from global memory (four k-steps of the row in flight), W1 from LDS
+    f32x4 acc1[NT1];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 xq[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) xq[s4] = *reinterpret_cast<const float4*>(x0 + 16 * (s4 < ksteps ? s4 : 0));
+    for (int j0 = 0; j0 < ksteps; j0 += 4) {
+      float4 cur[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) cur[s4] = xq[s4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int jn = j0 + 4 + s4;
+        if (jn < ksteps) xq[s4] = *reinterpret_cast<const float4*>(x0 + 16 * jn);
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int j = j0 + s4;
+        if (j >= ksteps) break;
+        const float av[4] = {cur[s4].x, cur[s4].y, cur[s4].z, cur[s4].w};
+        const float* wrow = Ws + (16 * j + 4 * kq) * SN + l16;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int t = 0; t < NT1; ++t)
+            acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[u * SN + 16 * t], av[u], acc1[t], 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");   // one k-step of W1 fragments in registers at a time
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) {
+      const int n = 16 * t + 4 * kq;
+      acc1[t] = act4(acc1[t], b1, n, d1, m, N1);
+      if (live) *reinterpret_cast<f32x4*>(H1 + m * ld1 + n) = acc1[t];
+    }
+    // ---- layer 2: input = acc1 (k-step t of this layer is accumulator tile t of the last), W2 from L2
+    f32x4 acc2[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NT1; ++j) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* wp = W2 + (int64_t)(16 * j + 4 * kq + u) * N2 + l16;
+#pragma unroll
+        for (int t = 0; t < NT2; ++t)
+          acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[16 * t], acc1[j][u], acc2[t], 0, 0, 0);
+      }
+      asm volatile("" ::: "memory");   // keeps the weight loads of later k-steps from piling up in registers
+    }
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+      const int n = 16 * t + 4 * kq;
+      acc2[t] = act4(acc2[t], b2, n, d2, m, N2);
+      if (live) store4(H2 + m * ld2 + n, acc2[t], NT3 == 0 && last_scalar);
+    }
+    // ---- layer 3
+    if (NT3 > 0) {
+      f32x4 acc3[NT3 > 0 ? NT3 : 1];
+#pragma unroll
+      for (int t = 0; t < NT3; ++t) acc3[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NT2; ++j) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* wp = W3 + (int64_t)(16 * j + 4 * kq + u) * N3 + l16;
+#pragma unroll
+          for (int t = 0; t < NT3; ++t)
+            acc3[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[16 * t], acc2[j][u], acc3[t], 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+      }
+#pragma unroll
+      for (int t = 0; t < NT3; ++t) {
+        const int n = 16 * t + 4 * kq;
+        const f32x4 o = act4(acc3[t], b3, n, d3, m, N3);
+        if (live) store4(H3 + m * ld3 + n, o, last_scalar);
+      }
+    }
+  }
+}
+
+}  // namespace ctr
+
+using namespace ctr;
+
+// Reports whether the chained kernel covers these widths (the caller falls back to one GEMM per layer).
+// A 128-wide first layer is not offered: its 32 accumulator tiles plus operands leave one block per CU
+// and it measures slower than a GEMM launch per layer.
+extern "C" int ctr_mlp_chain_supported(int K0, int N1, int N2, int N3) {
+  if (K0 < 16 || K0 % 16 || K0 > 256) return 0;
+  return N1 == 64 && N2 == 32 && (N3 == 16 || N3 == 0);
+}
+
+extern "C" int ctr_mlp_chain_fwd(int M, int K0, const float* X, int64_t ldx, int N1, const float* W1, const float* b1,
+                                 const ctr_dropout_t* drop1, float* H1, int64_t ld1, int N2, const float* W2,
+                                 const float* b2, const ctr_dropout_t* drop2, float* H2, int64_t ld2, int N3,
+                                 const float* W3, const float* b3, const ctr_dropout_t* drop3, float* H3, int64_t ld3,
+                                 void* stream) {
+  CTR_REQUIRE(M >= 0, "ctr_mlp_chain_fwd: negative M");
+  CTR_REQUIRE(ctr_mlp_chain_supported(K0, N1, N2, N3), "ctr_mlp_chain_fwd: widths %d -> %d -> %d -> %d not covered", K0,
+              N1, N2, N3);
+  if (M == 0) return CTR_OK;
+  CTR_REQUIRE(X && W1 && b1 && H1 && W2 && b2 && H2 && (N3 == 0 || (W3 && b3 && H3)), "ctr_mlp_chain_fwd: null pointer");
+  CTR_REQUIRE(ldx >= K0 && ldx % 4 == 0 && ((uintptr_t)X % 16) == 0, "ctr_mlp_chain_fwd: x must be 16-byte aligned rows");
+  CTR_REQUIRE(ld1 >= N1 && ld2 >= N2 && (N3 == 0 || ld3 >= N3), "ctr_mlp_chain_fwd: output leading dimension");
+  const float* last = N3 ? H3 : H2;
+  const int64_t ldl = N3 ? ld3 : ld2;
+  const int last_scalar = (ldl % 4 != 0 || ((uintptr_t)last % 16) != 0) ? 1 : 0;
+  CTR_REQUIRE(ld1 % 4 == 0 && ((uintptr_t)H1 % 16) == 0 && (N3 == 0 || (ld2 % 4 == 0 && ((uintptr_t)H2 % 16) == 0)),
+              "ctr_mlp_chain_fwd: outputs before the last must be 16-byte aligned rows");
+  const size_t lds = (size_t)K0 * (N1 + 4) * sizeof(float);
+  const int strips = (int)cdiv(M, 16);
+  int blocks = (int)cdiv(strips, 8);
+  if (blocks > 256) blocks = 256;
+  hipStream_t st = (hipStream_t)stream;
+  const Drop d1 = make_drop(drop1), d2 = make_drop(drop2), d3 = make_drop(drop3);
+#define CH(A_, B_, C_)                                                                                       \
+  do {                                                                                                       \
+    if (lds > 64 * 1024)                                                                                     \
+      CTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_fwd_kernel<A_, B_, C_>),          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
+    hipLaunchKernelGGL((mlp_chain_fwd_kernel<A_, B_, C_>), dim3(blocks), dim3(512), lds, st, M, K0, X, ldx, W1, b1, W2, \
+                       b2, W3, b3, d1, d2, d3, H1, ld1, H2, ld2, H3, ld3, last_scalar);                                   \
+  } while (0)
+  if (N3 == 16) CH(4, 2, 1);
+  else CH(4, 2, 0);
+#undef CH
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}

@@ -195,13 +195,34 @@ class Tower:
         self.names = [('%s_w_%d' % (prefix, i), '%s_b_%d' % (prefix, i)) for i in range(n_layers)]
         self.widths = [dense.shapes[w][1] for w, _ in self.names]
         self.d_in = dense.shapes[self.names[0][0]][0]
+        self._chain = None
 
     def forward(self, x, acts, drops, ws):
         """x: [B, >= d_in]; acts[i]: output buffer of layer i ([B, L_i] views)."""
         h = x[:, :self.d_in]
-        for i, (wn, bn) in enumerate(self.names):
+        n = len(self.names)
+        chain = self._chain_len(acts)
+        for i, (wn, bn) in enumerate(self.names[:n - chain]):
             ops.gemm(h, self.dense.p(wn), acts[i], bias=self.dense.p(bn), relu=True, dropout=drops[i], ws=ws)
             h = acts[i]
+        if chain:
+            k = n - chain
+            ops.mlp_chain_fwd(h, [self.dense.p(w) for w, _ in self.names[k:]],
+                              [self.dense.p(b).reshape(-1) for _, b in self.names[k:]], drops[k:], acts[k:])
+
+    def _chain_len(self, acts):
+        """How many of the last (narrow) layers go through one chained launch: the longest covered tail."""
+        if self._chain is None:
+            self._chain = 0
+            n = len(self.names)
+            for c in (3, 2):
+                k = n - c
+                if k < 1 or not ops.mlp_chain_supported(self.widths[k - 1], self.widths[k:]):
+                    continue
+                if all(a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 for a in acts[k - 1:n - 1]):
+                    self._chain = c
+                    break
+        return self._chain
 
     def backward(self, x, acts, g_last, gbufs, rates, dx, ws, accumulate_dx=False):
         """g_last: gradient w.r.t. acts[-1] (post relu+dropout); it is masked in place.

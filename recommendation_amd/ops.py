@@ -256,6 +256,31 @@ def sort_pairs(keys, vals, key_bits, ws):
     return ko, vo
 
 
+def mlp_chain_supported(K0, widths):
+    n3 = widths[2] if len(widths) > 2 else 0
+    return len(widths) in (2, 3) and bool(lib().ctr_mlp_chain_supported(int(K0), int(widths[0]), int(widths[1]), int(n3)))
+
+
+@_timed
+def mlp_chain_fwd(x, Ws, bs, drops, outs):
+    """outs[i] = dropout_i(relu(outs[i-1] Ws[i] + bs[i])) for two or three layers, outs[-1] = x."""
+    M, K0 = x.shape
+    xp, ldx = _rows(x, 'x')
+    n = len(Ws)
+    args = []
+    for i in range(3):
+        if i < n:
+            W, b, o = Ws[i], bs[i], outs[i]
+            kin = K0 if i == 0 else Ws[i - 1].shape[1]
+            if tuple(W.shape) != (kin, o.shape[1]) or not W.is_contiguous() or b.numel() != W.shape[1] or o.shape[0] != M:
+                raise ValueError('mlp_chain_fwd: layer %d shapes disagree' % i)
+            op, old = _rows(o, 'out')
+            args += [int(W.shape[1]), _ptr(W, torch.float32), _ptr(b, torch.float32), _dp(drops[i]), op, old]
+        else:
+            args += [0, None, None, None, None, 0]
+    check(lib().ctr_mlp_chain_fwd(M, K0, xp, ldx, *args, _stream()), 'ctr_mlp_chain_fwd')
+
+
 @_timed
 def auc_logloss(score, label, ws):
     """(auc, logloss) device scalars of float32 scores / labels (AUC with average ranks for ties)."""

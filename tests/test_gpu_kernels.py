@@ -397,3 +397,40 @@ def test_device_auc_and_logloss_match_the_host_metrics(ops_ws, n, ties):
     else:
         assert abs(auc.item() - ref) < 1e-6
     assert abs(ll.item() - tl.log_loss(y, np.asarray(p, np.float64))) < 1e-5 * max(1.0, abs(tl.log_loss(y, p)))
+
+
+@pytest.mark.parametrize('M,K0,widths,rate', [(1000, 256, (64, 32, 16), 0.0), (77, 128, (64, 32), 0.2),
+                                               (4099, 64, (64, 32, 16), 0.3), (513, 128, (64, 32), 0.2),
+                                               (65, 48, (64, 32), 0.0)])
+def test_chained_tower_layers_match_layer_by_layer_gemms(ops_ws, M, K0, widths, rate):
+    """one launch for the narrow layers == relu(h W + b) with the counter-hash dropout, layer by layer in float64"""
+    ops, ws = ops_ws
+    rng = np.random.default_rng(M + K0)
+    x = (rng.standard_normal((M, K0)) * 0.5).astype(np.float32)
+    Ws, bs, kin = [], [], K0
+    for w in widths:
+        Ws.append((rng.standard_normal((kin, w)) / np.sqrt(kin)).astype(np.float32))
+        bs.append((rng.standard_normal(w) * 0.1).astype(np.float32))
+        kin = w
+    assert ops.mlp_chain_supported(K0, widths)
+    assert not ops.mlp_chain_supported(K0 + 1, widths) and not ops.mlp_chain_supported(K0, (128, 64))
+    xd = torch.zeros(M, K0 + 4, device=DEV)
+    xd[:, :K0] = dev(x)
+    big = torch.full((M, sum(widths) + 12), 5.0, device=DEV)          # outputs as strided views of one buffer
+    outs, c = [], 4
+    for i, w in enumerate(widths):
+        if i == len(widths) - 1 and M % 2:
+            c += 3                                                    # the last output may start at any column
+        outs.append(big[:, c:c + w])
+        c += w
+    drops = [ops.make_dropout(rate, 99, 10 + i) for i in range(len(widths))]
+    ops.mlp_chain_fwd(xd[:, :K0], [dev(W) for W in Ws], [dev(b) for b in bs], drops, outs)
+    h = x.astype(np.float64)
+    for i, w in enumerate(widths):
+        h = np.maximum(h @ Ws[i].astype(np.float64) + bs[i], 0.0)
+        if rate:
+            h = h * O.keep_mask(99, 10 + i, M * w, 1 - rate).reshape(M, w) / (1 - rate)
+        assert rel_err(outs[i].cpu().numpy(), h) < 1e-5, i
+    assert (big[:, :4] == 5.0).all() and (big[:, c:] == 5.0).all()
+    if M % 2:
+        assert (big[:, c - widths[-1] - 3:c - widths[-1]] == 5.0).all()
