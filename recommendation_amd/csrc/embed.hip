@@ -8,6 +8,35 @@ namespace ctr {
 
 __device__ static inline float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// x + (x of the lane CTRL names inside this lane's row of 16), on the VALU's data-parallel path (no LDS)
+template <int CTRL>
+__device__ static inline float dpp_add(float x) {
+  const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false);
+  return x + __builtin_bit_cast(float, y);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_ROR = 0x120;
+
+// Sum over the lanes that share lane % G inside a row of 16 lanes (G <= 16); every lane gets a total.
+template <int G>
+__device__ static inline float row_stride_sum(float x) {
+  if (G <= 1) x = dpp_add<DPP_ROR + 1>(x);
+  if (G <= 2) x = dpp_add<DPP_ROR + 2>(x);
+  if (G <= 4) x = dpp_add<DPP_ROR + 4>(x);
+  if (G <= 8) x = dpp_add<DPP_ROR + 8>(x);
+  return x;
+}
+
+// Two values per lane in, one out: lanes 0-31 get a summed over the lane pairs (l, l + 32), lanes 32-63 get b.
+__device__ static inline float half_swap_sum(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+// Even rows of 16 lanes get a summed over the row pairs (0,1) and (2,3), odd rows get b.
+__device__ static inline float row_swap_sum(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
 // DENSE: Z already sits in z_out (N = F rows per sample); only the reductions are computed.
 template <int G, bool DENSE>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(
@@ -55,25 +84,47 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
     q.x += z.x * z.x; q.y += z.y * z.y; q.z += z.z * z.z; q.w += z.w * z.w;
     if (first_out) {
       float t = (z.x + z.y) + (z.z + z.w);
+      if constexpr (G <= 4) {
+        if (G >= 2) t = dpp_add<DPP_XOR1>(t);
+        if (G >= 4) t = dpp_add<DPP_XOR2>(t);
+      } else {
 #pragma unroll
-      for (int o = G / 2; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        for (int o = G / 2; o > 0; o >>= 1) t += __shfl_xor(t, o);
+      }
       if (active && g == 0) first_out[b * first_ld + n] = t * drop_mul(d_first, (uint64_t)b * N + n);
     }
   }
+  if constexpr (G <= 16) {
+    // Column sums over the wave's 64 / G row groups as a halving exchange: each swap leaves a lane with half
+    // as many values, summed over twice as many lanes.  Row k of 16 lanes ends with column 4g + (0, 2, 1, 3)[k]
+    // of both s and q, complete after the in-row sum.
+    float sv = row_swap_sum(half_swap_sum(s.x, s.y), half_swap_sum(s.z, s.w));
+    float qv = row_swap_sum(half_swap_sum(q.x, q.y), half_swap_sum(q.z, q.w));
+    sv = row_stride_sum<G>(sv);
+    qv = row_stride_sum<G>(qv);
+    const int row = lane >> 4, gg = lane & 15;
+    if (gg < G) {
+      const int col = gg * 4 + ((row & 1) << 1 | row >> 1);
+      if (s_out) s_out[b * E + col] = sv;
+      if (second_out)
+        second_out[b * second_ld + col] = 0.5f * (sv * sv - qv) * drop_mul(d_second, (uint64_t)b * E + col);
+    }
+  } else {
 #pragma unroll
-  for (int o = G; o < 64; o <<= 1) {
-    s.x += __shfl_xor(s.x, o); s.y += __shfl_xor(s.y, o); s.z += __shfl_xor(s.z, o); s.w += __shfl_xor(s.w, o);
-    q.x += __shfl_xor(q.x, o); q.y += __shfl_xor(q.y, o); q.z += __shfl_xor(q.z, o); q.w += __shfl_xor(q.w, o);
-  }
-  if (r == 0) {
-    if (s_out) *reinterpret_cast<float4*>(s_out + b * E + g * 4) = s;
-    if (second_out) {
-      const uint64_t base = (uint64_t)b * E + g * 4;
-      float* o = second_out + b * second_ld + g * 4;
-      o[0] = 0.5f * (s.x * s.x - q.x) * drop_mul(d_second, base + 0);
-      o[1] = 0.5f * (s.y * s.y - q.y) * drop_mul(d_second, base + 1);
-      o[2] = 0.5f * (s.z * s.z - q.z) * drop_mul(d_second, base + 2);
-      o[3] = 0.5f * (s.w * s.w - q.w) * drop_mul(d_second, base + 3);
+    for (int o = G; o < 64; o <<= 1) {
+      s.x += __shfl_xor(s.x, o); s.y += __shfl_xor(s.y, o); s.z += __shfl_xor(s.z, o); s.w += __shfl_xor(s.w, o);
+      q.x += __shfl_xor(q.x, o); q.y += __shfl_xor(q.y, o); q.z += __shfl_xor(q.z, o); q.w += __shfl_xor(q.w, o);
+    }
+    if (r == 0) {
+      if (s_out) *reinterpret_cast<float4*>(s_out + b * E + g * 4) = s;
+      if (second_out) {
+        const uint64_t base = (uint64_t)b * E + g * 4;
+        float* o = second_out + b * second_ld + g * 4;
+        o[0] = 0.5f * (s.x * s.x - q.x) * drop_mul(d_second, base + 0);
+        o[1] = 0.5f * (s.y * s.y - q.y) * drop_mul(d_second, base + 1);
+        o[2] = 0.5f * (s.z * s.z - q.z) * drop_mul(d_second, base + 2);
+        o[3] = 0.5f * (s.w * s.w - q.w) * drop_mul(d_second, base + 3);
+      }
     }
   }
   if (!DENSE && cont_tail && z_out) {
