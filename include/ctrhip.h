@@ -195,6 +195,8 @@ typedef struct {
 #define CTR_GEMM_SPLIT_BF16 1
 int ctr_set_gemm_mode(int mode);
 int ctr_get_gemm_mode(void);
+/* Diagnostic: resident blocks per CU the runtime grants the 128x128 split tile kernel (designed for 2); < 0 on error. */
+int ctr_gemm_split_blocks_per_cu(void);
 size_t ctr_gemm_f32_workspace_bytes(int M, int N, int K);
 int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K,
                  const float* A, int64_t lda, const float* B, int64_t ldb,

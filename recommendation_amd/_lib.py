@@ -82,6 +82,7 @@ SIGNATURES = {
     'ctr_afm_pair_bwd': (i, [vp, i64, vp, i, i, i, DP, vp, i64, vp]),
     'ctr_set_gemm_mode': (i, [i]),
     'ctr_get_gemm_mode': (i, []),
+    'ctr_gemm_split_blocks_per_cu': (i, []),
     'ctr_mlp_chain_supported': (i, [i, i, i, i]),
     'ctr_mlp_chain_fwd': (i, [i, i, vp, i64, i, vp, vp, DP, vp, i64, i, vp, vp, DP, vp, i64, i, vp, vp, DP, vp, i64, vp]),
     'ctr_auc_workspace_bytes': (sz, [i64]),

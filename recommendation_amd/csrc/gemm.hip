@@ -386,10 +386,14 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K,
 
   // group g of an operand tile with R rows: k-contiguous operands walk (row, kg) = (g / SKG, g % SKG) so a
   // row's bytes sit in neighbouring threads; the others walk (g % R, g / R) so lanes read consecutive rows
-  auto load_stage = [&](int st, float (&va)[NA][8], float (&vb)[NB][8]) {
+  // k-contiguous operands need 16-byte alignment for the unchecked path; the others never do
+  const bool vec_ok = (!A_K || vecA) && (!B_K || vecB);
+  // only_fast: the caller guarantees a whole stage inside K and vec_ok.  The steady-state loop uses it so that
+  // its loads sit in straight-line code: behind a branch the compiler can no longer count the loads in
+  // flight and waits for ALL of them - the stage just requested included - before the older stage is used.
+  auto load_stage = [&](int st, auto only_fast, float (&va)[NA][8], float (&vb)[NB][8]) {
     const int k0 = kbeg + st * SK;
-    // k-contiguous operands need 16-byte alignment for the unchecked path; the others never do
-    const bool fast = k0 + SK <= kend && (!A_K || vecA) && (!B_K || vecB);
+    const bool fast = decltype(only_fast)::value || (k0 + SK <= kend && vec_ok);
     if (fast) {
 #pragma unroll
       for (int q = 0; q < NA; ++q) {
@@ -485,24 +489,34 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K,
 
   float xa[NA][8], xb[NB][8], ya[NA][8], yb[NB][8];
   __bf16* S1 = S0 + STAGE;
-  load_stage(0, xa, xb);
+  const int nfull = vec_ok ? (kend - kbeg) / SK : 0;   // stages the unchecked loads may fetch
+  load_stage(0, no{}, xa, xb);
   store_stage(S0, xa, xb);
-  if (nstages > 1) load_stage(1, xa, xb);          // x holds stage 1
+  if (nstages > 1) load_stage(1, no{}, xa, xb);    // x holds stage 1
   __syncthreads();
   // loop invariant: buffer 0 holds stage st (st even), x holds stage st+1
   int st = 0;
-  while (st + 3 < nstages) {
-    load_stage(st + 2, ya, yb);
+  while (st + 3 < nfull) {                         // steady state: whole stages, branch-free loads
+    load_stage(st + 2, yes{}, ya, yb);
     multiply(S0, yes{}, S1, xa, xb);               // stage st out of buffer 0, stage st+1 into buffer 1
     __syncthreads();
-    load_stage(st + 3, xa, xb);
+    load_stage(st + 3, yes{}, xa, xb);
     multiply(S1, yes{}, S0, ya, yb);               // stage st+1 out of buffer 1, stage st+2 into buffer 0
+    __syncthreads();
+    st += 2;
+  }
+  while (st + 3 < nstages) {                       // the same with checked loads (a ragged last stage, unaligned rows)
+    load_stage(st + 2, no{}, ya, yb);
+    multiply(S0, yes{}, S1, xa, xb);
+    __syncthreads();
+    load_stage(st + 3, no{}, xa, xb);
+    multiply(S1, yes{}, S0, ya, yb);
     __syncthreads();
     st += 2;
   }
   const int left = nstages - st;                   // 1, 2 or 3 stages remain
   if (left == 3) {
-    load_stage(st + 2, ya, yb);
+    load_stage(st + 2, no{}, ya, yb);
     multiply(S0, yes{}, S1, xa, xb);
     __syncthreads();
     multiply(S1, yes{}, S0, ya, yb);
@@ -890,6 +904,17 @@ extern "C" int ctr_set_gemm_mode(int mode) {
 }
 
 extern "C" int ctr_get_gemm_mode(void) { return g_gemm_mode; }
+
+// Diagnostic: resident blocks per CU the runtime grants the 128x128 split-bf16 tile kernel (it is written
+// for two; one means its two-blocks-per-CU overlap of split work and matrix-core work is not happening).
+extern "C" int ctr_gemm_split_blocks_per_cu(void) {
+  const size_t lds = split_lds_bytes(128, 128);
+  const void* fn = reinterpret_cast<const void*>(&gemm_split_kernel<true, false, 128, 128, 2>);
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, lds) != hipSuccess) return -1;
+  return nb;
+}
 
 extern "C" size_t ctr_gemm_f32_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;

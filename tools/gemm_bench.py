@@ -19,6 +19,8 @@ else:
     ('dw0', 429, 256, B, 1, 0), ('dw1', 256, 128, B, 1, 0), ('dw2', 128, 64, B, 1, 0), ('dw3', 64, 32, B, 1, 0),
     ('sq4k', 4096, 4096, 4096, 0, 0),
   ]
+if len(sys.argv) > 2 and sys.argv[1] == 'one':         # a single named shape, for counter passes
+    shapes = [sh for sh in shapes if sh[0] in sys.argv[2:]]
 for name, M, N, K, ta, tb in shapes:
     def mk(r, c):
         ld = (c + 3) // 4 * 4
