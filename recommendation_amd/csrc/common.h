@@ -79,10 +79,34 @@ __device__ static inline float drop_mul(const Drop& d, uint64_t index) {
   return hash24(d.seed, d.stream_id, index) < d.thr ? d.scale : 0.f;
 }
 
+// x + (x of the lane CTRL names inside this lane's row of 16), on the VALU's data-parallel path (no LDS)
+template <int CTRL>
+__device__ static inline float dpp_add(float x) {
+  const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false);
+  return x + __builtin_bit_cast(float, y);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_ROR = 0x120;
+
+// Two values per lane in, one out: lanes 0-31 get a summed over the lane pairs (l, l + 32), lanes 32-63 get b.
+__device__ static inline float half_swap_sum(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+// Even rows of 16 lanes get a summed over the row pairs (0,1) and (2,3), odd rows get b.
+__device__ static inline float row_swap_sum(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
+// Sum over the 64 lanes, the same bits in every lane: four in-row steps on the data-parallel path, then the
+// rows of 16 through two lane-swap instructions (no LDS crossbar traffic).
 __device__ static inline float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v = dpp_add<DPP_XOR1>(v);
+  v = dpp_add<DPP_XOR2>(v);
+  v = dpp_add<DPP_ROR + 4>(v);
+  v = dpp_add<DPP_ROR + 8>(v);
+  v = row_swap_sum(v, v);
+  return half_swap_sum(v, v);
 }
 
 }  // namespace ctr

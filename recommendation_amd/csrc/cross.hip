@@ -11,77 +11,119 @@
 namespace ctr {
 
 constexpr int LMAX = 8;
+constexpr int PREP_THREADS = 1024;
 
-// Bl[l][j] for l = 0..L (prefix sums of b) and q[l] = Bl_l . w_l.  One block.
-__global__ __launch_bounds__(256) void cross_prep_kernel(const float* __restrict__ w, const float* __restrict__ b,
-                                                        int64_t wld, int D, int L, float* __restrict__ Bl,
-                                                        float* __restrict__ q) {
-  __shared__ float red[256];
+// Four consecutive floats row[j .. j+3] of a row of D; vec: the row may be read 16 bytes at a time.
+__device__ static inline float4 row4(const float* __restrict__ row, int j, int D, bool vec) {
+  if (vec && j + 3 < D) return *reinterpret_cast<const float4*>(row + j);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (j < D) v.x = row[j];
+  if (j + 1 < D) v.y = row[j + 1];
+  if (j + 2 < D) v.z = row[j + 2];
+  if (j + 3 < D) v.w = row[j + 3];
+  return v;
+}
+__device__ static inline void put4(float* __restrict__ row, int j, int D, bool vec, float4 v) {
+  if (vec && j + 3 < D) {
+    *reinterpret_cast<float4*>(row + j) = v;
+    return;
+  }
+  if (j < D) row[j] = v.x;
+  if (j + 1 < D) row[j + 1] = v.y;
+  if (j + 2 < D) row[j + 2] = v.z;
+  if (j + 3 < D) row[j + 3] = v.w;
+}
+__device__ static inline bool rows16(const void* p, int64_t ld) { return ((uintptr_t)p % 16) == 0 && ld % 4 == 0; }
+__device__ static inline float dot4(float4 a, float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+
+// Bl[l][j] for l = 0..L (prefix sums of b, rows DP = D rounded up to 4 apart) and q[l] = Bl_l . w_l.  One block.
+__global__ __launch_bounds__(PREP_THREADS) void cross_prep_kernel(const float* __restrict__ w,
+                                                                 const float* __restrict__ b, int64_t wld, int D,
+                                                                 int DP, int L, float* __restrict__ Bl,
+                                                                 float* __restrict__ q) {
+  __shared__ float red[LMAX][PREP_THREADS / 64];
   float qacc[LMAX];
 #pragma unroll
   for (int l = 0; l < LMAX; ++l) qacc[l] = 0.f;
-  for (int j = threadIdx.x; j < D; j += 256) {
+  for (int j = threadIdx.x; j < D; j += PREP_THREADS) {
     float run = 0.f;
-    for (int l = 0; l <= L; ++l) {
-      Bl[(int64_t)l * D + j] = run;
+#pragma unroll
+    for (int l = 0; l <= LMAX; ++l) {
+      if (l <= L) Bl[(int64_t)l * DP + j] = run;
       if (l < L) {
         qacc[l] += run * w[(int64_t)l * wld + j];
         run += b[(int64_t)l * wld + j];
       }
     }
   }
-  for (int l = 0; l < L; ++l) {
-    red[threadIdx.x] = qacc[l];
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) q[l] = red[0];
-    __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l) {
+    const float v = wave_sum(qacc[l]);
+    if (lane == 0) red[l][wave] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < L) {
+    float v = 0.f;
+    for (int k = 0; k < PREP_THREADS / 64; ++k) v += red[threadIdx.x][k];
+    q[threadIdx.x] = v;
   }
 }
 
-template <int NPL>
+// One wave per sample; lane holds columns 256*i + 4*lane .. +3 for i < NQ.  The L dot products x0 . w_l do not
+// depend on the recursion, so they are taken in one sweep over the row in registers and reduced together.
+template <int NQ>
 __global__ __launch_bounds__(256) void cross_fwd_kernel(const float* __restrict__ x0, int64_t x0_ld,
                                                        const float* __restrict__ w, int64_t wld,
-                                                       const float* __restrict__ Bl,
+                                                       const float* __restrict__ Bl, int DP,
                                                        const float* __restrict__ q, int B, int D, int L,
                                                        float* __restrict__ xL, int64_t xL_ld,
                                                        float* __restrict__ aux) {
   const int lane = threadIdx.x & 63;
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
-  float x[NPL];
+  const bool vx = rows16(x0, x0_ld), vw = rows16(w, wld), vo = rows16(xL, xL_ld);
+  const float* xr = x0 + b * x0_ld;
+  float4 x[NQ];
 #pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    const int j = lane + 64 * i;
-    x[i] = j < D ? x0[b * x0_ld + j] : 0.f;
+  for (int i = 0; i < NQ; ++i) x[i] = row4(xr, 256 * i + 4 * lane, D, vx);
+  float p[LMAX];
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l) {
+    p[l] = 0.f;
+    if (l < L) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i)
+        if (256 * i < D) p[l] += dot4(x[i], row4(w + (int64_t)l * wld, 256 * i + 4 * lane, D, vw));
+    }
   }
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l)
+    if (l < L) p[l] = wave_sum(p[l]);
   float c = 1.f;
-  for (int l = 0; l < L; ++l) {
-    float p = 0.f;
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      const int j = lane + 64 * i;
-      if (j < D) p += x[i] * w[(int64_t)l * wld + j];
-    }
-    p = wave_sum(p);
-    const float s = c * p + q[l];
-    c += s;
-    if (lane == 0 && aux) {
-      aux[b * 2 * L + l] = p;
-      aux[b * 2 * L + L + l] = c;  // c_{l+1}
+  for (int l = 0; l < LMAX; ++l) {
+    if (l < L) {
+      const float s = c * p[l] + q[l];
+      c += s;
+      if (lane == 0 && aux) {
+        aux[b * 2 * L + l] = p[l];
+        aux[b * 2 * L + L + l] = c;  // c_{l+1}
+      }
     }
   }
+  float* orow = xL + b * xL_ld;
 #pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    const int j = lane + 64 * i;
-    if (j < D) xL[b * xL_ld + j] = x[i] * c + Bl[(int64_t)L * D + j];
+  for (int i = 0; i < NQ; ++i) {
+    const int j = 256 * i + 4 * lane;
+    if (j < D) {
+      const float4 bl = row4(Bl + (int64_t)L * DP, j, D, true);
+      put4(orow, j, D, vo, make_float4(x[i].x * c + bl.x, x[i].y * c + bl.y, x[i].z * c + bl.z, x[i].w * c + bl.w));
+    }
   }
 }
 
-template <int NPL>
+template <int NQ>
 __global__ __launch_bounds__(256) void cross_bwd_kernel(const float* __restrict__ x0, int64_t x0_ld,
                                                        const float* __restrict__ w, int64_t wld,
                                                        const float* __restrict__ aux,
@@ -91,13 +133,14 @@ __global__ __launch_bounds__(256) void cross_bwd_kernel(const float* __restrict_
   const int lane = threadIdx.x & 63;
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
-  float gv[NPL];
+  const bool vx = rows16(x0, x0_ld), vw = rows16(w, wld), vg = rows16(g, g_ld), vd = rows16(dx0, dx0_ld);
+  float4 gv[NQ];
   float a = 0.f;
 #pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    const int j = lane + 64 * i;
-    gv[i] = j < D ? g[b * g_ld + j] : 0.f;
-    if (j < D) a += gv[i] * x0[b * x0_ld + j];
+  for (int i = 0; i < NQ; ++i) {
+    const int j = 256 * i + 4 * lane;
+    gv[i] = row4(g + b * g_ld, j, D, vg);
+    if (256 * i < D) a += dot4(gv[i], row4(x0 + b * x0_ld, j, D, vx));
   }
   a = wave_sum(a);
   // scalar backward of c_{l+1} = c_l * (1 + p_l) + q_l
@@ -118,43 +161,64 @@ __global__ __launch_bounds__(256) void cross_bwd_kernel(const float* __restrict_
       dc = dc * (1.f + p_l);
     }
   }
+  float* drow = dx0 + b * dx0_ld;
 #pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    const int j = lane + 64 * i;
+  for (int i = 0; i < NQ; ++i) {
+    const int j = 256 * i + 4 * lane;
     if (j < D) {
-      float v = gv[i] * cL;
+      float4 v = make_float4(gv[i].x * cL, gv[i].y * cL, gv[i].z * cL, gv[i].w * cL);
 #pragma unroll
       for (int l = 0; l < LMAX; ++l)
-        if (l < L) v += dp[l] * w[(int64_t)l * wld + j];
-      float* d = dx0 + b * dx0_ld + j;
-      *d = accumulate ? *d + v : v;
+        if (l < L) {
+          const float4 wv = row4(w + (int64_t)l * wld, j, D, vw);
+          v.x += dp[l] * wv.x; v.y += dp[l] * wv.y; v.z += dp[l] * wv.z; v.w += dp[l] * wv.w;
+        }
+      if (accumulate) {
+        const float4 o = row4(drow, j, D, vd);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      put4(drow, j, D, vd, v);
     }
   }
 }
 
-// part[chunk][l][j] = sum_{b in chunk} dp_l[b] * x0[b,j]   (l < L);   part[chunk][L][j] = sum_b g[b,j]
-// grid (ceil(D/64), nchunks), block (64, 4)
+// part[chunk][l][j] = sum_{b in chunk} dp_l[b] * x0[b,j]   (l < L);   part[chunk][L][j] = sum_b g[b,j];
+// psdq[chunk][l] = sum_{b in chunk} dq_l[b] (written by the blocks of the first column group).
+// grid (ceil(D/256), nchunks), block 256 = 4 waves over the chunk's rows; a lane owns four consecutive columns
 __global__ __launch_bounds__(256) void cross_bwd_partial_kernel(const float* __restrict__ x0, int64_t x0_ld,
                                                                const float* __restrict__ g, int64_t g_ld,
-                                                               const float* __restrict__ dpq, int B, int D,
+                                                               const float* __restrict__ dpq, int B, int D, int DP,
                                                                int L, int rows_per_chunk,
-                                                               float* __restrict__ part) {
-  __shared__ float red[4][64];
+                                                               float* __restrict__ part, float* __restrict__ psdq) {
+  __shared__ float4 red[4][64];
+  __shared__ float sred[4][LMAX];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + tx;
+  const int j = blockIdx.x * 256 + 4 * tx;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
   const int64_t r1 = r0 + rows_per_chunk < B ? r0 + rows_per_chunk : B;
-  float acc[LMAX + 1];
+  const bool vx = rows16(x0, x0_ld), vg = rows16(g, g_ld);
+  float4 acc[LMAX + 1];
+  float sdq[LMAX];
 #pragma unroll
-  for (int l = 0; l <= LMAX; ++l) acc[l] = 0.f;
-  if (j < D) {
-    for (int64_t r = r0 + ty; r < r1; r += 4) {
-      const float xv = x0[r * x0_ld + j];
+  for (int l = 0; l <= LMAX; ++l) acc[l] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int l = 0; l < LMAX; ++l)
-        if (l < L) acc[l] += dpq[r * 2 * L + l] * xv;
-      acc[LMAX] += g[r * g_ld + j];
-    }
+  for (int l = 0; l < LMAX; ++l) sdq[l] = 0.f;
+  for (int64_t r = r0 + ty; r < r1; r += 8) {      // two rows in flight per wave
+    const int64_t rb = r + 4 < r1 ? r + 4 : r;
+    const float wb = r + 4 < r1 ? 1.f : 0.f;
+    const float4 xa = row4(x0 + r * x0_ld, j, D, vx), xb = row4(x0 + rb * x0_ld, j, D, vx);
+    const float4 ga = row4(g + r * g_ld, j, D, vg), gb = row4(g + rb * g_ld, j, D, vg);
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l)
+      if (l < L) {
+        const float da = dpq[r * 2 * L + l], db = dpq[rb * 2 * L + l] * wb;
+        acc[l].x += da * xa.x; acc[l].y += da * xa.y; acc[l].z += da * xa.z; acc[l].w += da * xa.w;
+        acc[l].x += db * xb.x; acc[l].y += db * xb.y; acc[l].z += db * xb.z; acc[l].w += db * xb.w;
+        sdq[l] += dpq[r * 2 * L + L + l];
+        sdq[l] += dpq[rb * 2 * L + L + l] * wb;
+      }
+    acc[LMAX].x += ga.x; acc[LMAX].y += ga.y; acc[LMAX].z += ga.z; acc[LMAX].w += ga.w;
+    acc[LMAX].x += gb.x * wb; acc[LMAX].y += gb.y * wb; acc[LMAX].z += gb.z * wb; acc[LMAX].w += gb.w * wb;
   }
 #pragma unroll
   for (int l = 0; l <= LMAX; ++l) {
@@ -163,59 +227,78 @@ __global__ __launch_bounds__(256) void cross_bwd_partial_kernel(const float* __r
       __syncthreads();
       if (ty == 0 && j < D) {
         const int slot = l == LMAX ? L : l;
-        part[((int64_t)blockIdx.y * (L + 1) + slot) * D + j] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        const float4 a0 = red[0][tx], a1 = red[1][tx], a2 = red[2][tx], a3 = red[3][tx];
+        put4(part + ((int64_t)blockIdx.y * (L + 1) + slot) * DP, j, D, true,
+             make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                         (a0.w + a1.w) + (a2.w + a3.w)));
       }
       __syncthreads();
     }
   }
-}
-
-// sdq[l] = sum_b dq_l[b]; one block, fixed order.
-__global__ __launch_bounds__(256) void cross_bwd_sdq_kernel(const float* __restrict__ dpq, int B, int L,
-                                                           float* __restrict__ sdq) {
-  __shared__ float red[256];
-  for (int l = 0; l < L; ++l) {
-    float acc = 0.f;
-    for (int b = threadIdx.x; b < B; b += 256) acc += dpq[(int64_t)b * 2 * L + L + l];
-    red[threadIdx.x] = acc;
+  if (blockIdx.x == 0) {
+    if (tx == 0)
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) sred[ty][l] = sdq[l];
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) sdq[l] = red[0];
-    __syncthreads();
+    if ((int)threadIdx.x < L)
+      psdq[(int64_t)blockIdx.y * LMAX + threadIdx.x] =
+          (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
   }
 }
 
-__global__ __launch_bounds__(256) void cross_bwd_final_kernel(const float* __restrict__ part, int nchunks,
+// Sums the chunk partials in a fixed order and finishes dw / db.  Block = 64 columns x 4 chunk groups.
+__global__ __launch_bounds__(256) void cross_bwd_final_kernel(const float* __restrict__ part,
+                                                             const float* __restrict__ psdq, int nchunks,
                                                              const float* __restrict__ w, int64_t wld,
-                                                             const float* __restrict__ Bl,
-                                                             const float* __restrict__ sdq, int D, int L,
+                                                             const float* __restrict__ Bl, int D, int DP, int L,
                                                              float* __restrict__ dw, float* __restrict__ db) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= D) return;
-  float gsum = 0.f;
-  for (int c = 0; c < nchunks; ++c) gsum += part[((int64_t)c * (L + 1) + L) * D + j];
+  __shared__ float red[4][LMAX + 1][64];
+  __shared__ float sdq[LMAX];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + tx;
+  if (ty < 2) {                                    // waves 0 and 1 each total four of the dq sums over the chunks
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int l = ty * 4 + u;
+      float v = 0.f;
+      if (l < L)
+        for (int c = tx; c < nchunks; c += 64) v += psdq[(int64_t)c * LMAX + l];
+      v = wave_sum(v);
+      if (tx == 0) sdq[l] = v;
+    }
+  }
+  float acc[LMAX + 1];
+#pragma unroll
+  for (int l = 0; l <= LMAX; ++l) acc[l] = 0.f;
+  if (j < D)
+    for (int c = ty; c < nchunks; c += 4) {
+#pragma unroll
+      for (int l = 0; l <= LMAX; ++l)
+        if (l <= L) acc[l] += part[((int64_t)c * (L + 1) + l) * DP + j];
+    }
+#pragma unroll
+  for (int l = 0; l <= LMAX; ++l) red[ty][l][tx] = acc[l];
+  __syncthreads();
+  if (ty != 0 || j >= D) return;
   // dBl_L = colsum(g); dBl_l = sdq_l * w_l (l < L); db_l' = sum_{l > l'} dBl_l
-  float run = gsum;
+  float run = (red[0][L][tx] + red[1][L][tx]) + (red[2][L][tx] + red[3][L][tx]);
   for (int l = L - 1; l >= 0; --l) {
     db[(int64_t)l * wld + j] = run;
     run += sdq[l] * w[(int64_t)l * wld + j];
-    float acc = 0.f;
-    for (int c = 0; c < nchunks; ++c) acc += part[((int64_t)c * (L + 1) + l) * D + j];
-    dw[(int64_t)l * wld + j] = acc + sdq[l] * Bl[(int64_t)l * D + j];
+    const float a = (red[0][l][tx] + red[1][l][tx]) + (red[2][l][tx] + red[3][l][tx]);
+    dw[(int64_t)l * wld + j] = a + sdq[l] * Bl[(int64_t)l * DP + j];
   }
 }
 
 static int cross_chunks(int B) {
-  int64_t n = cdiv(B, 256);
+  int64_t n = cdiv(B, 64);
   if (n < 1) n = 1;
-  if (n > 512) n = 512;
+  if (n > 256) n = 256;
   return (int)n;
 }
 
-static size_t cross_prep_floats(int D, int L) { return align_up((size_t)(L + 1) * D + LMAX, 64); }
+static int cross_dp(int D) { return (D + 3) / 4 * 4; }   // row stride of the workspace's own [.., D] arrays
+static size_t cross_prep_floats(int D, int L) { return align_up((size_t)(L + 1) * cross_dp(D) + LMAX, 64); }
 
 }  // namespace ctr
 
@@ -224,20 +307,20 @@ using namespace ctr;
 extern "C" size_t ctr_cross_fwd_workspace_bytes(int D, int L) { return cross_prep_floats(D, L) * sizeof(float); }
 
 extern "C" size_t ctr_cross_bwd_workspace_bytes(int B, int D, int L) {
-  return (cross_prep_floats(D, L) + align_up((size_t)B * 2 * L, 64) + 64 +
-          (size_t)cross_chunks(B) * (L + 1) * D) * sizeof(float);
+  return (cross_prep_floats(D, L) + align_up((size_t)B * 2 * L, 64) + (size_t)cross_chunks(B) * LMAX +
+          (size_t)cross_chunks(B) * (L + 1) * cross_dp(D)) * sizeof(float);
 }
 
 #define CROSS_DISPATCH(KERNEL, ...)                                                              \
   do {                                                                                           \
-    const int npl = (int)cdiv(D, 64);                                                            \
+    const int nq = (int)cdiv(D, 256);                                                            \
     const dim3 grid((unsigned)cdiv(B, 4)), block(256);                                           \
-    if (npl <= 4) hipLaunchKernelGGL(KERNEL<4>, grid, block, 0, st, __VA_ARGS__);                \
-    else if (npl <= 8) hipLaunchKernelGGL(KERNEL<8>, grid, block, 0, st, __VA_ARGS__);           \
-    else if (npl <= 16) hipLaunchKernelGGL(KERNEL<16>, grid, block, 0, st, __VA_ARGS__);         \
-    else if (npl <= 32) hipLaunchKernelGGL(KERNEL<32>, grid, block, 0, st, __VA_ARGS__);         \
-    else if (npl <= 64) hipLaunchKernelGGL(KERNEL<64>, grid, block, 0, st, __VA_ARGS__);         \
-    else hipLaunchKernelGGL(KERNEL<128>, grid, block, 0, st, __VA_ARGS__);                       \
+    if (nq <= 1) hipLaunchKernelGGL(KERNEL<1>, grid, block, 0, st, __VA_ARGS__);                 \
+    else if (nq <= 2) hipLaunchKernelGGL(KERNEL<2>, grid, block, 0, st, __VA_ARGS__);            \
+    else if (nq <= 4) hipLaunchKernelGGL(KERNEL<4>, grid, block, 0, st, __VA_ARGS__);            \
+    else if (nq <= 8) hipLaunchKernelGGL(KERNEL<8>, grid, block, 0, st, __VA_ARGS__);            \
+    else if (nq <= 16) hipLaunchKernelGGL(KERNEL<16>, grid, block, 0, st, __VA_ARGS__);          \
+    else hipLaunchKernelGGL(KERNEL<32>, grid, block, 0, st, __VA_ARGS__);                        \
   } while (0)
 
 extern "C" int ctr_cross_fwd(const float* x0, int64_t x0_ld, const float* w, const float* b, int64_t wld,
@@ -253,10 +336,11 @@ extern "C" int ctr_cross_fwd(const float* x0, int64_t x0_ld, const float* w, con
     return CTR_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  const int DP = cross_dp(D);
   float* Bl = (float*)workspace;
-  float* q = Bl + (size_t)(L + 1) * D;
-  hipLaunchKernelGGL(cross_prep_kernel, dim3(1), dim3(256), 0, st, w, b, wld, D, L, Bl, q);
-  CROSS_DISPATCH(cross_fwd_kernel, x0, x0_ld, w, wld, Bl, q, B, D, L, xL, xL_ld, aux_out);
+  float* q = Bl + (size_t)(L + 1) * DP;
+  hipLaunchKernelGGL(cross_prep_kernel, dim3(1), dim3(PREP_THREADS), 0, st, w, b, wld, D, DP, L, Bl, q);
+  CROSS_DISPATCH(cross_fwd_kernel, x0, x0_ld, w, wld, Bl, DP, q, B, D, L, xL, xL_ld, aux_out);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
@@ -274,20 +358,20 @@ extern "C" int ctr_cross_bwd(const float* x0, int64_t x0_ld, const float* w, con
     return CTR_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  float* Bl = (float*)workspace;
-  float* q = Bl + (size_t)(L + 1) * D;
-  float* dpq = Bl + cross_prep_floats(D, L);
-  float* sdq = dpq + align_up((size_t)B * 2 * L, 64);
-  float* part = sdq + 64;
+  const int DP = cross_dp(D);
   const int nchunks = cross_chunks(B);
   const int rows_per_chunk = (int)cdiv(B, nchunks);
-  hipLaunchKernelGGL(cross_prep_kernel, dim3(1), dim3(256), 0, st, w, b, wld, D, L, Bl, q);
+  float* Bl = (float*)workspace;
+  float* q = Bl + (size_t)(L + 1) * DP;
+  float* dpq = Bl + cross_prep_floats(D, L);
+  float* psdq = dpq + align_up((size_t)B * 2 * L, 64);
+  float* part = psdq + (size_t)nchunks * LMAX;
+  hipLaunchKernelGGL(cross_prep_kernel, dim3(1), dim3(PREP_THREADS), 0, st, w, b, wld, D, DP, L, Bl, q);
   CROSS_DISPATCH(cross_bwd_kernel, x0, x0_ld, w, wld, aux, g, g_ld, B, D, L, dx0, dx0_ld, accumulate, dpq);
-  hipLaunchKernelGGL(cross_bwd_partial_kernel, dim3((unsigned)cdiv(D, 64), nchunks), dim3(256), 0, st, x0,
-                     x0_ld, g, g_ld, dpq, B, D, L, rows_per_chunk, part);
-  hipLaunchKernelGGL(cross_bwd_sdq_kernel, dim3(1), dim3(256), 0, st, dpq, B, L, sdq);
-  hipLaunchKernelGGL(cross_bwd_final_kernel, dim3((unsigned)cdiv(D, 256)), dim3(256), 0, st, part, nchunks, w,
-                     wld, Bl, sdq, D, L, dw, db);
+  hipLaunchKernelGGL(cross_bwd_partial_kernel, dim3((unsigned)cdiv(D, 256), nchunks), dim3(256), 0, st, x0,
+                     x0_ld, g, g_ld, dpq, B, D, DP, L, rows_per_chunk, part, psdq);
+  hipLaunchKernelGGL(cross_bwd_final_kernel, dim3((unsigned)cdiv(D, 64)), dim3(256), 0, st, part, psdq, nchunks, w,
+                     wld, Bl, D, DP, L, dw, db);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }

@@ -8,14 +8,6 @@ namespace ctr {
 
 __device__ static inline float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// x + (x of the lane CTRL names inside this lane's row of 16), on the VALU's data-parallel path (no LDS)
-template <int CTRL>
-__device__ static inline float dpp_add(float x) {
-  const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false);
-  return x + __builtin_bit_cast(float, y);
-}
-constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_ROR = 0x120;
-
 // Sum over the lanes that share lane % G inside a row of 16 lanes (G <= 16); every lane gets a total.
 template <int G>
 __device__ static inline float row_stride_sum(float x) {
@@ -24,17 +16,6 @@ __device__ static inline float row_stride_sum(float x) {
   if (G <= 4) x = dpp_add<DPP_ROR + 4>(x);
   if (G <= 8) x = dpp_add<DPP_ROR + 8>(x);
   return x;
-}
-
-// Two values per lane in, one out: lanes 0-31 get a summed over the lane pairs (l, l + 32), lanes 32-63 get b.
-__device__ static inline float half_swap_sum(float a, float b) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
-  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-}
-// Even rows of 16 lanes get a summed over the row pairs (0,1) and (2,3), odd rows get b.
-__device__ static inline float row_swap_sum(float a, float b) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
-  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
 
 // DENSE: Z already sits in z_out (N = F rows per sample); only the reductions are computed.

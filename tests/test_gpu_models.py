@@ -83,8 +83,10 @@ def test_deepfm_smode_lazy_adam_matches_dense_on_touched_rows(sess):
     for _ in range(3):
         m1.run(sess, Xc, Xf, y, True)
         m2.run(sess, Xc, Xf, y, True)
+    # the row-wise and the whole-table update kernels are compiled separately (different fma contraction):
+    # equal to the last bit or two, not bitwise
     for (k, a), b in zip(m1.get_params().items(), m2.get_params().values()):
-        assert np.array_equal(a, b), k
+        assert np.allclose(a, b, rtol=1e-6, atol=1e-8), k
 
 
 def test_deepfm_dropout_masks_match_hash(sess):
