@@ -916,10 +916,37 @@ extern "C" int ctr_gemm_split_blocks_per_cu(void) {
   return nb;
 }
 
+namespace ctr {
+// out[k][n] = in[n][k]: a weight matrix stored k-contiguous becomes n-contiguous (32x32 tiles through LDS)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int64_t ldi, int N, int K,
+                                                       float* __restrict__ out, int64_t ldo) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8)
+    if (n0 + r < N && k0 + tx < K) tile[r][tx] = in[(int64_t)(n0 + r) * ldi + k0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8)
+    if (k0 + r < K && n0 + tx < N) out[(int64_t)(k0 + r) * ldo + n0 + tx] = tile[tx][r];
+}
+}  // namespace ctr
+
+// A k-contiguous B (trans_b) costs the tile kernels 64-byte row pieces at a row stride apart; when B is a
+// large square-ish weight matrix (small next to M rows of A) it is turned once into the n-contiguous layout
+// first.  Measured: 8192x1024x1024 gains 19%; short K (<= 256) and ragged N (429, 1677) lose to the extra launch.
+static bool pretranspose_b(int M, int N, int K) {
+  return M >= 2048 && (int64_t)N * K <= (int64_t)1 << 23 && N >= 512 && N % 128 == 0 && K >= 512;
+}
+static size_t bt_floats(int N, int K) { return (size_t)K * (size_t)((N + 3) / 4 * 4); }
+
 extern "C" size_t ctr_gemm_f32_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const Plan p = make_plan(M, N, K);
-  return p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+  size_t need = p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+  if (pretranspose_b(M, N, K)) need = align_up(need, 256) + bt_floats(N, K) * sizeof(float);
+  return need;
 }
 
 extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float* A, int64_t lda,
@@ -978,6 +1005,18 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
       return CTR_EWORKSPACE;
     }
     partial = (float*)workspace;
+  }
+  if (trans_b && !trans_a && g_gemm_mode == CTR_GEMM_SPLIT_BF16 && pretranspose_b(M, N, K) && workspace) {
+    const size_t off = align_up(partial ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0, 256);
+    if (workspace_bytes >= off + bt_floats(N, K) * sizeof(float)) {   // else: the direct path below
+      float* Bt = reinterpret_cast<float*>(static_cast<char*>(workspace) + off);
+      const int64_t ldt = (N + 3) / 4 * 4;
+      hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)cdiv(K, 32), (unsigned)cdiv(N, 32)), dim3(256), 0, st, B,
+                         ldb, N, K, Bt, ldt);
+      B = Bt;
+      ldb = ldt;
+      trans_b = 0;
+    }
   }
   const bool vecA = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0);
   const bool vecB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
