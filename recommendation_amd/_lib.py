@@ -83,6 +83,9 @@ SIGNATURES = {
     'ctr_set_gemm_mode': (i, [i]),
     'ctr_get_gemm_mode': (i, []),
     'ctr_gemm_split_blocks_per_cu': (i, []),
+    'ctr_unit_bwd_supported': (i, [i]),
+    'ctr_unit_bwd_workspace_bytes': (sz, [i, i]),
+    'ctr_unit_bwd': (i, [i, i, vp, vp, vp, i64, vp, i64, i, f, vp, vp, vp, sz, vp]),
     'ctr_mlp_chain_supported': (i, [i, i, i, i]),
     'ctr_mlp_chain_fwd': (i, [i, i, vp, i64, i, vp, vp, DP, vp, i64, i, vp, vp, DP, vp, i64, i, vp, vp, DP, vp, i64, vp]),
     'ctr_auc_workspace_bytes': (sz, [i64]),

@@ -292,6 +292,129 @@ extern "C" int ctr_rowdot_bwd_x(const float* g, const float* w, int B, int K, fl
   return CTR_OK;
 }
 
+namespace ctr {
+constexpr int UB_KMAX = 255;             // columns the fused output-unit backward covers (one thread each, + bias slot)
+constexpr int UB_BLOCKS = 1024;
+constexpr int UB_U = 8;                  // steps in flight per thread
+
+// Backward of the output unit y = X w + b in one pass over X (DeepFM/DeepFM.py:82-88):
+//   dX[b,k] = dl[b] * w[k]  (times mask_scale * [X[b,k] > 0] for k >= mask_from: the relu + dropout of the
+//   tower's last layer, whose output is that column range of X),  dw[k] = sum_b X[b,k] dl[b],  db = sum_b dl[b].
+// A block owns a contiguous range of samples; thread t works on column t % K of sample row t / K of each step
+// (256 / K samples per step, so a step reads and writes one contiguous piece of X and dX), keeps the dw term
+// of its column in a register, and the block folds its row slots in LDS into one partial row.
+__global__ __launch_bounds__(256) void unit_bwd_kernel(int B, int K, const float* __restrict__ dl,
+                                                      const float* __restrict__ w, const float* __restrict__ X,
+                                                      int64_t ldx, float* __restrict__ dX, int64_t lddx,
+                                                      int mask_from, float mask_scale, int rows_per_block,
+                                                      float* __restrict__ part) {
+  __shared__ float red[256], dred[256];
+  const int rps = 256 / K;                          // sample rows per step
+  const int r = threadIdx.x / K, k = threadIdx.x - r * K;
+  const bool on = r < rps;
+  const float wv = on ? w[k] : 0.f;
+  const bool masked = k >= mask_from;
+  const int64_t b0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t b1 = b0 + rows_per_block < B ? b0 + rows_per_block : B;
+  float acc = 0.f, dsum = 0.f;
+  if (on) {
+    for (int64_t b = b0 + r; b < b1; b += UB_U * rps) {
+      float x[UB_U], d[UB_U];
+#pragma unroll
+      for (int u = 0; u < UB_U; ++u) {
+        const int64_t bb = b + u * rps;
+        const bool live = bb < b1;
+        x[u] = live ? X[bb * ldx + k] : 0.f;
+        d[u] = live ? dl[bb] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < UB_U; ++u) {
+        const int64_t bb = b + u * rps;
+        acc += x[u] * d[u];
+        if (k == 0) dsum += d[u];
+        float g = d[u] * wv;
+        if (masked) g = x[u] > 0.f ? g * mask_scale : 0.f;
+        if (bb < b1) dX[bb * lddx + k] = g;
+      }
+    }
+  }
+  red[threadIdx.x] = acc;
+  dred[threadIdx.x] = dsum;
+  __syncthreads();
+  if ((int)threadIdx.x <= K) {
+    float v = 0.f;
+    if ((int)threadIdx.x < K) {
+      for (int q = 0; q < rps; ++q) v += red[q * K + threadIdx.x];
+    } else {
+      for (int q = 0; q < rps; ++q) v += dred[q * K];
+    }
+    part[(int64_t)blockIdx.x * (K + 1) + threadIdx.x] = v;
+  }
+}
+
+// out[k] = sum over the partial rows in a fixed order; column K is the bias gradient
+__global__ __launch_bounds__(1024) void unit_bwd_final_kernel(const float* __restrict__ part, int nrows, int K,
+                                                             float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float red[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 16 row phases
+  const int k = blockIdx.x * 64 + tx;
+  float acc = 0.f;
+  if (k <= K) {
+    int r = ty;
+    for (; r + 7 * 16 < nrows; r += 8 * 16) {               // eight loads in flight
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(r + 16 * u) * (K + 1) + k];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; r < nrows; r += 16) acc += part[(int64_t)r * (K + 1) + k];
+  }
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && k <= K) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += red[q][tx];
+    if (k < K) dw[k] = v;
+    else if (db) db[0] = v;
+  }
+}
+}  // namespace ctr
+
+static int unit_bwd_rows_per_block(int B) {
+  const int64_t rows = cdiv(B > 0 ? B : 1, UB_BLOCKS);
+  return (int)(rows < 32 ? 32 : rows);
+}
+static int unit_bwd_blocks(int B) { return (int)cdiv(B > 0 ? B : 1, unit_bwd_rows_per_block(B)); }
+
+extern "C" int ctr_unit_bwd_supported(int K) { return K >= 1 && K <= UB_KMAX; }
+
+extern "C" size_t ctr_unit_bwd_workspace_bytes(int B, int K) {
+  return (size_t)unit_bwd_blocks(B) * (size_t)(K + 1) * sizeof(float);
+}
+
+extern "C" int ctr_unit_bwd(int B, int K, const float* dl, const float* w, const float* X, int64_t ldx, float* dX,
+                            int64_t lddx, int mask_from, float mask_scale, float* dw, float* db, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  CTR_REQUIRE(B > 0 && ctr_unit_bwd_supported(K), "ctr_unit_bwd: need B > 0 and 1 <= K <= %d", UB_KMAX);
+  CTR_REQUIRE(dl && w && X && dX && dw && workspace, "ctr_unit_bwd: null pointer");
+  CTR_REQUIRE(ldx >= K && lddx >= K, "ctr_unit_bwd: leading dimension < K");
+  if (workspace_bytes < ctr_unit_bwd_workspace_bytes(B, K)) {
+    set_error("ctr_unit_bwd: workspace %zu < %zu", workspace_bytes, ctr_unit_bwd_workspace_bytes(B, K));
+    return CTR_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = unit_bwd_blocks(B);
+  float* part = (float*)workspace;
+  if (mask_from < 0 || mask_from > K) mask_from = K;
+  hipLaunchKernelGGL(unit_bwd_kernel, dim3(nb), dim3(256), 0, st, B, K, dl, w, X, ldx, dX, lddx, mask_from, mask_scale,
+                     unit_bwd_rows_per_block(B), part);
+  hipLaunchKernelGGL(unit_bwd_final_kernel, dim3((unsigned)cdiv(K + 1, 64)), dim3(1024), 0, st, part, nb, K, dw, db);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
 extern "C" size_t ctr_loss_head_workspace_bytes(int B) { return (size_t)cdiv(B > 0 ? B : 1, 256) * sizeof(float); }
 
 extern "C" int ctr_loss_head(int kind, const float* x, const float* y, int B, float grad_scale, float* y_out,

@@ -224,13 +224,15 @@ class Tower:
                     break
         return self._chain
 
-    def backward(self, x, acts, g_last, gbufs, rates, dx, ws, accumulate_dx=False):
-        """g_last: gradient w.r.t. acts[-1] (post relu+dropout); it is masked in place.
+    def backward(self, x, acts, g_last, gbufs, rates, dx, ws, accumulate_dx=False, g_last_masked=False):
+        """g_last: gradient w.r.t. acts[-1] (post relu+dropout); it is masked in place unless the caller
+        already did (g_last_masked).
         gbufs[i]: scratch [B, L_i] for i < n-1.  dx (optional): [B, >= d_in] receives dL/dx
         (added to its content when accumulate_dx)."""
         n = len(self.names)
         scale = [1.0 / (1.0 - r) if r else 1.0 for r in rates]
-        ops.relu_mask_apply(g_last, acts[n - 1], scale[n - 1])
+        if not g_last_masked:
+            ops.relu_mask_apply(g_last, acts[n - 1], scale[n - 1])
         g = g_last
         for i in range(n - 1, -1, -1):
             wn, bn = self.names[i]

@@ -256,6 +256,25 @@ def sort_pairs(keys, vals, key_bits, ws):
     return ko, vo
 
 
+def unit_bwd_supported(K):
+    return bool(lib().ctr_unit_bwd_supported(int(K)))
+
+
+@_timed
+def unit_bwd(dl, w, x, dx, dw, db, *, mask_from=-1, mask_scale=1.0, ws):
+    """Backward of the output unit y = x w + b: dx = dl w^T (relu/dropout-masked from column mask_from on),
+    dw = x^T dl, db = sum dl, one pass over x."""
+    B, K = x.shape
+    if dl.numel() != B or w.numel() != K or dw.numel() != K or tuple(dx.shape) != (B, K):
+        raise ValueError('unit_bwd: shapes disagree')
+    xp, ldx = _rows(x, 'x')
+    dp, ldd = _rows(dx, 'dx')
+    wp, wn = ws.get(lib().ctr_unit_bwd_workspace_bytes(B, K))
+    check(lib().ctr_unit_bwd(B, K, _ptr(dl, torch.float32), _ptr(w, torch.float32), xp, ldx, dp, ldd, int(mask_from),
+                             float(mask_scale), _ptr(dw, torch.float32), _ptr(db, torch.float32), wp, wn, _stream()),
+          'ctr_unit_bwd')
+
+
 def mlp_chain_supported(K0, widths):
     n3 = widths[2] if len(widths) > 2 else 0
     return len(widths) in (2, 3) and bool(lib().ctr_mlp_chain_supported(int(K0), int(widths[0]), int(widths[1]), int(n3)))

@@ -61,10 +61,17 @@ class DeepFM(CTRModel):
         ws = self.session.ws
         concat, dconcat, dl = bufs['concat'], bufs['dconcat'], bufs['dlogit']
         wn, bn = 'output_unit/output_w_%d' % (n - 1), 'output_unit/output_b_%d' % (n - 1)
-        ops.rowdot_bwd_x(dl, self.dense.p(wn).reshape(-1), dconcat)
-        ops.dense_wgrad(concat, dl.view(B, 1), self.dense.g(wn), self.dense.g(bn), ws=ws)
+        fused = ops.unit_bwd_supported(self.concat_width)
+        if fused:   # output unit backward + the last tower layer's relu/dropout mask in one pass over concat
+            keep = 1.0 - self.dropout_deep
+            ops.unit_bwd(dl, self.dense.p(wn).reshape(-1), concat, dconcat, self.dense.g(wn).reshape(-1),
+                         self.dense.g(bn).reshape(-1), mask_from=N + E, mask_scale=1.0 / keep if keep < 1.0 else 1.0,
+                         ws=ws)
+        else:
+            ops.rowdot_bwd_x(dl, self.dense.p(wn).reshape(-1), dconcat)
+            ops.dense_wgrad(concat, dl.view(B, 1), self.dense.g(wn), self.dense.g(bn), ws=ws)
         self.tower.backward(bufs['x0'], bufs['acts'], dconcat[:, N + E:], bufs['gbufs'],
-                            [self.dropout_deep] * n, bufs['dx0'], ws)
+                            [self.dropout_deep] * n, bufs['dx0'], ws, g_last_masked=fused)
         ops.embed_bwd_dz(bufs['dx0'], B=B, N=N, E=E, gz=bufs['dx0'], g_first=dconcat[:, :N],
                          g_second=dconcat[:, N:N + E], s=bufs['s'], z=bufs['x0'],
                          drop_first=self._drop(self.dropout_fm, 1, True),

@@ -434,3 +434,26 @@ def test_chained_tower_layers_match_layer_by_layer_gemms(ops_ws, M, K0, widths, 
     assert (big[:, :4] == 5.0).all() and (big[:, c:] == 5.0).all()
     if M % 2:
         assert (big[:, c - widths[-1] - 3:c - widths[-1]] == 5.0).all()
+
+
+@pytest.mark.parametrize('B,K,mask_from', [(1000, 74, 42), (65, 255, -1), (4099, 17, 0), (3, 1, 1)])
+def test_fused_output_unit_backward(ops_ws, B, K, mask_from):
+    """dX = dl w^T with the relu/dropout mask on the tail columns, dw = X^T dl, db = sum dl, in one pass"""
+    ops, ws = ops_ws
+    rng = np.random.default_rng(B + K)
+    x = rng.standard_normal((B, K)).astype(np.float32)
+    dl = (rng.standard_normal(B) / B).astype(np.float32)
+    w = rng.standard_normal(K).astype(np.float32)
+    xd = torch.zeros(B, K + 3, device=DEV)
+    xd[:, :K] = dev(x)
+    dxd = torch.full((B, K + 5), 7.0, device=DEV)
+    dw, db = torch.zeros(K, device=DEV), torch.zeros(1, device=DEV)
+    assert ops.unit_bwd_supported(K) and not ops.unit_bwd_supported(256)
+    ops.unit_bwd(dev(dl), dev(w), xd[:, :K], dxd[:, :K], dw, db, mask_from=mask_from, mask_scale=1.25, ws=ws)
+    ref = dl[:, None].astype(np.float64) * w[None, :]
+    if mask_from >= 0:
+        ref[:, mask_from:] *= np.where(x[:, mask_from:] > 0, 1.25, 0.0)
+    assert rel_err(dxd[:, :K].cpu().numpy(), ref) < 1e-6
+    assert (dxd[:, K:] == 7.0).all()
+    assert rel_err(dw.cpu().numpy(), x.astype(np.float64).T @ dl) < 1e-5
+    assert abs(float(db.item()) - float(dl.astype(np.float64).sum())) < 1e-6
