@@ -804,14 +804,16 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(int M, int N, int K, 
   }
 }
 
-// out[j] (+)= sum over slabs of part[s*cols + j]; block (64,4): slab phase ty takes slabs ty, ty+4, ...
-// eight loads in flight per thread; the four phases are added in a fixed order
+// out[j] (+)= sum over slabs of part[s*cols + j]; block (64,16): slab phase ty takes slabs ty, ty+16, ...
+// eight loads in flight per thread; the sixteen phases are added in a fixed order.  (Hundreds of slabs over
+// four phases made this launch as long as the GEMM that fed it.)
 // A second problem (part2, cols2, out2) rides in the same launch on the blocks past the first one's.
-__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ part, int nslabs, int cols,
-                                                      float* __restrict__ out, int accumulate,
-                                                      const float* __restrict__ part2, int cols2,
-                                                      float* __restrict__ out2) {
-  __shared__ float red[4][64];
+constexpr int SLAB_PH = 16;
+__global__ __launch_bounds__(64 * SLAB_PH) void slab_sum_kernel(const float* __restrict__ part, int nslabs, int cols,
+                                                               float* __restrict__ out, int accumulate,
+                                                               const float* __restrict__ part2, int cols2,
+                                                               float* __restrict__ out2) {
+  __shared__ float red[SLAB_PH][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   int bx = blockIdx.x;
   const int nb1 = (cols + 63) / 64;
@@ -820,19 +822,21 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
   float acc = 0.f;
   if (j < cols) {
     int s = ty;
-    for (; s + 28 < nslabs; s += 32) {
+    for (; s + 7 * SLAB_PH < nslabs; s += 8 * SLAB_PH) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(s + 4 * u) * cols + j];
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(s + SLAB_PH * u) * cols + j];
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += v[u];
     }
-    for (; s < nslabs; s += 4) acc += part[(int64_t)s * cols + j];
+    for (; s < nslabs; s += SLAB_PH) acc += part[(int64_t)s * cols + j];
   }
   red[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && j < cols) {
-    const float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < SLAB_PH; ++q) v += red[q][tx];
     out[j] = accumulate ? out[j] + v : v;
   }
 }
@@ -1147,7 +1151,7 @@ extern "C" int ctr_dense_wgrad(int M, int N, int K, const float* A, int64_t lda,
     else
       hipLaunchKernelGGL(wgrad_colsum_partial<false>, dim3((unsigned)cdiv(N, 64), nchunks), dim3(256), 0, st, B, ldb,
                          K, N, rows_per_chunk, part);
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, part, nchunks, N, db, 0,
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv(N, 64)), dim3(64 * SLAB_PH), 0, st, part, nchunks, N, db, 0,
                        (const float*)nullptr, 0, (float*)nullptr);
     CTR_LAUNCH_CHECK();
     return CTR_OK;
@@ -1166,7 +1170,7 @@ extern "C" int ctr_dense_wgrad(int M, int N, int K, const float* A, int64_t lda,
   else WLAUNCH(1, 1);
 #undef WLAUNCH
   // one launch adds the dW slabs and, on its last blocks, the bias slabs
-  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)(cdiv((int64_t)M * N, 64) + (db ? cdiv(N, 64) : 0))), dim3(256), 0,
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)(cdiv((int64_t)M * N, 64) + (db ? cdiv(N, 64) : 0))), dim3(64 * SLAB_PH), 0,
                      st, part, p.nkb, M * N, dW, 0, (const float*)bias_part, N, db);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
