@@ -109,6 +109,178 @@ __global__ __launch_bounds__(256) void pnn_inner_kernel(const float* __restrict_
   }
 }
 
+// The same term for E = 16 with every contraction on the matrix cores.  One wave per sample:
+//   u = W Z      : A = W fragments (registers, loaded once per wave), B = Z straight from global memory -
+//                  lane (k-slot g, column l16) reads Z[4s + g][l16], a contiguous 256 bytes per step;
+//   dZ = W^T du  : the accumulator layout of u (lane holds rows p = 16m + 4g + r of column e = l16) IS a B
+//                  operand when the contraction index p is walked in the order (m, r) with k-slot g, so du
+//                  never moves; A = W^T fragments gathered in that order once per wave;
+//   dW += du Z^T : contraction over e needs both operands transposed: du and Z go through a wave-private
+//                  LDS tile once per sample.
+// PT, NT: 16-row tiles of p and of n.
+template <bool BWD, int PT, int NT>
+__global__ __launch_bounds__(256) void pnn_inner16_kernel(const float* __restrict__ z, int64_t z_ld,
+                                                         const float* __restrict__ w, int B, int N, int P,
+                                                         float* __restrict__ usq, const float* __restrict__ coef,
+                                                         int64_t coef_ld, float* __restrict__ dz, int64_t dz_ld,
+                                                         float* __restrict__ dw_part) {
+  constexpr int E = 16, NS = 4 * NT, ES = E + 1;
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l16 = lane & 15, g = lane >> 4;
+  float* us = lds + wave * ((16 * PT + 16 * NT) * ES);
+  float* Zs = us + 16 * PT * ES;
+  float wa[PT][NS];
+#pragma unroll
+  for (int m = 0; m < PT; ++m)
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+      const int pp = 16 * m + l16, n = 4 * s2 + g;
+      wa[m][s2] = (pp < P && n < N) ? w[pp * N + n] : 0.f;
+    }
+  float wt[BWD ? NT : 1][BWD ? 4 * PT : 1];
+  f32x4 dwacc[BWD ? PT : 1][BWD ? NT : 1];
+  if (BWD) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4 * PT; ++q) {
+        const int n = 16 * t + l16, pp = 16 * (q >> 2) + 4 * g + (q & 3);
+        wt[t][q] = (pp < P && n < N) ? w[pp * N + n] : 0.f;
+      }
+#pragma unroll
+    for (int m = 0; m < PT; ++m)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) dwacc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  const int64_t iters = (B + stride - 1) / stride;
+  // the next sample's Z fragments (and this sample's coef and old dZ values) are requested before the matrix
+  // work of the current one: a wave runs its samples back to back with the loads a sample ahead
+  float zn[NS];
+  {
+    const int64_t b0 = (int64_t)blockIdx.x * WAVES + wave;
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+      const int n = 4 * s2 + g;
+      zn[s2] = (b0 < B && n < N) ? z[b0 * z_ld + n * E + l16] : 0.f;
+    }
+  }
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t b = it * stride + (int64_t)blockIdx.x * WAVES + wave;
+    const bool live = b < B;
+    float zf[NS];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) zf[s2] = zn[s2];
+    {
+      const int64_t bn = b + stride;
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) {
+        const int n = 4 * s2 + g;
+        zn[s2] = (bn < B && n < N) ? z[bn * z_ld + n * E + l16] : 0.f;
+      }
+    }
+    float cf[BWD ? PT : 1][4], dzo[BWD ? NT : 1][4];
+    if (BWD) {
+#pragma unroll
+      for (int m = 0; m < PT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pp = 16 * m + 4 * g + r;
+          cf[m][r] = (live && pp < P) ? (coef_ld ? coef[b * coef_ld + pp] : coef[pp]) : 0.f;
+        }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = 16 * t + 4 * g + r;
+          dzo[t][r] = (live && n < N) ? dz[b * dz_ld + n * E + l16] : 0.f;
+        }
+    }
+    f32x4 u[PT];
+#pragma unroll
+    for (int m = 0; m < PT; ++m) u[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+      for (int m = 0; m < PT; ++m) u[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][s2], zf[s2], u[m], 0, 0, 0);
+    if (!BWD) {
+#pragma unroll
+      for (int m = 0; m < PT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sq = u[m][r] * u[m][r];
+          sq = dpp_add<DPP_XOR1>(sq);
+          sq = dpp_add<DPP_XOR2>(sq);
+          sq = dpp_add<DPP_ROR + 4>(sq);
+          sq = dpp_add<DPP_ROR + 8>(sq);
+          const int pp = 16 * m + 4 * g + r;
+          if (live && l16 == 0 && pp < P) usq[b * P + pp] = sq;
+        }
+    } else {
+#pragma unroll
+      for (int m = 0; m < PT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          u[m][r] *= cf[m][r];
+        }
+      f32x4 dza[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) dza[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < PT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            dza[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[t][4 * m + r], u[m][r], dza[t], 0, 0, 0);
+      if (live) {
+        float* dr = dz + b * dz_ld;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = 16 * t + 4 * g + r;
+            if (n < N) dr[n * E + l16] = dzo[t][r] + dza[t][r];
+          }
+      }
+      __syncthreads();   // the tiles of the previous sample are fully read
+#pragma unroll
+      for (int m = 0; m < PT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) us[(16 * m + 4 * g + r) * ES + l16] = u[m][r];
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) Zs[(4 * s2 + g) * ES + l16] = zf[s2];
+      __syncthreads();
+#pragma unroll
+      for (int e0 = 0; e0 < E; e0 += 4) {
+        float av[PT], bv[NT];
+#pragma unroll
+        for (int m = 0; m < PT; ++m) av[m] = us[(16 * m + l16) * ES + e0 + g];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bv[t] = Zs[(16 * t + l16) * ES + e0 + g];
+#pragma unroll
+        for (int m = 0; m < PT; ++m)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            dwacc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[t], dwacc[m][t], 0, 0, 0);
+      }
+    }
+  }
+  if (BWD) {
+    const int64_t row = (int64_t)blockIdx.x * WAVES + wave;
+#pragma unroll
+    for (int m = 0; m < PT; ++m)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pp = 16 * m + 4 * g + r, n = 16 * t + l16;
+          if (pp < P && n < N) dw_part[row * (P * N) + pp * N + n] = dwacc[m][t][r];
+        }
+  }
+}
+
 // Fixed-order sum of the per-wave partial rows; the summed row is split over up to three
 // destinations [n0 | n1 | rest].  A block owns 16 columns; its 16 row groups each add every 16th
 // row with 8 loads in flight, then the groups are added in order.
@@ -602,6 +774,22 @@ extern "C" int ctr_pnn_inner_fwd(const float* z, int64_t z_ld, const float* w, i
   CTR_REQUIRE(pnn_lds_bytes(N, E, P) <= 64 * 1024, "ctr_pnn_inner_fwd: N=%d,E=%d,P=%d exceed the LDS budget", N, E, P);
   if (B == 0) return CTR_OK;
   CTR_REQUIRE(z && w && usq_out && z_ld >= (int64_t)N * E, "ctr_pnn_inner_fwd: null pointer / z_ld");
+  if (E == 16 && N <= 64 && P <= 64) {   // every contraction on the matrix cores
+    const int pt = P <= 16 ? 1 : P <= 32 ? 2 : 4, nt = (N + 15) / 16;
+#define PF(PT_, NT_)                                                                                            \
+  hipLaunchKernelGGL((pnn_inner16_kernel<false, PT_, NT_>), dim3(pnn_blocks(B)), dim3(256), 0, (hipStream_t)stream, z, \
+                     z_ld, w, B, N, P, usq_out, (const float*)nullptr, (int64_t)0, (float*)nullptr, (int64_t)0,   \
+                     (float*)nullptr)
+#define PFN(PT_)                                                                   \
+  do {                                                                             \
+    if (nt == 1) PF(PT_, 1); else if (nt == 2) PF(PT_, 2); else if (nt == 3) PF(PT_, 3); else PF(PT_, 4); \
+  } while (0)
+    if (pt == 1) PFN(1); else if (pt == 2) PFN(2); else PFN(4);
+#undef PFN
+#undef PF
+    CTR_LAUNCH_CHECK();
+    return CTR_OK;
+  }
   hipLaunchKernelGGL((pnn_inner_kernel<false, 1, 1>), dim3(pnn_blocks(B)), dim3(256), pnn_lds_bytes(N, E, P),
                      (hipStream_t)stream, z, z_ld, w, B, N, E, P, usq_out, (const float*)nullptr, (int64_t)0,
                      (float*)nullptr, (int64_t)0, (float*)nullptr);
@@ -629,6 +817,24 @@ extern "C" int ctr_pnn_inner_bwd(const float* z, int64_t z_ld, const float* w, c
   hipStream_t st = (hipStream_t)stream;
   const int nb = pnn_blocks(B);
   float* part = (float*)workspace;
+  if (E == 16 && N <= 64 && P <= 64) {   // every contraction on the matrix cores
+    const int pt = P <= 16 ? 1 : P <= 32 ? 2 : 4, nt = (N + 15) / 16;
+    const size_t lds16 = (size_t)WAVES * (16 * pt + 16 * nt) * 17 * sizeof(float);
+#define PB(PT_, NT_)                                                                                            \
+  hipLaunchKernelGGL((pnn_inner16_kernel<true, PT_, NT_>), dim3(nb), dim3(256), lds16, st, z, z_ld, w, B, N, P,  \
+                     (float*)nullptr, coef, coef_ld, dz, dz_ld, part)
+#define PBN(PT_)                                                                   \
+  do {                                                                             \
+    if (nt == 1) PB(PT_, 1); else if (nt == 2) PB(PT_, 2); else if (nt == 3) PB(PT_, 3); else PB(PT_, 4); \
+  } while (0)
+    if (pt == 1) PBN(1); else if (pt == 2) PBN(2); else PBN(4);
+#undef PBN
+#undef PB
+    hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)cdiv((int64_t)P * N, 16)), dim3(256), 0, st, part, nb * WAVES,
+                       P * N, dw_out, P * N, (float*)nullptr, 0, (float*)nullptr);
+    CTR_LAUNCH_CHECK();
+    return CTR_OK;
+  }
   const size_t lds = pnn_lds_bytes(N, E, P);
 #define PL(MT, NT)                                                                                              \
   hipLaunchKernelGGL((pnn_inner_kernel<true, MT, NT>), dim3(nb), dim3(256), lds, st, z, z_ld, w, B, N, E, P,      \
