@@ -205,6 +205,9 @@ __global__ __launch_bounds__(256) void pnn_inner16_kernel(const float* __restric
 #pragma unroll
       for (int m = 0; m < PT; ++m) u[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][s2], zf[s2], u[m], 0, 0, 0);
     if (!BWD) {
+      // after the in-row sums every lane of a row of 16 holds the row's 4 PT totals; lane l16 keeps the one
+      // of (m, r) = (l16 / 4, l16 % 4), so the sample's P values leave in one store
+      float keep = 0.f;
 #pragma unroll
       for (int m = 0; m < PT; ++m)
 #pragma unroll
@@ -214,9 +217,10 @@ __global__ __launch_bounds__(256) void pnn_inner16_kernel(const float* __restric
           sq = dpp_add<DPP_XOR2>(sq);
           sq = dpp_add<DPP_ROR + 4>(sq);
           sq = dpp_add<DPP_ROR + 8>(sq);
-          const int pp = 16 * m + 4 * g + r;
-          if (live && l16 == 0 && pp < P) usq[b * P + pp] = sq;
+          if (l16 == 4 * m + r) keep = sq;
         }
+      const int pp = 16 * (l16 >> 2) + 4 * g + (l16 & 3);
+      if (live && (l16 >> 2) < PT && pp < P) usq[b * P + pp] = keep;
     } else {
 #pragma unroll
       for (int m = 0; m < PT; ++m)
