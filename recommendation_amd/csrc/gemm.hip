@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(int M, int N, int K, 
   const int64_t astep = 2 * lda, bstep = 2 * ldb;
   const int steps = (int)((kend - kbeg + 1) / 2);
   const int last_live = (int)(kend - kbeg) - lk;   // this lane's k offset must stay below this (exclusive: k < kend)
-#pragma unroll 2
+#pragma unroll 8
   for (int it = 0; it < steps; ++it) {
     const bool kok = 2 * it < last_live;
     float a[TM], b[TN];
@@ -879,7 +879,7 @@ static Plan make_plan(int M, int N, int K) {
     splits = (int)cdiv(512, tiles);
     const int max_splits = K / (4 * BK);  // keep at least 4 k-steps per split
     if (splits > max_splits) splits = max_splits;
-    if (splits > 128) splits = 128;
+    if (splits > 512) splits = 512;
     if (splits < 1) splits = 1;
   }
   int k_chunk = (int)cdiv(cdiv(K, splits), 32) * 32;  // whole stages of either kernel
@@ -1061,8 +1061,13 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
   return CTR_OK;
 }
 
-// Stream path is used when the output is small next to K: M*N <= 16384, N <= 128, K >= 2048.
-static bool wgrad_streams(int M, int N, int K) { return (int64_t)M * N <= 16384 && N <= 128 && K >= 2048; }
+// Stream path is used when the output is small next to K: M*N <= 16384, N <= 128, K >= 2048 - except a
+// several-tile output under a very long K (DIN's attention layers, K = B*T), where its tiles re-read the
+// operands and the split-K tile kernel measures 1.7x faster.
+static bool wgrad_streams(int M, int N, int K) {
+  if ((int64_t)M * N >= 8192 && K >= 262144) return false;
+  return (int64_t)M * N <= 16384 && N <= 128 && K >= 2048;
+}
 
 extern "C" size_t ctr_dense_wgrad_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;

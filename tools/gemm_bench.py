@@ -21,6 +21,8 @@ else:
   ]
 if len(sys.argv) > 2 and sys.argv[1] == 'one':         # a single named shape, for counter passes
     shapes = [sh for sh in shapes if sh[0] in sys.argv[2:]]
+if len(sys.argv) > 1 and sys.argv[1] == 'wgrad':
+    shapes = []
 for name, M, N, K, ta, tb in shapes:
     def mk(r, c):
         ld = (c + 3) // 4 * 4
@@ -41,10 +43,11 @@ for name, M, N, K, ta, tb in shapes:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     print('%-6s M=%6d N=%5d K=%6d  %8.1f us  %6.1f TF' % (name, M, N, K, us, 2.0 * M * N * K / us / 1e6))
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1] != 'wgrad':
     sys.exit(0)
 print('--- dense_wgrad')
-for name, M, N, K in [('dw0', 429, 256, B), ('dw1', 256, 128, B), ('dw2', 128, 64, B), ('dw3', 64, 32, B), ('dwo', 74, 1, B)]:
+for name, M, N, K in [('dw0', 429, 256, B), ('dw1', 256, 128, B), ('dw2', 128, 64, B), ('dw3', 64, 32, B), ('dwo', 74, 1, B),
+                      ('din1', 128, 80, 409600), ('din2', 80, 40, 409600), ('din3', 512, 80, 409600)]:
     x = torch.randn(K, (M + 3) // 4 * 4, device='cuda')[:, :M]
     g = torch.randn(K, (N + 3) // 4 * 4, device='cuda')[:, :N]
     dW = torch.zeros(M, N, device='cuda'); db = torch.zeros(N, device='cuda')

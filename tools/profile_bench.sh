@@ -1,0 +1,22 @@
+#!/bin/bash
+# rocprofv3 passes over the default bench.py run (DeepFM, Criteo-Kaggle shape, one GPU):
+#   1. kernel trace + stats  -> gpurun_out/prof/stats/…_kernel_stats.csv
+#   2. FETCH_SIZE counters   -> gpurun_out/prof/fetch/…_counter_collection.csv
+#   3. WRITE_SIZE counters   -> gpurun_out/prof/write/…_counter_collection.csv
+# then folds 2 and 3 into gpurun_out/prof/pmc_traffic.json.  Copy the summaries into profiles/ afterwards.
+set -e
+export TMPDIR=/tmp
+R=$PWD
+OUT=$R/gpurun_out/prof
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp
+ARGS="--steps 30 --warmup 3 --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/bench_under_rocprof.json
+echo "stats pass done"
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timers > /dev/null
+echo "fetch pass done"
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timers > /dev/null
+echo "write pass done"
+cd $R
+python3 tools/pmc_summary.py $(find $OUT/fetch -name "*counter_collection.csv" | head -1) $(find $OUT/write -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
