@@ -365,6 +365,18 @@ int ctr_mlp_chain_fwd(int M, int K0, const float* X, int64_t ldx,
                       int N3, const float* W3, const float* b3, const ctr_dropout_t* drop3, float* H3, int64_t ld3,
                       void* stream);
 
+/* Backward of that tail with respect to the activations, two layers per launch (the gradient walks
+ * in -> mid -> out; widths (32, 64, 128) or (16, 32, 64), ctr_mlp_chain_bwd_supported):
+ *   Gmid = (Gin Wb^T) * [Hmid > 0] * scale_mid,  Wb [mid, in]  = weights of the layer mid -> in
+ *   Gout = (Gmid Wa^T) * [Hout > 0] * scale_out, Wa [out, mid] = weights of the layer out -> mid
+ * Gin is the gradient of the last layer's output with its own relu/dropout mask already applied.
+ * Rows of Hmid, Hout, Gmid, Gout must be 16-byte aligned; Gin may be any column range of a wider buffer. */
+int ctr_mlp_chain_bwd_supported(int in, int mid, int out);
+int ctr_mlp_chain_bwd(int M, int in, const float* Gin, int64_t ldgi, int mid, const float* Wb,
+                      const float* Hmid, int64_t ldhm, float scale_mid, float* Gmid, int64_t ldgm, int out,
+                      const float* Wa, const float* Hout, int64_t ldho, float scale_out, float* Gout,
+                      int64_t ldgo, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Evaluation metrics on the device (the reference round-trips predictions to the host:
  * DeepFM/main.py:105-126, DIN/main.py:12-61).  auc_out[0] = area under the ROC curve of

@@ -140,6 +140,84 @@ __global__ __launch_bounds__(512) void mlp_chain_fwd_kernel(int M, int K0, const
   }
 }
 
+// Backward of the same tail with respect to the activations, two layers in one launch:
+//   g_mid = (g_in  W_b^T) * [h_mid > 0] * scale_mid      (W_b: [MID, IN],  the layer mid -> in)
+//   g_out = (g_mid W_a^T) * [h_out > 0] * scale_out      (W_a: [OUT, MID], the layer out -> mid)
+// g_in is the (already masked) gradient of the last layer's output.  Same register flow as the forward: a
+// layer's accumulators (lane holds 4 consecutive columns of its row) are the next product's operand; the
+// transposed weights sit in LDS for the whole kernel.  Both gradients are written (the weight gradients read them).
+template <int NTI, int NTM, int NTO>
+__global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(int M, const float* __restrict__ Gin, int64_t ldgi,
+                                                           int in_scalar, const float* __restrict__ Wb,
+                                                           const float* __restrict__ Hm, int64_t ldhm, float scale_m,
+                                                           float* __restrict__ Gm, int64_t ldgm,
+                                                           const float* __restrict__ Wa,
+                                                           const float* __restrict__ Ho, int64_t ldho, float scale_o,
+                                                           float* __restrict__ Go, int64_t ldgo) {
+  extern __shared__ float Ws[];
+  constexpr int IN = 16 * NTI, MID = 16 * NTM, OUT = 16 * NTO, SB = MID + 4, SA = OUT + 4;
+  float* Wbt = Ws;                 // [IN][SB]:  Wbt[k][n] = Wb[n][k]
+  float* Wat = Ws + IN * SB;       // [MID][SA]: Wat[k][n] = Wa[n][k]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l16 = lane & 15, kq = lane >> 4;
+  for (int q = threadIdx.x; q < MID * IN; q += 256) Wbt[(q % IN) * SB + q / IN] = Wb[q];
+  for (int q = threadIdx.x; q < OUT * MID; q += 256) Wat[(q % MID) * SA + q / MID] = Wa[q];
+  __syncthreads();
+  const int strips = (M + 15) / 16;
+  for (int strip = blockIdx.x * 4 + wave; strip < strips; strip += gridDim.x * 4) {
+    const int64_t m = strip * 16 + l16;
+    const bool live = m < M;
+    const int64_t mc = live ? m : (int64_t)M - 1;
+    f32x4 gi[NTI];
+#pragma unroll
+    for (int j = 0; j < NTI; ++j) {
+      const float* p = Gin + mc * ldgi + 16 * j + 4 * kq;
+      if (in_scalar) gi[j] = f32x4{p[0], p[1], p[2], p[3]};
+      else gi[j] = *reinterpret_cast<const f32x4*>(p);
+    }
+    f32x4 hm[NTM];
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) hm[t] = *reinterpret_cast<const f32x4*>(Hm + mc * ldhm + 16 * t + 4 * kq);
+    f32x4 gm[NTM];
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) gm[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NTI; ++j)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* wrow = Wbt + (16 * j + 4 * kq + u) * SB + l16;
+#pragma unroll
+        for (int t = 0; t < NTM; ++t) gm[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[16 * t], gi[j][u], gm[t], 0, 0, 0);
+      }
+    f32x4 ho[NTO];
+#pragma unroll
+    for (int t = 0; t < NTO; ++t) ho[t] = *reinterpret_cast<const f32x4*>(Ho + mc * ldho + 16 * t + 4 * kq);
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gm[t][r] = hm[t][r] > 0.f ? gm[t][r] * scale_m : 0.f;
+      if (live) *reinterpret_cast<f32x4*>(Gm + m * ldgm + 16 * t + 4 * kq) = gm[t];
+    }
+    f32x4 go[NTO];
+#pragma unroll
+    for (int t = 0; t < NTO; ++t) go[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NTM; ++j)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* wrow = Wat + (16 * j + 4 * kq + u) * SA + l16;
+#pragma unroll
+        for (int t = 0; t < NTO; ++t) go[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[16 * t], gm[j][u], go[t], 0, 0, 0);
+      }
+#pragma unroll
+    for (int t = 0; t < NTO; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) go[t][r] = ho[t][r] > 0.f ? go[t][r] * scale_o : 0.f;
+      if (live) *reinterpret_cast<f32x4*>(Go + m * ldgo + 16 * t + 4 * kq) = go[t];
+    }
+  }
+}
+
 }  // namespace ctr
 
 using namespace ctr;
@@ -186,6 +264,40 @@ extern "C" int ctr_mlp_chain_fwd(int M, int K0, const float* X, int64_t ldx, int
   if (N3 == 16) CH(4, 2, 1);
   else CH(4, 2, 0);
 #undef CH
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+// Widths (in, mid, out) of the two-layer backward chain: the gradient walks in -> mid -> out.
+extern "C" int ctr_mlp_chain_bwd_supported(int in, int mid, int out) {
+  return (in == 32 && mid == 64 && out == 128) || (in == 16 && mid == 32 && out == 64);
+}
+
+extern "C" int ctr_mlp_chain_bwd(int M, int in, const float* Gin, int64_t ldgi, int mid, const float* Wb,
+                                 const float* Hmid, int64_t ldhm, float scale_mid, float* Gmid, int64_t ldgm, int out,
+                                 const float* Wa, const float* Hout, int64_t ldho, float scale_out, float* Gout,
+                                 int64_t ldgo, void* stream) {
+  CTR_REQUIRE(M >= 0, "ctr_mlp_chain_bwd: negative M");
+  CTR_REQUIRE(ctr_mlp_chain_bwd_supported(in, mid, out), "ctr_mlp_chain_bwd: widths %d -> %d -> %d not covered", in, mid,
+              out);
+  if (M == 0) return CTR_OK;
+  CTR_REQUIRE(Gin && Wb && Hmid && Gmid && Wa && Hout && Gout, "ctr_mlp_chain_bwd: null pointer");
+  CTR_REQUIRE(ldgi >= in && ldhm >= mid && ldgm >= mid && ldho >= out && ldgo >= out, "ctr_mlp_chain_bwd: leading dimension");
+  const auto rows16 = [](const void* p, int64_t ld) { return ld % 4 == 0 && ((uintptr_t)p % 16) == 0; };
+  CTR_REQUIRE(rows16(Hmid, ldhm) && rows16(Gmid, ldgm) && rows16(Hout, ldho) && rows16(Gout, ldgo),
+              "ctr_mlp_chain_bwd: activations and output gradients must be 16-byte aligned rows");
+  const int in_scalar = rows16(Gin, ldgi) ? 0 : 1;
+  const size_t lds = ((size_t)in * (mid + 4) + (size_t)mid * (out + 4)) * sizeof(float);
+  const int strips = (int)cdiv(M, 16);
+  int blocks = (int)cdiv(strips, 4);
+  if (blocks > 512) blocks = 512;   // every block transposes both weight matrices into LDS first
+  hipStream_t st = (hipStream_t)stream;
+#define CB(A_, B_, C_)                                                                                         \
+  hipLaunchKernelGGL((mlp_chain_bwd_kernel<A_, B_, C_>), dim3(blocks), dim3(256), lds, st, M, Gin, ldgi, in_scalar, Wb, \
+                     Hmid, ldhm, scale_mid, Gmid, ldgm, Wa, Hout, ldho, scale_out, Gout, ldgo)
+  if (in == 32) CB(2, 4, 8);
+  else CB(1, 2, 4);
+#undef CB
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }

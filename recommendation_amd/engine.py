@@ -196,6 +196,7 @@ class Tower:
         self.widths = [dense.shapes[w][1] for w, _ in self.names]
         self.d_in = dense.shapes[self.names[0][0]][0]
         self._chain = None
+        self._bwd_chain = None
 
     def forward(self, x, acts, drops, ws):
         """x: [B, >= d_in]; acts[i]: output buffer of layer i ([B, L_i] views)."""
@@ -234,16 +235,34 @@ class Tower:
         if not g_last_masked:
             ops.relu_mask_apply(g_last, acts[n - 1], scale[n - 1])
         g = g_last
+        # the last two activation gradients in one chained launch when the widths are covered
+        chained = 0
+        if n >= 3 and self._bwd_chain_ok(acts, gbufs):
+            ops.mlp_chain_bwd(g_last, self.dense.p(self.names[n - 1][0]), acts[n - 2], scale[n - 2], gbufs[n - 2],
+                              self.dense.p(self.names[n - 2][0]), acts[n - 3], scale[n - 3], gbufs[n - 3])
+            chained = 2
         for i in range(n - 1, -1, -1):
             wn, bn = self.names[i]
             h_in = x[:, :self.d_in] if i == 0 else acts[i - 1]
             ops.dense_wgrad(h_in, g, self.dense.g(wn), self.dense.g(bn).reshape(-1), ws=ws)   # dW = h_in^T g, db
             if i > 0:
-                ops.gemm(g, self.dense.p(wn), gbufs[i - 1], trans_b=True, mask_src=acts[i - 1],
-                         mask_scale=scale[i - 1], ws=ws)
+                if chained:
+                    chained -= 1
+                else:
+                    ops.gemm(g, self.dense.p(wn), gbufs[i - 1], trans_b=True, mask_src=acts[i - 1],
+                             mask_scale=scale[i - 1], ws=ws)
                 g = gbufs[i - 1]
             elif dx is not None:
                 ops.gemm(g, self.dense.p(wn), dx[:, :self.d_in], trans_b=True, accumulate=accumulate_dx, ws=ws)
+
+    def _bwd_chain_ok(self, acts, gbufs):
+        if self._bwd_chain is None:
+            n = len(self.names)
+            ok = ops.mlp_chain_bwd_supported(self.widths[n - 1], self.widths[n - 2], self.widths[n - 3])
+            for t in (acts[n - 2], acts[n - 3], gbufs[n - 2], gbufs[n - 3]):
+                ok = ok and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+            self._bwd_chain = bool(ok)
+        return self._bwd_chain
 
 
 def adam_lr_t(lr, t, b1=0.9, b2=0.999):

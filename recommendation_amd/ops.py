@@ -300,6 +300,30 @@ def mlp_chain_fwd(x, Ws, bs, drops, outs):
     check(lib().ctr_mlp_chain_fwd(M, K0, xp, ldx, *args, _stream()), 'ctr_mlp_chain_fwd')
 
 
+def mlp_chain_bwd_supported(w_in, w_mid, w_out):
+    return bool(lib().ctr_mlp_chain_bwd_supported(int(w_in), int(w_mid), int(w_out)))
+
+
+@_timed
+def mlp_chain_bwd(g_in, Wb, h_mid, scale_mid, g_mid, Wa, h_out, scale_out, g_out):
+    """g_mid = (g_in Wb^T) masked by h_mid, g_out = (g_mid Wa^T) masked by h_out (relu/dropout masks)."""
+    M, n_in = g_in.shape
+    mid, out = Wb.shape[0], Wa.shape[0]
+    if Wb.shape[1] != n_in or Wa.shape[1] != mid or not Wb.is_contiguous() or not Wa.is_contiguous():
+        raise ValueError('mlp_chain_bwd: weight shapes disagree')
+    for t, wdt in ((h_mid, mid), (g_mid, mid), (h_out, out), (g_out, out)):
+        if tuple(t.shape) != (M, wdt):
+            raise ValueError('mlp_chain_bwd: activation shapes disagree')
+    gp, ldgi = _rows(g_in, 'g_in')
+    hm, ldhm = _rows(h_mid, 'h_mid')
+    gm, ldgm = _rows(g_mid, 'g_mid')
+    ho, ldho = _rows(h_out, 'h_out')
+    go, ldgo = _rows(g_out, 'g_out')
+    check(lib().ctr_mlp_chain_bwd(M, n_in, gp, ldgi, mid, _ptr(Wb, torch.float32), hm, ldhm, float(scale_mid), gm, ldgm,
+                                  out, _ptr(Wa, torch.float32), ho, ldho, float(scale_out), go, ldgo, _stream()),
+          'ctr_mlp_chain_bwd')
+
+
 @_timed
 def auc_logloss(score, label, ws):
     """(auc, logloss) device scalars of float32 scores / labels (AUC with average ranks for ties)."""

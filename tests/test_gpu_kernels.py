@@ -457,3 +457,27 @@ def test_fused_output_unit_backward(ops_ws, B, K, mask_from):
     assert (dxd[:, K:] == 7.0).all()
     assert rel_err(dw.cpu().numpy(), x.astype(np.float64).T @ dl) < 1e-5
     assert abs(float(db.item()) - float(dl.astype(np.float64).sum())) < 1e-6
+
+
+@pytest.mark.parametrize('M,widths,offset', [(1000, (32, 64, 128), 0), (77, (16, 32, 64), 3), (4099, (32, 64, 128), 2)])
+def test_chained_activation_gradients_match_layer_by_layer(ops_ws, M, widths, offset):
+    """two dX steps in one launch == (g W^T) * relu/dropout mask, layer by layer in float64"""
+    ops, ws = ops_ws
+    n_in, mid, out = widths
+    rng = np.random.default_rng(M)
+    g_in = rng.standard_normal((M, n_in)).astype(np.float32)
+    Wb = (rng.standard_normal((mid, n_in)) / 8).astype(np.float32)
+    Wa = (rng.standard_normal((out, mid)) / 8).astype(np.float32)
+    h_mid = np.maximum(rng.standard_normal((M, mid)), 0).astype(np.float32)
+    h_out = np.maximum(rng.standard_normal((M, out)), 0).astype(np.float32)
+    big = torch.zeros(M, n_in + 7, device=DEV)                # the incoming gradient may start at any column
+    big[:, offset:offset + n_in] = dev(g_in)
+    g_mid, g_out = torch.full((M, mid), 9.0, device=DEV), torch.full((M, out + 4), 9.0, device=DEV)
+    assert ops.mlp_chain_bwd_supported(*widths) and not ops.mlp_chain_bwd_supported(32, 64, 256)
+    ops.mlp_chain_bwd(big[:, offset:offset + n_in], dev(Wb), dev(h_mid), 1.25, g_mid, dev(Wa), dev(h_out), 2.0,
+                      g_out[:, :out])
+    r_mid = (g_in.astype(np.float64) @ Wb.astype(np.float64).T) * np.where(h_mid > 0, 1.25, 0.0)
+    r_out = (r_mid @ Wa.astype(np.float64).T) * np.where(h_out > 0, 2.0, 0.0)
+    assert rel_err(g_mid.cpu().numpy(), r_mid) < 1e-5
+    assert rel_err(g_out[:, :out].cpu().numpy(), r_out) < 1e-5
+    assert (g_out[:, out:] == 9.0).all()
