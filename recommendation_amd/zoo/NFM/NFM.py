@@ -2,7 +2,7 @@
 import torch
 
 from recommendation_amd import ops
-from recommendation_amd.engine import Tower, round_up
+from recommendation_amd.engine import Tower, round_up, unit_backward
 from recommendation_amd.model_base import CTRModel
 from recommendation_amd._lib import LOSS_SIGMOID_LOGLOSS
 
@@ -58,10 +58,9 @@ class NFM(CTRModel):
         B = idx.shape[0]
         dl, last = bufs['dlogit'], bufs['acts'][-1]
         wn, bn = 'output/output_w_%d' % (n - 1), 'output/output_b_%d' % (n - 1)
-        ops.rowdot_bwd_x(dl, self.dense.p(wn).reshape(-1), bufs['glast'])
-        ops.dense_wgrad(last, dl.view(B, 1), self.dense.g(wn), self.dense.g(bn), ws=ws)
+        fused = unit_backward(self.dense, wn, bn, last, bufs['glast'], dl, ws, mask_from=0, rate=self.dropout_deep)
         self.tower.backward(bufs['x0'], bufs['acts'], bufs['glast'], bufs['gbufs'], [self.dropout_deep] * n,
-                            bufs['dx0'], ws)
+                            bufs['dx0'], ws, g_last_masked=fused)
         ops.embed_bwd_dz(bufs['z'], B=B, N=self.N, E=E, g_second=bufs['dx0'][:, :E], s=bufs['s'], z=bufs['z'],
                          drop_second=self._drop(self.dropout_bi, 2, True))
         self._tables_backward(idx, bufs['z'], bufs)

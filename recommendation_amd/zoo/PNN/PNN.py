@@ -6,7 +6,7 @@ broadcast over the samples.  args.inner_mode = 'per_sample' selects the per-samp
 import torch
 
 from recommendation_amd import ops
-from recommendation_amd.engine import Tower, round_up
+from recommendation_amd.engine import Tower, round_up, unit_backward
 from recommendation_amd.model_base import CTRModel
 from recommendation_amd._lib import LOSS_SIGMOID_SCE_PROB
 
@@ -103,10 +103,10 @@ class PNN(CTRModel):
         B = idx.shape[0]
         n = len(self.hidden_layers)
         dl, last = bufs['dlogit'], bufs['acts'][-1]
-        ops.rowdot_bwd_x(dl, d.p('hidden/output_w').reshape(-1), bufs['glast'])
-        ops.dense_wgrad(last, dl.view(B, 1), d.g('hidden/output_w'), d.g('hidden/output_b'), ws=ws)
+        fused = unit_backward(d, 'hidden/output_w', 'hidden/output_b', last, bufs['glast'], dl, ws, mask_from=0,
+                              rate=self.dropout)
         self.tower.backward(bufs['prod'], bufs['acts'], bufs['glast'], bufs['gbufs'], [self.dropout] * n,
-                            bufs['dprod'], ws)
+                            bufs['dprod'], ws, g_last_masked=fused)
         gpre = bufs['dprod']
         ops.relu_mask_apply(gpre, bufs['prod'], 1.0 / (1.0 - self.dropout) if self.dropout else 1.0)
         ops.colsum(gpre, d.g('product/product_bias'), ws=ws)
