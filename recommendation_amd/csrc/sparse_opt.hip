@@ -162,15 +162,32 @@ __global__ __launch_bounds__(256) void sparse_apply_tail_kernel(
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (r == 0) acc = *reinterpret_cast<const float4*>(part_head + blk * E + g * 4);
   // continuation pieces sit in blocks blk+1, blk+2, ... while the block's first key is `key`
-  for (int64_t k0 = blk + 1; k0 < n_blocks; k0 += R) {
-    const int64_t k = k0 + r;
-    const bool ok = k < n_blocks && keys[k * SEG] == key;
-    if (ok) {
-      const float4 v = *reinterpret_cast<const float4*>(part + k * E + g * 4);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  // Four steps of R blocks per round trip: a hot key's run spans hundreds of blocks and one wave walks it,
+  // so the walk is a chain of dependent (key, partial row) loads; each lane still adds its blocks in
+  // ascending order (same bits as one step at a time).
+  constexpr int TU = 4;
+  for (int64_t k0 = blk + 1; k0 < n_blocks; k0 += TU * R) {
+    bool ok[TU];
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const int64_t k = k0 + u * R + r;
+      ok[u] = k < n_blocks && keys[k * SEG] == key;
     }
-    // the run ends inside this step as soon as one slot misses (wave-uniform exit)
-    if (__ballot(ok) != __ballot(1)) break;
+    float4 v[TU];
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const int64_t k = k0 + u * R + r;
+      // a block past the run's first miss can carry the key again only if it is the same run: keys are sorted
+      v[u] = ok[u] ? *reinterpret_cast<const float4*>(part + k * E + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    bool all = true;
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      if (ok[u]) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+      all = all && ok[u];
+    }
+    // the run ends inside this round as soon as one slot misses (wave-uniform exit)
+    if (__ballot(all) != __ballot(1)) break;
   }
 #pragma unroll
   for (int o = G; o < 64; o <<= 1) {
