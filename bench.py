@@ -180,8 +180,10 @@ def main():
     if not args.no_kernel_timers:
         prof = ops.KernelTimer(pool=PROFILE_STEPS * 160)
         ops.set_timer(prof)
+        sess.side_enabled = False      # one stream: every operator's time is its own, not a shared GPU's
         for i in range(PROFILE_STEPS):
             model.train_step(*batches[i % len(batches)])
+        sess.side_enabled = True
         ops.set_timer(None)
         profile = prof.summary()
         dom_name = max(profile, key=lambda n: profile[n]['total_ms'])

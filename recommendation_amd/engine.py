@@ -4,6 +4,7 @@ All arithmetic happens in libctrhip kernels (ops.py); this file only owns buffer
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from collections import OrderedDict
 
@@ -225,7 +226,7 @@ class Tower:
                     break
         return self._chain
 
-    def backward(self, x, acts, g_last, gbufs, rates, dx, ws, accumulate_dx=False, g_last_masked=False):
+    def backward(self, x, acts, g_last, gbufs, rates, dx, ws, accumulate_dx=False, g_last_masked=False, side=None):
         """g_last: gradient w.r.t. acts[-1] (post relu+dropout); it is masked in place unless the caller
         already did (g_last_masked).
         gbufs[i]: scratch [B, L_i] for i < n-1.  dx (optional): [B, >= d_in] receives dL/dx
@@ -241,19 +242,29 @@ class Tower:
             ops.mlp_chain_bwd(g_last, self.dense.p(self.names[n - 1][0]), acts[n - 2], scale[n - 2], gbufs[n - 2],
                               self.dense.p(self.names[n - 2][0]), acts[n - 3], scale[n - 3], gbufs[n - 3])
             chained = 2
+        # activation gradients first (they are what the rest of the step waits for) ...
+        gs = [None] * n
+        gs[n - 1] = g_last
         for i in range(n - 1, -1, -1):
-            wn, bn = self.names[i]
-            h_in = x[:, :self.d_in] if i == 0 else acts[i - 1]
-            ops.dense_wgrad(h_in, g, self.dense.g(wn), self.dense.g(bn).reshape(-1), ws=ws)   # dW = h_in^T g, db
+            wn = self.names[i][0]
             if i > 0:
                 if chained:
                     chained -= 1
                 else:
-                    ops.gemm(g, self.dense.p(wn), gbufs[i - 1], trans_b=True, mask_src=acts[i - 1],
+                    ops.gemm(gs[i], self.dense.p(wn), gbufs[i - 1], trans_b=True, mask_src=acts[i - 1],
                              mask_scale=scale[i - 1], ws=ws)
-                g = gbufs[i - 1]
+                gs[i - 1] = gbufs[i - 1]
             elif dx is not None:
-                ops.gemm(g, self.dense.p(wn), dx[:, :self.d_in], trans_b=True, accumulate=accumulate_dx, ws=ws)
+                ops.gemm(gs[0], self.dense.p(wn), dx[:, :self.d_in], trans_b=True, accumulate=accumulate_dx, ws=ws)
+        # ... then the weight gradients: dW = h_in^T g, db.  With `side` (a Session) they go to its side stream
+        # and overlap whatever the caller launches next; the caller joins before the dense optimizer.
+        ctx = side.side_stream() if side is not None else contextlib.nullcontext()
+        wws = side.ws_side if side is not None else ws
+        with ctx:
+            for i in range(n - 1, -1, -1):
+                wn, bn = self.names[i]
+                h_in = x[:, :self.d_in] if i == 0 else acts[i - 1]
+                ops.dense_wgrad(h_in, gs[i], self.dense.g(wn), self.dense.g(bn).reshape(-1), ws=wws)
 
     def _bwd_chain_ok(self, acts, gbufs):
         if self._bwd_chain is None:

@@ -277,6 +277,7 @@ class CTRModel:
         self._forward(idx, xc, bufs, True)
         self._loss(bufs, yy, True)
         self._backward(idx, xc, bufs)
+        self.session.side_join()                            # weight gradients issued to the side stream
         if self.world > 1:
             self.comm.all_reduce_sum(self.dense.grad)       # loss gradient was pre-scaled by 1/world
         self.dense.apply(self._optimizer())

@@ -6,6 +6,8 @@ the GPU device, the RNG seed of the dropout streams and the scratch workspace.
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 
 from . import _lib
@@ -21,6 +23,14 @@ class Session:
         torch.cuda.set_device(self.device)
         self.seed = int(seed)
         self.ws = Workspace(self.device)
+        # second stream + workspace for work that does not feed the rest of the step (the towers' weight
+        # gradients run there beside the embedding backward); joined before the dense optimizer
+        self.ws_side = Workspace(self.device)
+        self._side = None
+        self._fork_ev = None
+        self._join_ev = None
+        self._side_open = False
+        self.side_enabled = True     # False: side_stream() is a no-op context (per-kernel timing passes)
 
     def __enter__(self):
         return self
@@ -28,6 +38,27 @@ class Session:
     def __exit__(self, *exc):
         torch.cuda.synchronize(self.device)
         return False
+
+    def side_stream(self):
+        """Context manager: the enclosed launches go to the side stream, ordered after everything issued so far
+        on the current stream.  Kernels launched inside must take their scratch from `ws_side`."""
+        if not self.side_enabled:
+            return contextlib.nullcontext()
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+            self._fork_ev = torch.cuda.Event()
+            self._join_ev = torch.cuda.Event()
+        self._fork_ev.record()
+        self._side.wait_event(self._fork_ev)
+        self._side_open = True
+        return torch.cuda.stream(self._side)
+
+    def side_join(self):
+        """The current stream waits for everything issued to the side stream."""
+        if self._side_open:
+            self._join_ev.record(self._side)
+            torch.cuda.current_stream().wait_event(self._join_ev)
+            self._side_open = False
 
     def synchronize(self):
         torch.cuda.synchronize(self.device)

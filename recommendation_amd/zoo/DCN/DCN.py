@@ -67,7 +67,7 @@ class DCN(CTRModel):
         wn, bn = 'stack_layer/stack_w_%d' % (n - 1), 'stack_layer/stack_b_%d' % (n - 1)
         fused = unit_backward(self.dense, wn, bn, stack, dstack, dl, ws, mask_from=D, rate=self.dropout)
         self.tower.backward(bufs['x0'], bufs['acts'], dstack[:, D:], bufs['gbufs'], [self.dropout] * n,
-                            bufs['dx0'], ws, g_last_masked=fused)
+                            bufs['dx0'], ws, g_last_masked=fused, side=self.session)
         ops.cross_bwd(bufs['x0'], self.dense.stacked(self._wn), self.dense.stacked(self._bn), bufs['aux'],
                       dstack[:, :D], bufs['dx0'], self.dense.stacked(self._wn, self.dense.grad),
                       self.dense.stacked(self._bn, self.dense.grad), ws, accumulate=True)

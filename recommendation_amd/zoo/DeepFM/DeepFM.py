@@ -64,7 +64,7 @@ class DeepFM(CTRModel):
         # output unit backward + the last tower layer's relu/dropout mask in one pass over concat
         fused = unit_backward(self.dense, wn, bn, concat, dconcat, dl, ws, mask_from=N + E, rate=self.dropout_deep)
         self.tower.backward(bufs['x0'], bufs['acts'], dconcat[:, N + E:], bufs['gbufs'],
-                            [self.dropout_deep] * n, bufs['dx0'], ws, g_last_masked=fused)
+                            [self.dropout_deep] * n, bufs['dx0'], ws, g_last_masked=fused, side=self.session)
         ops.embed_bwd_dz(bufs['dx0'], B=B, N=N, E=E, gz=bufs['dx0'], g_first=dconcat[:, :N],
                          g_second=dconcat[:, N:N + E], s=bufs['s'], z=bufs['x0'],
                          drop_first=self._drop(self.dropout_fm, 1, True),

@@ -71,6 +71,7 @@ class ESMM(CTRModel):
             wn, bn = '%s_deep_part/%s_output_w' % (t, t), '%s_deep_part/%s_output_b' % (t, t)
             fused = unit_backward(self.dense, wn, bn, last, bufs[t + '_glast'], dl, ws, mask_from=0, rate=self.dropout)
             self.towers[t].backward(bufs['inp'], bufs[t + '_acts'], bufs[t + '_glast'], bufs[t + '_gbufs'],
-                                    [self.dropout] * n, bufs['dinp'], ws, accumulate_dx=(k == 1), g_last_masked=fused)
+                                    [self.dropout] * n, bufs['dinp'], ws, accumulate_dx=(k == 1), g_last_masked=fused,
+                                    side=self.session)
         ops.embed_bwd_dz(bufs['dz'], B=B, N=self.N, E=self.embed_size, g_first=bufs['dinp'][:, :self.N])
         self._tables_backward(idx, bufs['dz'], bufs)

@@ -60,7 +60,7 @@ class NFM(CTRModel):
         wn, bn = 'output/output_w_%d' % (n - 1), 'output/output_b_%d' % (n - 1)
         fused = unit_backward(self.dense, wn, bn, last, bufs['glast'], dl, ws, mask_from=0, rate=self.dropout_deep)
         self.tower.backward(bufs['x0'], bufs['acts'], bufs['glast'], bufs['gbufs'], [self.dropout_deep] * n,
-                            bufs['dx0'], ws, g_last_masked=fused)
+                            bufs['dx0'], ws, g_last_masked=fused, side=self.session)
         ops.embed_bwd_dz(bufs['z'], B=B, N=self.N, E=E, g_second=bufs['dx0'][:, :E], s=bufs['s'], z=bufs['z'],
                          drop_second=self._drop(self.dropout_bi, 2, True))
         self._tables_backward(idx, bufs['z'], bufs)

@@ -106,7 +106,7 @@ class PNN(CTRModel):
         fused = unit_backward(d, 'hidden/output_w', 'hidden/output_b', last, bufs['glast'], dl, ws, mask_from=0,
                               rate=self.dropout)
         self.tower.backward(bufs['prod'], bufs['acts'], bufs['glast'], bufs['gbufs'], [self.dropout] * n,
-                            bufs['dprod'], ws, g_last_masked=fused)
+                            bufs['dprod'], ws, g_last_masked=fused, side=self.session)
         gpre = bufs['dprod']
         ops.relu_mask_apply(gpre, bufs['prod'], 1.0 / (1.0 - self.dropout) if self.dropout else 1.0)
         ops.colsum(gpre, d.g('product/product_bias'), ws=ws)
