@@ -106,6 +106,24 @@ int ctr_embed_bwd_dz(const float* gz, int64_t gz_ld,
                      int B, int N, int E,
                      const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second,
                      float* dz, int64_t dz_ld, void* stream);
+/* Sharded tables (no counterpart in the single-process reference; same arithmetic as ctr_embed_fwd /
+ * ctr_embed_bwd_dz, DeepFM/DeepFM.py:42-63): the rows of field n were fetched by the field's owner rank and
+ * arrive as one block of columns per owner.  Row n < F of sample b is the E floats at
+ * blocks[fbase[n] + b * fstride[n]]; fbase / fstride are device arrays of F int64 (element offsets, multiples
+ * of 4).  ctr_embed_assemble_fwd builds Z (+ continuous rows, FM sums, dropout) from them in one pass;
+ * ctr_embed_bwd_dz_blocks writes dZ of those rows straight back into the same block layout (the buffer the
+ * gradient exchange sends) and the other rows into dz. */
+int ctr_embed_assemble_fwd(const float* blocks, const int64_t* fbase, const int64_t* fstride,
+                           const float* x_cont, const float* cont_w, int B, int F, int C, int E,
+                           float* z_out, int64_t z_ld, int cont_tail, float* first_out, int64_t first_ld,
+                           float* s_out, float* second_out, int64_t second_ld,
+                           const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second, void* stream);
+int ctr_embed_bwd_dz_blocks(const float* gz, int64_t gz_ld, const float* g_first, int64_t g_first_ld,
+                            const float* g_second, int64_t g_second_ld, const float* s, const float* z,
+                            int64_t z_ld, const float* g_sum, int B, int N, int E,
+                            const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second, float* dz,
+                            int64_t dz_ld, float* blocks_out, const int64_t* fbase, const int64_t* fstride, int F,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Deterministic embedding backward: sort + segment-reduce + fused row update.

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
     float* __restrict__ z_out, int64_t z_ld, int cont_tail,
     float* __restrict__ first_out, int64_t first_ld, float* __restrict__ s_out,
     float* __restrict__ second_out, int64_t second_ld, Drop d_first, Drop d_second,
-    int32_t* __restrict__ oor_count) {
+    int32_t* __restrict__ oor_count, const float* __restrict__ blk, const int64_t* __restrict__ fbase,
+    const int64_t* __restrict__ fstride) {
   constexpr int R = 64 / G;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -44,7 +45,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
     if (active && DENSE) {
       z = *reinterpret_cast<const float4*>(z_out + b * z_ld + (int64_t)n * E + g * 4);
     } else if (active) {
-      if (n < F) {
+      if (n < F && blk) {   // rows already fetched by their owners, one block of columns per owner
+        z = *reinterpret_cast<const float4*>(blk + fbase[n] + b * fstride[n] + g * 4);
+      } else if (n < F) {
         const int x = idx[b * F + n];
         const int64_t off = row_offset[n];
         const int64_t V = row_offset[n + 1] - off;
@@ -152,7 +155,8 @@ __global__ __launch_bounds__(256) void embed_bwd_dz_kernel(
     const float* gz, int64_t gz_ld, const float* __restrict__ g_first, int64_t g_first_ld,
     const float* __restrict__ g_second, int64_t g_second_ld, const float* __restrict__ s,
     const float* __restrict__ z, int64_t z_ld, const float* __restrict__ g_sum, int B, int N, int E,
-    Drop d_first, Drop d_second, float* dz, int64_t dz_ld) {
+    Drop d_first, Drop d_second, float* dz, int64_t dz_ld, float* __restrict__ blk, const int64_t* __restrict__ fbase,
+    const int64_t* __restrict__ fstride, int F) {
   const int G = E / 4;
   const int64_t total = (int64_t)B * N * G;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total;
@@ -181,7 +185,9 @@ __global__ __launch_bounds__(256) void embed_bwd_dz_kernel(
       const float4 gs = *reinterpret_cast<const float4*>(g_sum + b * E + g * 4);
       a.x += gs.x; a.y += gs.y; a.z += gs.z; a.w += gs.w;
     }
-    *reinterpret_cast<float4*>(dz + b * dz_ld + (int64_t)n * E + g * 4) = a;
+    // rows of sharded fields go straight into their owner's block of the exchange buffer
+    float* dst = (blk && n < F) ? blk + fbase[n] + b * fstride[n] + g * 4 : dz + b * dz_ld + (int64_t)n * E + g * 4;
+    *reinterpret_cast<float4*>(dst) = a;
   }
 }
 
@@ -191,15 +197,17 @@ static bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
 using namespace ctr;
 
-extern "C" int ctr_embed_fwd(const float* tables, const int64_t* row_offset, const int32_t* idx,
-                             const float* x_cont, const float* cont_w, int B, int F, int C, int E,
-                             float* z_out, int64_t z_ld, int cont_tail, float* first_out,
-                             int64_t first_ld, float* s_out, float* second_out, int64_t second_ld,
-                             const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second,
-                             int32_t* oor_count, void* stream) {
+static int embed_fwd_impl(const float* tables, const int64_t* row_offset, const int32_t* idx,
+                          const float* x_cont, const float* cont_w, int B, int F, int C, int E,
+                          float* z_out, int64_t z_ld, int cont_tail, float* first_out,
+                          int64_t first_ld, float* s_out, float* second_out, int64_t second_ld,
+                          const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second,
+                          int32_t* oor_count, const float* blk, const int64_t* fbase, const int64_t* fstride,
+                          void* stream) {
   CTR_REQUIRE(B >= 0 && F >= 0 && C >= 0, "ctr_embed_fwd: negative size");
   CTR_REQUIRE(pow2(E) && E >= 4 && E <= 256, "ctr_embed_fwd: E=%d must be a power of two in [4,256]", E);
-  CTR_REQUIRE(F == 0 || (tables && row_offset && idx), "ctr_embed_fwd: null table/index pointer");
+  CTR_REQUIRE(F == 0 || (tables && row_offset && idx) || (blk && fbase && fstride),
+              "ctr_embed_fwd: null table/index pointer");
   CTR_REQUIRE(!z_out || (z_ld % 4 == 0 && ((uintptr_t)z_out % 16) == 0),
               "ctr_embed_fwd: z_out must be 16-byte aligned with z_ld %% 4 == 0");
   CTR_REQUIRE(!(cont_w || cont_tail) || x_cont || C == 0, "ctr_embed_fwd: x_cont missing");
@@ -212,7 +220,7 @@ extern "C" int ctr_embed_fwd(const float* tables, const int64_t* row_offset, con
 #define LAUNCH(GG)                                                                                  \
   hipLaunchKernelGGL((embed_fwd_kernel<GG, false>), grid, block, 0, st, tables, row_offset, idx, x_cont, \
                      cont_w, B, F, C, E, z_out, z_ld, cont_tail, first_out, first_ld, s_out,       \
-                     second_out, second_ld, d1, d2, oor_count)
+                     second_out, second_ld, d1, d2, oor_count, blk, fbase, fstride)
   switch (E / 4) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;
@@ -225,6 +233,30 @@ extern "C" int ctr_embed_fwd(const float* tables, const int64_t* row_offset, con
 #undef LAUNCH
   CTR_LAUNCH_CHECK();
   return CTR_OK;
+}
+
+extern "C" int ctr_embed_fwd(const float* tables, const int64_t* row_offset, const int32_t* idx,
+                             const float* x_cont, const float* cont_w, int B, int F, int C, int E,
+                             float* z_out, int64_t z_ld, int cont_tail, float* first_out,
+                             int64_t first_ld, float* s_out, float* second_out, int64_t second_ld,
+                             const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second,
+                             int32_t* oor_count, void* stream) {
+  return embed_fwd_impl(tables, row_offset, idx, x_cont, cont_w, B, F, C, E, z_out, z_ld, cont_tail, first_out,
+                        first_ld, s_out, second_out, second_ld, drop_first, drop_second, oor_count, nullptr, nullptr,
+                        nullptr, stream);
+}
+
+extern "C" int ctr_embed_assemble_fwd(const float* blocks, const int64_t* fbase, const int64_t* fstride,
+                                      const float* x_cont, const float* cont_w, int B, int F, int C, int E,
+                                      float* z_out, int64_t z_ld, int cont_tail, float* first_out,
+                                      int64_t first_ld, float* s_out, float* second_out, int64_t second_ld,
+                                      const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second,
+                                      void* stream) {
+  CTR_REQUIRE(F == 0 || (blocks && fbase && fstride && ((uintptr_t)blocks % 16) == 0),
+              "ctr_embed_assemble_fwd: null / misaligned block pointer");
+  return embed_fwd_impl(nullptr, nullptr, nullptr, x_cont, cont_w, B, F, C, E, z_out, z_ld, cont_tail, first_out,
+                        first_ld, s_out, second_out, second_ld, drop_first, drop_second, nullptr, blocks, fbase,
+                        fstride, stream);
 }
 
 extern "C" int ctr_fm_fwd(const float* z, int64_t z_ld, int B, int N, int E, float* first_out,
@@ -242,7 +274,8 @@ extern "C" int ctr_fm_fwd(const float* z, int64_t z_ld, int B, int N, int E, flo
   hipLaunchKernelGGL((embed_fwd_kernel<GG, true>), grid, block, 0, st, (const float*)nullptr,      \
                      (const int64_t*)nullptr, (const int32_t*)nullptr, (const float*)nullptr,      \
                      (const float*)nullptr, B, N, 0, E, zz, z_ld, 0, first_out, first_ld, s_out,   \
-                     second_out, second_ld, d1, d2, (int32_t*)nullptr)
+                     second_out, second_ld, d1, d2, (int32_t*)nullptr, (const float*)nullptr,      \
+                     (const int64_t*)nullptr, (const int64_t*)nullptr)
   switch (E / 4) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;
@@ -274,11 +307,12 @@ extern "C" int ctr_embed_onehot_fwd(const float* tables, const int64_t* row_offs
   return CTR_OK;
 }
 
-extern "C" int ctr_embed_bwd_dz(const float* gz, int64_t gz_ld, const float* g_first,
-                                int64_t g_first_ld, const float* g_second, int64_t g_second_ld,
-                                const float* s, const float* z, int64_t z_ld, const float* g_sum, int B,
-                                int N, int E, const ctr_dropout_t* drop_first,
-                                const ctr_dropout_t* drop_second, float* dz, int64_t dz_ld, void* stream) {
+static int embed_bwd_dz_impl(const float* gz, int64_t gz_ld, const float* g_first, int64_t g_first_ld,
+                             const float* g_second, int64_t g_second_ld, const float* s, const float* z,
+                             int64_t z_ld, const float* g_sum, int B, int N, int E,
+                             const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second, float* dz,
+                             int64_t dz_ld, float* blk, const int64_t* fbase, const int64_t* fstride, int F,
+                             void* stream) {
   CTR_REQUIRE(B >= 0 && N >= 0 && E >= 4 && E % 4 == 0, "ctr_embed_bwd_dz: bad size");
   CTR_REQUIRE(dz && dz_ld % 4 == 0 && ((uintptr_t)dz % 16) == 0, "ctr_embed_bwd_dz: dz alignment");
   CTR_REQUIRE(!gz || (gz_ld % 4 == 0 && ((uintptr_t)gz % 16) == 0), "ctr_embed_bwd_dz: gz alignment");
@@ -290,7 +324,28 @@ extern "C" int ctr_embed_bwd_dz(const float* gz, int64_t gz_ld, const float* g_f
   const int64_t blocks = cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096;
   hipLaunchKernelGGL(embed_bwd_dz_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gz,
                      gz_ld, g_first, g_first_ld, g_second, g_second_ld, s, z, z_ld, g_sum, B, N, E,
-                     make_drop(drop_first), make_drop(drop_second), dz, dz_ld);
+                     make_drop(drop_first), make_drop(drop_second), dz, dz_ld, blk, fbase, fstride, F);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
+}
+
+extern "C" int ctr_embed_bwd_dz(const float* gz, int64_t gz_ld, const float* g_first,
+                                int64_t g_first_ld, const float* g_second, int64_t g_second_ld,
+                                const float* s, const float* z, int64_t z_ld, const float* g_sum, int B,
+                                int N, int E, const ctr_dropout_t* drop_first,
+                                const ctr_dropout_t* drop_second, float* dz, int64_t dz_ld, void* stream) {
+  return embed_bwd_dz_impl(gz, gz_ld, g_first, g_first_ld, g_second, g_second_ld, s, z, z_ld, g_sum, B, N, E,
+                           drop_first, drop_second, dz, dz_ld, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int ctr_embed_bwd_dz_blocks(const float* gz, int64_t gz_ld, const float* g_first,
+                                       int64_t g_first_ld, const float* g_second, int64_t g_second_ld,
+                                       const float* s, const float* z, int64_t z_ld, const float* g_sum, int B,
+                                       int N, int E, const ctr_dropout_t* drop_first,
+                                       const ctr_dropout_t* drop_second, float* dz, int64_t dz_ld, float* blocks_out,
+                                       const int64_t* fbase, const int64_t* fstride, int F, void* stream) {
+  CTR_REQUIRE(F >= 0 && F <= N && (F == 0 || (blocks_out && fbase && fstride && ((uintptr_t)blocks_out % 16) == 0)),
+              "ctr_embed_bwd_dz_blocks: block layout arguments");
+  return embed_bwd_dz_impl(gz, gz_ld, g_first, g_first_ld, g_second, g_second_ld, s, z, z_ld, g_sum, B, N, E,
+                           drop_first, drop_second, dz, dz_ld, blocks_out, fbase, fstride, F, stream);
 }

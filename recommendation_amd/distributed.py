@@ -136,6 +136,15 @@ class ShardedFront:
                 src=torch.zeros(max(W * B * self.nf_own, 1), dtype=torch.int32, device=dev),
                 idx_in=[B * n for n in nf], idx_out=[B * self.nf_own] * W,
                 row_in=[B * self.nf_own * E] * W, row_out=[B * n * E for n in nf])
+            # where row n of sample b sits in `blocks` (one [B, nf_j*E] block per owner j, owner after owner)
+            fbase, fstride, off = [], [], 0
+            for a, b in self.ranges:
+                for n in range(a, b):
+                    fbase.append(off + (n - a) * E)
+                    fstride.append((b - a) * E)
+                off += B * (b - a) * E
+            self._buf[B]['fbase'] = torch.tensor(fbase, dtype=torch.int64, device=dev)
+            self._buf[B]['fstride'] = torch.tensor(fstride, dtype=torch.int64, device=dev)
         return self._buf[B]
 
     def _block_views(self, flat, B):
@@ -161,25 +170,26 @@ class ShardedFront:
                           z_out=bf['rows'], oor_count=oor_count)
         self.comm.all_to_all(bf['blocks'], bf['rows'].view(-1)[:W * B * self.nf_own * E], bf['row_out'],
                              bf['row_in'])
-        for (a, b), blk in zip(self.ranges, self._block_views(bf['blocks'], B)):
-            if blk is not None:
-                ops.copy2d(blk, z_out[:, a * E:b * E])
-        if self.cont_embed:
-            ops.embed_fwd(self.t.weight, self.t.row_offset[:1], idx[:, :0].contiguous(), x_cont, cont_w, E=E,
-                          z_out=z_out[:, self.F * E:], cont_tail=cont_tail)
-        elif cont_tail:
-            ops.copy2d(x_cont, z_out[:, self.F * E:self.F * E + self.C])
-        if first_out is not None or s_out is not None or second_out is not None:
-            ops.fm_fwd(z_out, N=self.N, E=E, first_out=first_out, s_out=s_out, second_out=second_out,
-                       drop_first=drop_first, drop_second=drop_second)
+        # one pass: owner blocks -> Z rows, continuous rows / tail, FM sums, dropout
+        ops.embed_assemble_fwd(bf['blocks'], bf['fbase'], bf['fstride'], x_cont if (self.cont_embed or cont_tail) else None,
+                               cont_w if self.cont_embed else None, F=self.F, E=E, z_out=z_out, cont_tail=cont_tail,
+                               first_out=first_out, s_out=s_out, second_out=second_out, drop_first=drop_first,
+                               drop_second=drop_second)
 
-    def backward_tables(self, idx, dz, keys, src, ws, opt, lazy):
+    def dz_route(self, B):
+        """Keyword arguments for ops.embed_bwd_dz: dZ of the sharded fields goes straight into the buffer the
+        gradient exchange sends (then call backward_tables(..., dz_in_blocks=True))."""
+        bf = self._buffers(B)
+        return dict(blocks_out=bf['blocks'], fbase=bf['fbase'], fstride=bf['fstride'], F=self.F)
+
+    def backward_tables(self, idx, dz, keys, src, ws, opt, lazy, dz_in_blocks=False):
         ops, E, W = self.ops, self.E, self.W
         B = idx.shape[0]
         bf = self._buffers(B)
-        for (a, b), blk in zip(self.ranges, self._block_views(bf['blocks'], B)):
-            if blk is not None:
-                ops.copy2d(dz[:, a * E:b * E], blk)
+        if not dz_in_blocks:
+            for (a, b), blk in zip(self.ranges, self._block_views(bf['blocks'], B)):
+                if blk is not None:
+                    ops.copy2d(dz[:, a * E:b * E], blk)
         self.comm.all_to_all(bf['grows'].view(-1)[:W * B * self.nf_own * E], bf['blocks'], bf['row_in'],
                              bf['row_out'])
         if not self.nf_own:

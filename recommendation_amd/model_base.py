@@ -322,6 +322,12 @@ class CTRModel:
     def _backward(self, idx, xc, bufs):
         raise NotImplementedError
 
-    def _tables_backward(self, idx, dz, bufs):
+    def _dz_route(self, B):
+        """Extra keyword arguments for ops.embed_bwd_dz when the front end wants dZ in its exchange layout."""
+        route = getattr(self.front, 'dz_route', None)
+        return route(B) if route is not None else {}
+
+    def _tables_backward(self, idx, dz, bufs, routed=False):
+        kw = dict(dz_in_blocks=True) if routed and hasattr(self.front, 'dz_route') else {}
         self.front.backward_tables(idx, dz, bufs['keys'], bufs['src'], self.session.ws, self._optimizer(),
-                                   lazy=(self.adam_mode == 'lazy'))
+                                   lazy=(self.adam_mode == 'lazy'), **kw)

@@ -173,6 +173,28 @@ def embed_fwd(tables, row_offset, idx, x_cont=None, cont_w=None, *, E, z_out=Non
 
 
 @_timed
+def embed_assemble_fwd(blocks, fbase, fstride, x_cont=None, cont_w=None, *, F, E, z_out, cont_tail=False,
+                       first_out=None, s_out=None, second_out=None, drop_first=None, drop_second=None):
+    """Z from per-owner row blocks (sharded tables) + continuous rows + FM sums, one pass (see embed_fwd)."""
+    B = z_out.shape[0]
+    C_ = 0 if x_cont is None else x_cont.shape[1]
+    if fbase.numel() != F or fstride.numel() != F or fbase.dtype != torch.int64 or fstride.dtype != torch.int64:
+        raise ValueError('fbase / fstride must be int64 [F]')
+    N = F + (C_ if cont_w is not None else 0)
+    zp, zld = _rows(z_out, 'z_out')
+    if z_out.shape[1] < N * E + (C_ if cont_tail else 0):
+        raise ValueError('z_out too small')
+    fp, fld = (None, 0) if first_out is None else _rows(first_out, 'first_out')
+    sp, sld = (None, 0) if second_out is None else _rows(second_out, 'second_out')
+    if s_out is not None and (tuple(s_out.shape) != (B, E) or not s_out.is_contiguous()):
+        raise ValueError('s_out must be contiguous [B,E]')
+    check(lib().ctr_embed_assemble_fwd(_ptr(blocks, torch.float32), _ptr(fbase, torch.int64), _ptr(fstride, torch.int64),
+                                       _ptr(x_cont, torch.float32), _ptr(cont_w, torch.float32), B, int(F), C_, E,
+                                       zp, zld, int(bool(cont_tail)), fp, fld, _ptr(s_out, torch.float32), sp, sld,
+                                       _dp(drop_first), _dp(drop_second), _stream()), 'ctr_embed_assemble_fwd')
+
+
+@_timed
 def fm_fwd(z, *, N, E, first_out=None, s_out=None, second_out=None, drop_first=None, drop_second=None):
     B = z.shape[0]
     zp, zld = _rows(z, 'z')
@@ -216,7 +238,7 @@ def embed_onehot_fwd(tables, row_offset, idx, x_cont, *, E, z_out, cont_tail=Fal
 
 @_timed
 def embed_bwd_dz(dz, *, B, N, E, gz=None, g_first=None, g_second=None, s=None, z=None, g_sum=None,
-                 drop_first=None, drop_second=None):
+                 drop_first=None, drop_second=None, blocks_out=None, fbase=None, fstride=None, F=0):
     dzp, dzld = _rows(dz, 'dz')
     gzp, gzld = (None, 0) if gz is None else _rows(gz, 'gz')
     g1p, g1ld = (None, 0) if g_first is None else _rows(g_first, 'g_first')
@@ -228,6 +250,12 @@ def embed_bwd_dz(dz, *, B, N, E, gz=None, g_first=None, g_second=None, s=None, z
             raise ValueError('%s too small' % nm)
     if g_sum is not None and (tuple(g_sum.shape) != (B, E) or not g_sum.is_contiguous()):
         raise ValueError('g_sum must be contiguous [B,E]')
+    if blocks_out is not None:     # rows of the sharded fields go straight into the exchange buffer
+        check(lib().ctr_embed_bwd_dz_blocks(gzp, gzld, g1p, g1ld, g2p, g2ld, _ptr(s, torch.float32), zp, zld,
+                                            _ptr(g_sum, torch.float32), B, N, E, _dp(drop_first), _dp(drop_second),
+                                            dzp, dzld, _ptr(blocks_out, torch.float32), _ptr(fbase, torch.int64),
+                                            _ptr(fstride, torch.int64), int(F), _stream()), 'ctr_embed_bwd_dz_blocks')
+        return
     check(lib().ctr_embed_bwd_dz(gzp, gzld, g1p, g1ld, g2p, g2ld, _ptr(s, torch.float32), zp, zld,
                                  _ptr(g_sum, torch.float32), B, N, E,
                                  _dp(drop_first), _dp(drop_second), dzp, dzld, _stream()), 'ctr_embed_bwd_dz')

@@ -68,5 +68,5 @@ class DeepFM(CTRModel):
         ops.embed_bwd_dz(bufs['dx0'], B=B, N=N, E=E, gz=bufs['dx0'], g_first=dconcat[:, :N],
                          g_second=dconcat[:, N:N + E], s=bufs['s'], z=bufs['x0'],
                          drop_first=self._drop(self.dropout_fm, 1, True),
-                         drop_second=self._drop(self.dropout_fm, 2, True))
-        self._tables_backward(idx, bufs['dx0'], bufs)
+                         drop_second=self._drop(self.dropout_fm, 2, True), **self._dz_route(B))
+        self._tables_backward(idx, bufs['dx0'], bufs, routed=True)

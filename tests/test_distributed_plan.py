@@ -72,6 +72,16 @@ class TorchBackend:
     def fm_fwd(self, z, **kw):
         raise AssertionError('not used in this test')
 
+    def embed_assemble_fwd(self, blocks, fbase, fstride, x_cont=None, cont_w=None, *, F, E, z_out, cont_tail=False,
+                           **kw):
+        B = z_out.shape[0]
+        rows = torch.arange(B).view(B, 1)
+        for n in range(F):
+            src = int(fbase[n]) + rows * int(fstride[n]) + torch.arange(E).view(1, E)
+            z_out[:, n * E:(n + 1) * E] = blocks[src]
+        if cont_tail:
+            z_out[:, F * E:F * E + x_cont.shape[1]] = x_cont
+
     def emb_sort(self, idx, row_offset, *, N, total_rows, rmode, keys_out, src_out, ws):
         self._idx, self._off = idx.clone(), row_offset
 

@@ -481,3 +481,50 @@ def test_chained_activation_gradients_match_layer_by_layer(ops_ws, M, widths, of
     assert rel_err(g_mid.cpu().numpy(), r_mid) < 1e-5
     assert rel_err(g_out[:, :out].cpu().numpy(), r_out) < 1e-5
     assert (g_out[:, out:] == 9.0).all()
+
+
+def test_embed_assemble_and_routed_dz_match_the_plain_layout(ops_ws):
+    """Z built from per-owner column blocks == the FM front end on the dense Z; dZ routed into the block layout
+    == dZ in the plain layout copied block by block (bit-exact: same arithmetic, other addresses)."""
+    ops, ws = ops_ws
+    B, F, C, E = 130, 7, 3, 16
+    ranges = [(0, 3), (3, 3), (3, 7)]                       # an owner without fields in the middle
+    rng = np.random.default_rng(3)
+    z = rng.standard_normal((B, F * E)).astype(np.float32)
+    xc = rng.standard_normal((B, C)).astype(np.float32)
+    flat, fbase, fstride, off = [], [], [], 0
+    for a, b in ranges:
+        flat.append(z[:, a * E:b * E].reshape(-1))
+        for n in range(a, b):
+            fbase.append(off + (n - a) * E)
+            fstride.append((b - a) * E)
+        off += B * (b - a) * E
+    blocks = dev(np.concatenate(flat))
+    fb, fs = torch.tensor(fbase, device=DEV), torch.tensor(fstride, device=DEV)
+    ld = F * E + 4
+    d1, d2 = ops.make_dropout(0.5, 3, 1), ops.make_dropout(0.5, 3, 2)
+    outs = []
+    for mode in ('plain', 'blocks'):
+        zo = torch.zeros(B, ld, device=DEV)
+        first, s, second = torch.zeros(B, F, device=DEV), torch.zeros(B, E, device=DEV), torch.zeros(B, E, device=DEV)
+        if mode == 'plain':
+            zo[:, :F * E] = dev(z)
+            zo[:, F * E:F * E + C] = dev(xc)
+            ops.fm_fwd(zo, N=F, E=E, first_out=first, s_out=s, second_out=second, drop_first=d1, drop_second=d2)
+        else:
+            ops.embed_assemble_fwd(blocks, fb, fs, dev(xc), None, F=F, E=E, z_out=zo, cont_tail=True, first_out=first,
+                                   s_out=s, second_out=second, drop_first=d1, drop_second=d2)
+        outs.append((zo, first, s, second))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    zo, first, s, second = outs[0]
+    gz = dev(rng.standard_normal((B, ld)).astype(np.float32))
+    g1, g2 = dev(rng.standard_normal((B, F)).astype(np.float32)), dev(rng.standard_normal((B, E)).astype(np.float32))
+    dz_plain = torch.zeros(B, ld, device=DEV)
+    ops.embed_bwd_dz(dz_plain, B=B, N=F, E=E, gz=gz, g_first=g1, g_second=g2, s=s, z=zo, drop_first=d1, drop_second=d2)
+    dz_other, routed = torch.zeros(B, ld, device=DEV), torch.zeros_like(blocks)
+    ops.embed_bwd_dz(dz_other, B=B, N=F, E=E, gz=gz, g_first=g1, g_second=g2, s=s, z=zo, drop_first=d1, drop_second=d2,
+                     blocks_out=routed, fbase=fb, fstride=fs, F=F)
+    want = torch.cat([dz_plain[:, a * E:b * E].reshape(-1) for a, b in ranges])
+    assert torch.equal(routed, want)
+    assert (dz_other == 0).all()                           # every row of this Z belongs to a sharded field
