@@ -263,6 +263,14 @@ def main():
         out['roofline'] = roof_of(dom_name)
         out['roofline_emb'] = roof_of('embed_fwd') if 'embed_fwd' in ks else None
         out['roofline_emb_bwd'] = roof_of('emb_sparse_apply') if 'emb_sparse_apply' in ks else None
+        if out['roofline_emb_bwd'] and 'emb_sparse_apply' in profile:
+            # in the timed region the sparse update shares the GPU with the tower weight gradients (side
+            # stream); its launch time alone on the GPU comes from the single-stream profiling pass
+            r = out['roofline_emb_bwd']
+            alone_us = 1e3 * profile['emb_sparse_apply']['total_ms'] / max(profile['emb_sparse_apply']['calls'], 1)
+            r['shares_gpu_with'] = 'tower weight gradients (side stream)'
+            r['alone_avg_us'] = alone_us
+            r['alone_frac'] = r['bytes_per_launch'] / (alone_us * 1e-6) / 1e9 / HBM_PEAK_GBS
         out['unique_rows_per_step'] = uniq
         out['profile_steps'] = PROFILE_STEPS
         out['kernel_ms_per_step'] = {n: round(v['total_ms'] / PROFILE_STEPS, 4) for n, v in
