@@ -528,3 +528,33 @@ def test_embed_assemble_and_routed_dz_match_the_plain_layout(ops_ws):
     want = torch.cat([dz_plain[:, a * E:b * E].reshape(-1) for a, b in ranges])
     assert torch.equal(routed, want)
     assert (dz_other == 0).all()                           # every row of this Z belongs to a sharded field
+
+
+@pytest.mark.parametrize('B,N,E,P,per_sample', [(1001, 39, 16, 50, True), (7, 7, 16, 5, False), (130, 64, 16, 64, True),
+                                                (66, 17, 16, 33, False), (258, 39, 8, 50, True), (33, 5, 32, 9, True)])
+def test_pnn_inner_product_term_forward_and_backward(ops_ws, B, N, E, P, per_sample):
+    """u = W Z per sample: usq = sum_e u^2; given coef: dZ += W^T (coef * u), dW = sum_b (coef * u) Z^T.
+    E = 16 takes the all-MFMA kernel, the other widths the LDS kernel; both against float64."""
+    ops, ws = ops_ws
+    rng = np.random.default_rng(B + N + P)
+    z = rng.standard_normal((B, N, E)).astype(np.float32)
+    w = (rng.standard_normal((P, N)) / np.sqrt(N)).astype(np.float32)
+    coef = rng.standard_normal((B, P) if per_sample else (P,)).astype(np.float32)
+    dz0 = rng.standard_normal((B, N, E)).astype(np.float32)
+    ld = N * E + 4
+    zd = torch.zeros(B, ld, device=DEV)
+    zd[:, :N * E] = dev(z.reshape(B, -1))
+    usq = torch.zeros(B, P, device=DEV)
+    ops.pnn_inner_fwd(zd[:, :N * E], dev(w), usq, N=N, E=E)
+    u = np.einsum('pn,bne->bpe', w.astype(np.float64), z.astype(np.float64))
+    assert rel_err(usq.cpu().numpy(), (u * u).sum(-1)) < 1e-5
+    dzd = torch.full((B, ld), 3.0, device=DEV)
+    dzd[:, :N * E] = dev(dz0.reshape(B, -1))
+    dw = torch.zeros(P, N, device=DEV)
+    ops.pnn_inner_bwd(zd[:, :N * E], dev(w), dev(coef), dzd[:, :N * E], dw, N=N, E=E, ws=ws)
+    du = u * (coef.astype(np.float64)[:, :, None] if per_sample else coef.astype(np.float64)[None, :, None])
+    dz_ref = dz0 + np.einsum('pn,bpe->bne', w.astype(np.float64), du)
+    dw_ref = np.einsum('bpe,bne->pn', du, z.astype(np.float64))
+    assert rel_err(dzd[:, :N * E].cpu().numpy().reshape(B, N, E), dz_ref) < 1e-5
+    assert rel_err(dw.cpu().numpy(), dw_ref) < 1e-5
+    assert (dzd[:, N * E:] == 3.0).all()
