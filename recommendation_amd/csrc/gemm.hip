@@ -352,19 +352,20 @@ __device__ static inline void split_store8(__bf16* __restrict__ S, int R, int ro
 // writes them to buffer (s+1)%2 - the split's VALU and LDS writes fill the issue slots between MFMAs - and
 // (3) meets the block at ONE barrier.  The loop is unrolled by two so the register sets alternate without
 // moves.
-template <bool A_K, bool B_K, int TBM, int TBN, int WGM>
-__global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K, const float* __restrict__ A,
+template <bool A_K, bool B_K, int TBM, int TBN, int WGM, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void gemm_split_kernel(int M, int N, int K, const float* __restrict__ A,
                                                            int64_t lda, bool vecA, const float* __restrict__ Bm,
                                                            int64_t ldb, bool vecB, float* __restrict__ C,
                                                            int64_t ldc, Epi epi, int k_chunk,
                                                            float* __restrict__ partial) {
-  constexpr int WGN = 4 / WGM;
+  constexpr int NT = 64 * NW;                            // threads: NW waves, each a 64 x 64 output tile
+  constexpr int WGN = NW / WGM;
   constexpr int TM = TBM / WGM / 32, TN = TBN / WGN / 32;
   constexpr int GA = TBM * SKG, GB = TBN * SKG;          // groups of 8 k per operand tile
-  constexpr int NA = (GA + 255) / 256, NB = (GB + 255) / 256;
+  constexpr int NA = (GA + NT - 1) / NT, NB = (GB + NT - 1) / NT;
   constexpr int STAGE = 3 * (TBM + TBN) * SROW;          // bf16 elements of one stage (A planes, then B planes)
   constexpr int OPER = 2 * STAGE * 2;                    // bytes
-  constexpr int SMEM = OPER > 4 * 32 * 36 * 4 ? OPER : 4 * 32 * 36 * 4;
+  constexpr int SMEM = OPER > NW * 32 * 36 * 4 ? OPER : NW * 32 * 36 * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* S0 = reinterpret_cast<__bf16*>(smem_raw);
   static_assert(SMEM <= 160 * 1024, "tile too large for the LDS");
@@ -397,30 +398,30 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K,
     if (fast) {
 #pragma unroll
       for (int q = 0; q < NA; ++q) {
-        const int g = t + 256 * q;
-        if (GA % 256 == 0 || g < GA)
+        const int g = t + NT * q;
+        if (GA % NT == 0 || g < GA)
           split_load8<A_K, true>(A, lda, vecA, m0 + (A_K ? g / SKG : g % TBM), M, k0 + 8 * (A_K ? g % SKG : g / TBM), kend,
                                  va[q]);
       }
 #pragma unroll
       for (int q = 0; q < NB; ++q) {
-        const int g = t + 256 * q;
-        if (GB % 256 == 0 || g < GB)
+        const int g = t + NT * q;
+        if (GB % NT == 0 || g < GB)
           split_load8<B_K, true>(Bm, ldb, vecB, n0 + (B_K ? g / SKG : g % TBN), N, k0 + 8 * (B_K ? g % SKG : g / TBN), kend,
                                  vb[q]);
       }
     } else {
 #pragma unroll
       for (int q = 0; q < NA; ++q) {
-        const int g = t + 256 * q;
-        if (GA % 256 == 0 || g < GA)
+        const int g = t + NT * q;
+        if (GA % NT == 0 || g < GA)
           split_load8<A_K, false>(A, lda, vecA, m0 + (A_K ? g / SKG : g % TBM), M, k0 + 8 * (A_K ? g % SKG : g / TBM), kend,
                                   va[q]);
       }
 #pragma unroll
       for (int q = 0; q < NB; ++q) {
-        const int g = t + 256 * q;
-        if (GB % 256 == 0 || g < GB)
+        const int g = t + NT * q;
+        if (GB % NT == 0 || g < GB)
           split_load8<B_K, false>(Bm, ldb, vecB, n0 + (B_K ? g / SKG : g % TBN), N, k0 + 8 * (B_K ? g % SKG : g / TBN), kend,
                                   vb[q]);
       }
@@ -429,13 +430,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(int M, int N, int K,
   auto store_stage = [&](__bf16* S, const float (&va)[NA][8], const float (&vb)[NB][8]) {
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
-      const int g = t + 256 * q;
-      if (GA % 256 == 0 || g < GA) split_store8(S, TBM, A_K ? g / SKG : g % TBM, A_K ? g % SKG : g / TBM, va[q]);
+      const int g = t + NT * q;
+      if (GA % NT == 0 || g < GA) split_store8(S, TBM, A_K ? g / SKG : g % TBM, A_K ? g % SKG : g / TBM, va[q]);
     }
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
-      const int g = t + 256 * q;
-      if (GB % 256 == 0 || g < GB)
+      const int g = t + NT * q;
+      if (GB % NT == 0 || g < GB)
         split_store8(S + 3 * TBM * SROW, TBN, B_K ? g / SKG : g % TBN, B_K ? g % SKG : g / TBN, vb[q]);
     }
   };
@@ -865,11 +866,15 @@ struct Plan {
   int bm, bn, tiles_m, tiles_n, splits, k_chunk;
 };
 
-static Plan make_plan(int M, int N, int K) {
+static int g_gemm_mode = CTR_GEMM_SPLIT_BF16;
+
+static Plan make_plan(int M, int N, int K, bool wide_ok) {
   Plan p;
-  // narrow outputs get tall tiles so the MFMA work is not spent on padding columns
+  // narrow outputs get tall tiles so the MFMA work is not spent on padding columns; wide outputs (split kernel
+  // only) get a 128 x 256 tile on eight waves, so a row block of A is fetched and split once per 256 columns
   if (N <= 32) { p.bm = 256; p.bn = 32; }
   else if (N <= 64) { p.bm = 256; p.bn = 64; }
+  else if (wide_ok && N > 192 && M >= 128 && K >= 512) { p.bm = 128; p.bn = 256; }   // short K: no gain in a step
   else { p.bm = 128; p.bn = 128; }
   p.tiles_m = (int)cdiv(M, p.bm);
   p.tiles_n = (int)cdiv(N, p.bn);
@@ -893,11 +898,10 @@ static Plan make_plan(int M, int N, int K) {
 
 using namespace ctr;
 
-static int g_gemm_mode = CTR_GEMM_SPLIT_BF16;
 
 static size_t split_lds_bytes(int tbm, int tbn) {
   const size_t oper = (size_t)2 * 3 * (tbm + tbn) * ctr::SROW * 2;
-  const size_t epi = (size_t)4 * 32 * 36 * 4;
+  const size_t epi = (size_t)8 * 32 * 36 * 4;
   return oper > epi ? oper : epi;
 }
 
@@ -947,8 +951,10 @@ static size_t bt_floats(int N, int K) { return (size_t)K * (size_t)((N + 3) / 4 
 
 extern "C" size_t ctr_gemm_f32_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  const Plan p = make_plan(M, N, K);
-  size_t need = p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+  // the transposition flags are not known here: the larger of the two tile plans' split-K slab counts
+  const Plan pn = make_plan(M, N, K, false), pw = make_plan(M, N, K, true);
+  const int splits = pn.splits > pw.splits ? pn.splits : pw.splits;
+  size_t need = splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
   if (pretranspose_b(M, N, K)) need = align_up(need, 256) + bt_floats(N, K) * sizeof(float);
   return need;
 }
@@ -1000,7 +1006,7 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
       return CTR_OK;
     }
   }
-  const Plan p = make_plan(M, N, K);
+  const Plan p = make_plan(M, N, K, g_gemm_mode == CTR_GEMM_SPLIT_BF16 && !trans_a);   // wide tiles lose on A^T B (measured)
   float* partial = nullptr;
   if (p.splits > 1) {
     const size_t need = (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float);
@@ -1039,10 +1045,19 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
       hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, TBM, TBN, WGM>), grid, block, 0, st, M, N, K, A, lda, vecA, B,  \
                          ldb, vecB, C, ldc, e, p.k_chunk, partial);                                         \
   } while (0)
+#define LAUNCH_WIDE(AK, BK_)                                                                                 \
+  do {                                                                                                      \
+    const size_t lds_ = split_lds_bytes(128, 256);                                                          \
+    CTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<AK, BK_, 128, 256, 2, 8>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));                    \
+    hipLaunchKernelGGL((gemm_split_kernel<AK, BK_, 128, 256, 2, 8>), grid, dim3(512), lds_, st, M, N, K, A, lda, vecA, \
+                       B, ldb, vecB, C, ldc, e, p.k_chunk, partial);                                        \
+  } while (0)
 #define LAUNCH(AK, BK_)                                    \
   do {                                                     \
     if (p.bn == 32) LAUNCH3(AK, BK_, 256, 32, 4);          \
     else if (p.bn == 64) LAUNCH3(AK, BK_, 256, 64, 4);     \
+    else if (p.bn == 256) LAUNCH_WIDE(AK, BK_);            \
     else LAUNCH3(AK, BK_, 128, 128, 2);                    \
   } while (0)
   if (!trans_a && !trans_b) LAUNCH(true, false);
@@ -1050,6 +1065,7 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
   else if (trans_a && !trans_b) LAUNCH(false, false);
   else LAUNCH(false, true);
 #undef LAUNCH
+#undef LAUNCH_WIDE
 #undef LAUNCH3
   if (partial) {
     const int64_t total = (int64_t)M * N;
