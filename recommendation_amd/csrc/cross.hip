@@ -246,32 +246,29 @@ __global__ __launch_bounds__(256) void cross_bwd_partial_kernel(const float* __r
   }
 }
 
-// Sums the chunk partials in a fixed order and finishes dw / db.  Block = 64 columns x 4 chunk groups.
-__global__ __launch_bounds__(256) void cross_bwd_final_kernel(const float* __restrict__ part,
-                                                             const float* __restrict__ psdq, int nchunks,
-                                                             const float* __restrict__ w, int64_t wld,
-                                                             const float* __restrict__ Bl, int D, int DP, int L,
-                                                             float* __restrict__ dw, float* __restrict__ db) {
-  __shared__ float red[4][LMAX + 1][64];
+// Sums the chunk partials in a fixed order and finishes dw / db.  Block = 64 columns x 16 chunk phases.
+constexpr int CF_PH = 16;
+__global__ __launch_bounds__(64 * CF_PH) void cross_bwd_final_kernel(const float* __restrict__ part,
+                                                                    const float* __restrict__ psdq, int nchunks,
+                                                                    const float* __restrict__ w, int64_t wld,
+                                                                    const float* __restrict__ Bl, int D, int DP, int L,
+                                                                    float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float red[CF_PH][LMAX + 1][64];
   __shared__ float sdq[LMAX];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + tx;
-  if (ty < 2) {                                    // waves 0 and 1 each total four of the dq sums over the chunks
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int l = ty * 4 + u;
-      float v = 0.f;
-      if (l < L)
-        for (int c = tx; c < nchunks; c += 64) v += psdq[(int64_t)c * LMAX + l];
-      v = wave_sum(v);
-      if (tx == 0) sdq[l] = v;
-    }
+  if (ty < LMAX) {                                 // wave l totals the dq sums of layer l over the chunks
+    float v = 0.f;
+    if (ty < L)
+      for (int c = tx; c < nchunks; c += 64) v += psdq[(int64_t)c * LMAX + ty];
+    v = wave_sum(v);
+    if (tx == 0) sdq[ty] = v;
   }
   float acc[LMAX + 1];
 #pragma unroll
   for (int l = 0; l <= LMAX; ++l) acc[l] = 0.f;
   if (j < D)
-    for (int c = ty; c < nchunks; c += 4) {
+    for (int c = ty; c < nchunks; c += CF_PH) {
 #pragma unroll
       for (int l = 0; l <= LMAX; ++l)
         if (l <= L) acc[l] += part[((int64_t)c * (L + 1) + l) * DP + j];
@@ -280,14 +277,26 @@ __global__ __launch_bounds__(256) void cross_bwd_final_kernel(const float* __res
   for (int l = 0; l <= LMAX; ++l) red[ty][l][tx] = acc[l];
   __syncthreads();
   if (ty != 0 || j >= D) return;
-  // dBl_L = colsum(g); dBl_l = sdq_l * w_l (l < L); db_l' = sum_{l > l'} dBl_l
-  float run = (red[0][L][tx] + red[1][L][tx]) + (red[2][L][tx] + red[3][L][tx]);
-  for (int l = L - 1; l >= 0; --l) {
-    db[(int64_t)l * wld + j] = run;
-    run += sdq[l] * w[(int64_t)l * wld + j];
-    const float a = (red[0][l][tx] + red[1][l][tx]) + (red[2][l][tx] + red[3][l][tx]);
-    dw[(int64_t)l * wld + j] = a + sdq[l] * Bl[(int64_t)l * DP + j];
+  float tot[LMAX + 1];
+#pragma unroll
+  for (int l = 0; l <= LMAX; ++l) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < CF_PH; ++q) v += red[q][l][tx];
+    tot[l] = v;
   }
+  // dBl_L = colsum(g); dBl_l = sdq_l * w_l (l < L); db_l' = sum_{l > l'} dBl_l
+  float run = 0.f;
+#pragma unroll
+  for (int l = 0; l <= LMAX; ++l)
+    if (l == L) run = tot[l];
+#pragma unroll
+  for (int l = LMAX - 1; l >= 0; --l)
+    if (l < L) {
+      db[(int64_t)l * wld + j] = run;
+      run += sdq[l] * w[(int64_t)l * wld + j];
+      dw[(int64_t)l * wld + j] = tot[l] + sdq[l] * Bl[(int64_t)l * DP + j];
+    }
 }
 
 static int cross_chunks(int B) {
@@ -370,7 +379,7 @@ extern "C" int ctr_cross_bwd(const float* x0, int64_t x0_ld, const float* w, con
   CROSS_DISPATCH(cross_bwd_kernel, x0, x0_ld, w, wld, aux, g, g_ld, B, D, L, dx0, dx0_ld, accumulate, dpq);
   hipLaunchKernelGGL(cross_bwd_partial_kernel, dim3((unsigned)cdiv(D, 256), nchunks), dim3(256), 0, st, x0,
                      x0_ld, g, g_ld, dpq, B, D, DP, L, rows_per_chunk, part, psdq);
-  hipLaunchKernelGGL(cross_bwd_final_kernel, dim3((unsigned)cdiv(D, 64)), dim3(256), 0, st, part, psdq, nchunks, w,
+  hipLaunchKernelGGL(cross_bwd_final_kernel, dim3((unsigned)cdiv(D, 64)), dim3(64 * CF_PH), 0, st, part, psdq, nchunks, w,
                      wld, Bl, D, DP, L, dw, db);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
