@@ -248,7 +248,7 @@ int ctr_rowdot_bwd_x(const float* g, const float* w, int B, int K,
 /* Whole backward of the output unit y = X w + b in one pass over X (DeepFM/DeepFM.py:82-88, same unit in
  * NFM/NFM.py:76-81, DCN/DCN.py:84-89):  dX[b,k] = dl[b] w[k], dw[k] = sum_b X[b,k] dl[b], db = sum_b dl[b].
  * Columns k >= mask_from of X are the output of the tower's last relu (+ dropout) layer: their dX is also
- * multiplied by mask_scale * [X[b,k] > 0] (mask_from = K or < 0: no masked range).  K <= 255
+ * multiplied by mask_scale * [X[b,k] > 0] (mask_from = K or < 0: no masked range).  K <= 4096
  * (ctr_unit_bwd_supported); fixed summation order. */
 int ctr_unit_bwd_supported(int K);
 size_t ctr_unit_bwd_workspace_bytes(int B, int K);

@@ -293,7 +293,8 @@ extern "C" int ctr_rowdot_bwd_x(const float* g, const float* w, int B, int K, fl
 }
 
 namespace ctr {
-constexpr int UB_KMAX = 255;             // columns the fused output-unit backward covers (one thread each, + bias slot)
+constexpr int UB_KMAX = 255;             // widest unit of the thread-per-column kernel (+ bias slot)
+constexpr int UB_KWIDE = 4096;           // widest unit of the columns-per-thread kernel
 constexpr int UB_BLOCKS = 1024;
 constexpr int UB_U = 8;                  // steps in flight per thread
 
@@ -352,6 +353,60 @@ __global__ __launch_bounds__(256) void unit_bwd_kernel(int B, int K, const float
   }
 }
 
+// The same for a wide unit (K > 255, e.g. DCN's [x_L | tower] stack): thread t owns columns t, t + 256, ...
+// (NC of them) of every sample row of the block's range; two rows in flight.
+template <int NC>
+__global__ __launch_bounds__(256) void unit_bwd_wide_kernel(int B, int K, const float* __restrict__ dl,
+                                                           const float* __restrict__ w, const float* __restrict__ X,
+                                                           int64_t ldx, float* __restrict__ dX, int64_t lddx,
+                                                           int mask_from, float mask_scale, int rows_per_block,
+                                                           float* __restrict__ part) {
+  const int t = threadIdx.x;
+  float wv[NC], acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int k = t + 256 * c;
+    wv[c] = k < K ? w[k] : 0.f;
+    acc[c] = 0.f;
+  }
+  const int64_t b0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t b1 = b0 + rows_per_block < B ? b0 + rows_per_block : B;
+  float dsum = 0.f;
+  for (int64_t b = b0; b < b1; b += 2) {
+    const bool two = b + 1 < b1;
+    const float d0 = dl[b], d1 = two ? dl[b + 1] : 0.f;
+    dsum += d0 + d1;
+    float x0[NC], x1[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int k = t + 256 * c;
+      x0[c] = k < K ? X[b * ldx + k] : 0.f;
+      x1[c] = (two && k < K) ? X[(b + 1) * ldx + k] : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int k = t + 256 * c;
+      if (k < K) {
+        acc[c] += x0[c] * d0;
+        acc[c] += x1[c] * d1;
+        float g0 = d0 * wv[c], g1 = d1 * wv[c];
+        if (k >= mask_from) {
+          g0 = x0[c] > 0.f ? g0 * mask_scale : 0.f;
+          g1 = x1[c] > 0.f ? g1 * mask_scale : 0.f;
+        }
+        dX[b * lddx + k] = g0;
+        if (two) dX[(b + 1) * lddx + k] = g1;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int k = t + 256 * c;
+    if (k < K) part[(int64_t)blockIdx.x * (K + 1) + k] = acc[c];
+  }
+  if (t == 0) part[(int64_t)blockIdx.x * (K + 1) + K] = dsum;   // every thread walked the same dl values
+}
+
 // out[k] = sum over the partial rows in a fixed order; column K is the bias gradient
 __global__ __launch_bounds__(1024) void unit_bwd_final_kernel(const float* __restrict__ part, int nrows, int K,
                                                              float* __restrict__ dw, float* __restrict__ db) {
@@ -382,22 +437,23 @@ __global__ __launch_bounds__(1024) void unit_bwd_final_kernel(const float* __res
 }
 }  // namespace ctr
 
-static int unit_bwd_rows_per_block(int B) {
+static int unit_bwd_rows_per_block(int B, int K) {
   const int64_t rows = cdiv(B > 0 ? B : 1, UB_BLOCKS);
-  return (int)(rows < 32 ? 32 : rows);
+  const int lo = K <= UB_KMAX ? 32 : 8;   // a wide row keeps a block busy on its own
+  return (int)(rows < lo ? lo : rows);
 }
-static int unit_bwd_blocks(int B) { return (int)cdiv(B > 0 ? B : 1, unit_bwd_rows_per_block(B)); }
+static int unit_bwd_blocks(int B, int K) { return (int)cdiv(B > 0 ? B : 1, unit_bwd_rows_per_block(B, K)); }
 
-extern "C" int ctr_unit_bwd_supported(int K) { return K >= 1 && K <= UB_KMAX; }
+extern "C" int ctr_unit_bwd_supported(int K) { return K >= 1 && K <= UB_KWIDE; }
 
 extern "C" size_t ctr_unit_bwd_workspace_bytes(int B, int K) {
-  return (size_t)unit_bwd_blocks(B) * (size_t)(K + 1) * sizeof(float);
+  return (size_t)unit_bwd_blocks(B, K) * (size_t)(K + 1) * sizeof(float);
 }
 
 extern "C" int ctr_unit_bwd(int B, int K, const float* dl, const float* w, const float* X, int64_t ldx, float* dX,
                             int64_t lddx, int mask_from, float mask_scale, float* dw, float* db, void* workspace,
                             size_t workspace_bytes, void* stream) {
-  CTR_REQUIRE(B > 0 && ctr_unit_bwd_supported(K), "ctr_unit_bwd: need B > 0 and 1 <= K <= %d", UB_KMAX);
+  CTR_REQUIRE(B > 0 && ctr_unit_bwd_supported(K), "ctr_unit_bwd: need B > 0 and 1 <= K <= %d", UB_KWIDE);
   CTR_REQUIRE(dl && w && X && dX && dw && workspace, "ctr_unit_bwd: null pointer");
   CTR_REQUIRE(ldx >= K && lddx >= K, "ctr_unit_bwd: leading dimension < K");
   if (workspace_bytes < ctr_unit_bwd_workspace_bytes(B, K)) {
@@ -405,11 +461,21 @@ extern "C" int ctr_unit_bwd(int B, int K, const float* dl, const float* w, const
     return CTR_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int nb = unit_bwd_blocks(B);
+  const int nb = unit_bwd_blocks(B, K);
   float* part = (float*)workspace;
   if (mask_from < 0 || mask_from > K) mask_from = K;
-  hipLaunchKernelGGL(unit_bwd_kernel, dim3(nb), dim3(256), 0, st, B, K, dl, w, X, ldx, dX, lddx, mask_from, mask_scale,
-                     unit_bwd_rows_per_block(B), part);
+  const int rpb = unit_bwd_rows_per_block(B, K);
+  if (K <= UB_KMAX) {
+    hipLaunchKernelGGL(unit_bwd_kernel, dim3(nb), dim3(256), 0, st, B, K, dl, w, X, ldx, dX, lddx, mask_from, mask_scale,
+                       rpb, part);
+  } else {
+#define UW(NC_)                                                                                                  \
+  hipLaunchKernelGGL(unit_bwd_wide_kernel<NC_>, dim3(nb), dim3(256), 0, st, B, K, dl, w, X, ldx, dX, lddx, mask_from, \
+                     mask_scale, rpb, part)
+    const int nc = (int)cdiv(K, 256);
+    if (nc <= 2) UW(2); else if (nc <= 4) UW(4); else if (nc <= 8) UW(8); else if (nc <= 12) UW(12); else UW(16);
+#undef UW
+  }
   hipLaunchKernelGGL(unit_bwd_final_kernel, dim3((unsigned)cdiv(K + 1, 64)), dim3(1024), 0, st, part, nb, K, dw, db);
   CTR_LAUNCH_CHECK();
   return CTR_OK;

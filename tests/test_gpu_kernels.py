@@ -436,7 +436,8 @@ def test_chained_tower_layers_match_layer_by_layer_gemms(ops_ws, M, K0, widths, 
         assert (big[:, c - widths[-1] - 3:c - widths[-1]] == 5.0).all()
 
 
-@pytest.mark.parametrize('B,K,mask_from', [(1000, 74, 42), (65, 255, -1), (4099, 17, 0), (3, 1, 1)])
+@pytest.mark.parametrize('B,K,mask_from', [(1000, 74, 42), (65, 255, -1), (4099, 17, 0), (3, 1, 1), (515, 2701, 1677), (33, 256, 100),
+                                           (70, 4096, -1)])
 def test_fused_output_unit_backward(ops_ws, B, K, mask_from):
     """dX = dl w^T with the relu/dropout mask on the tail columns, dw = X^T dl, db = sum dl, in one pass"""
     ops, ws = ops_ws
@@ -448,7 +449,7 @@ def test_fused_output_unit_backward(ops_ws, B, K, mask_from):
     xd[:, :K] = dev(x)
     dxd = torch.full((B, K + 5), 7.0, device=DEV)
     dw, db = torch.zeros(K, device=DEV), torch.zeros(1, device=DEV)
-    assert ops.unit_bwd_supported(K) and not ops.unit_bwd_supported(256)
+    assert ops.unit_bwd_supported(K) and not ops.unit_bwd_supported(4097)
     ops.unit_bwd(dev(dl), dev(w), xd[:, :K], dxd[:, :K], dw, db, mask_from=mask_from, mask_scale=1.25, ws=ws)
     ref = dl[:, None].astype(np.float64) * w[None, :]
     if mask_from >= 0:
