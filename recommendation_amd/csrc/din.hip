@@ -17,6 +17,23 @@ __global__ __launch_bounds__(256) void din_build_idx_kernel(const int32_t* __res
   }
 }
 
+// fixed-order block reductions over 256 threads (4 waves): wave result, then the four in order
+__device__ static inline float block_sum256(float v, float* red4) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red4[0] + red4[1]) + (red4[2] + red4[3]);
+}
+__device__ static inline float block_max256(float v, float* red4) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red4[0], red4[1]), fmaxf(red4[2], red4[3]));
+}
+
 // row (b,t) of out = [q_b, k_bt, q_b - k_bt, q_b * k_bt]           (DIN/DIN.py:171-174)
 __global__ __launch_bounds__(256) void din_concat_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                         int B, int T, int H, float* __restrict__ out) {
@@ -55,6 +72,52 @@ __global__ __launch_bounds__(256) void din_concat_bwd_kernel(const float* __rest
     }
     float* o = dq + b * H + h;
     *o = acc_q ? *o + a : a;
+  }
+}
+
+// The same with a block per sample for H dividing 256: thread (t-group, h) walks every (256/H)-th history
+// position, four positions in flight, so the loads of one step are whole contiguous rows of d_all and k;
+// the t-groups' dq terms are added through LDS in group order.
+__global__ __launch_bounds__(256) void din_concat_bwd_block_kernel(const float* __restrict__ d_all,
+                                                                  const float* __restrict__ q,
+                                                                  const float* __restrict__ k, int B, int T, int H,
+                                                                  float* __restrict__ dq, int acc_q,
+                                                                  float* __restrict__ dk, int acc_k) {
+  __shared__ float red[256];
+  const int64_t b = blockIdx.x;
+  const int G = 256 / H;
+  const int tg = threadIdx.x / H, h = threadIdx.x - tg * H;
+  const float qv = q[b * H + h];
+  float a = 0.f;
+  for (int t0 = tg; t0 < T; t0 += 4 * G) {
+    float d0[4], d1[4], d2[4], d3[4], kv[4], old[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * G;
+      const bool live = t < T;
+      const int64_t bt = b * T + (live ? t : 0);
+      const float* d = d_all + bt * 4 * H;
+      d0[u] = live ? d[h] : 0.f;
+      d1[u] = live ? d[H + h] : 0.f;
+      d2[u] = live ? d[2 * H + h] : 0.f;
+      d3[u] = live ? d[3 * H + h] : 0.f;
+      kv[u] = live ? k[bt * H + h] : 0.f;
+      old[u] = (live && acc_k) ? dk[bt * H + h] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * G;
+      if (t < T) dk[(b * T + t) * H + h] = old[u] + (d1[u] - d2[u] + d3[u] * qv);
+      a += d0[u] + d2[u] + d3[u] * kv[u];
+    }
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (tg == 0) {
+    float v = 0.f;
+    for (int g2 = 0; g2 < G; ++g2) v += red[g2 * H + h];
+    float* o = dq + b * H + h;
+    *o = acc_q ? *o + v : v;
   }
 }
 
@@ -99,6 +162,59 @@ __global__ __launch_bounds__(256) void din_attn_pool_fwd_kernel(const float* __r
   }
 }
 
+// The same with a block per sample (H divides 256): the softmax over T on all 256 threads, the weights
+// staged in LDS, then thread (t-group, h) pools every (256/H)-th position - whole rows of K per step.
+__global__ __launch_bounds__(256) void din_attn_pool_fwd_block_kernel(const float* __restrict__ score,
+                                                                     const int32_t* __restrict__ sl,
+                                                                     const float* __restrict__ K, int B, int T, int H,
+                                                                     float* __restrict__ att, float* __restrict__ out) {
+  extern __shared__ float sm[];       // att_s[T], red[256], red4[4]
+  float* att_s = sm;
+  float* red = sm + T;
+  float* red4 = red + 256;
+  const int64_t b = blockIdx.x;
+  const float inv = 1.f / sqrtf((float)H);
+  const float pad = -4294967295.f;  // -2**32 + 1
+  const int len = sl[b];
+  float mx = -INFINITY;
+  for (int t = threadIdx.x; t < T; t += 256) mx = fmaxf(mx, (t < len ? score[b * T + t] : pad) * inv);
+  mx = block_max256(mx, red4);
+  float sum = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) sum += expf((t < len ? score[b * T + t] : pad) * inv - mx);
+  sum = block_sum256(sum, red4);
+  const float rs = 1.f / sum;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const float a = expf((t < len ? score[b * T + t] : pad) * inv - mx) * rs;
+    att[b * T + t] = a;
+    att_s[t] = a;
+  }
+  __syncthreads();
+  const int G = 256 / H;
+  const int tg = threadIdx.x / H, h = threadIdx.x - tg * H;
+  const float* Kb = K + b * T * H;
+  float acc = 0.f;
+  for (int t0 = tg; t0 < T; t0 += 4 * G) {
+    float kv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * G;
+      kv[u] = t < T ? Kb[(int64_t)t * H + h] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * G;
+      if (t < T) acc += att_s[t] * kv[u];
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (tg == 0) {
+    float v = 0.f;
+    for (int g2 = 0; g2 < G; ++g2) v += red[g2 * H + h];
+    out[b * H + h] = v;
+  }
+}
+
 // datt[t] = dout . K[t];  dscore[t] = att[t] * (datt[t] - sum_j att[j] datt[j]) / sqrt(H)  (0 where masked)
 // dK[b,t,:] (+)= att[t] * dout
 __global__ __launch_bounds__(256) void din_attn_pool_bwd_kernel(const float* __restrict__ dout,
@@ -128,6 +244,60 @@ __global__ __launch_bounds__(256) void din_attn_pool_bwd_kernel(const float* __r
       float* o = dK + (b * T + t) * H + h;
       const float g = a * dout[b * H + h];
       *o = acc_k ? *o + g : g;
+    }
+  }
+}
+
+// Block per sample (H divides 256, H % 4 == 0): thread t forms datt[t] from its own row of K with 16-byte
+// loads, the block adds sum_j att[j] datt[j] in a fixed order, then thread (t-group, h) writes dK row-wise.
+__global__ __launch_bounds__(256) void din_attn_pool_bwd_block_kernel(const float* __restrict__ dout,
+                                                                     const float* __restrict__ att,
+                                                                     const int32_t* __restrict__ sl,
+                                                                     const float* __restrict__ K, int B, int T, int H,
+                                                                     float* __restrict__ dscore,
+                                                                     float* __restrict__ dK, int acc_k) {
+  extern __shared__ float sm[];       // att_s[T], do_s[H], red4[4]
+  float* att_s = sm;
+  float* do_s = sm + T;
+  float* red4 = do_s + H;
+  const int64_t b = blockIdx.x;
+  const float inv = 1.f / sqrtf((float)H);
+  const int len = sl[b];
+  for (int h = threadIdx.x; h < H; h += 256) do_s[h] = dout[b * H + h];
+  __syncthreads();
+  const float* Kb = K + b * T * H;
+  float dot = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    float da = 0.f;
+    for (int h = 0; h < H; h += 4) {
+      const float4 kv = *reinterpret_cast<const float4*>(Kb + (int64_t)t * H + h);
+      da += (do_s[h] * kv.x + do_s[h + 1] * kv.y) + (do_s[h + 2] * kv.z + do_s[h + 3] * kv.w);
+    }
+    const float a = att[b * T + t];
+    att_s[t] = a;
+    dscore[b * T + t] = da;   // staged: datt
+    dot += a * da;
+  }
+  dot = block_sum256(dot, red4);
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const float da = dscore[b * T + t];
+    dscore[b * T + t] = t < len ? att_s[t] * (da - dot) * inv : 0.f;
+  }
+  const int G = 256 / H;
+  const int tg = threadIdx.x / H, h = threadIdx.x - tg * H;
+  const float dv = do_s[h];
+  float* dKb = dK + b * T * H;
+  for (int t0 = tg; t0 < T; t0 += 4 * G) {
+    float old[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * G;
+      old[u] = (acc_k && t < T) ? dKb[(int64_t)t * H + h] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * G;
+      if (t < T) dKb[(int64_t)t * H + h] = old[u] + att_s[t] * dv;
     }
   }
 }
@@ -239,8 +409,12 @@ extern "C" int ctr_din_concat_bwd(const float* d_all, const float* q, const floa
   CTR_REQUIRE(B >= 0 && T >= 0 && H > 0, "ctr_din_concat_bwd: bad size");
   if (B == 0) return CTR_OK;
   CTR_REQUIRE(d_all && q && k && dq && dk, "ctr_din_concat_bwd: null pointer");
-  hipLaunchKernelGGL(din_concat_bwd_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, d_all, q,
-                     k, B, T, H, dq, accumulate_q, dk, accumulate_k);
+  if (H <= 256 && 256 % H == 0)
+    hipLaunchKernelGGL(din_concat_bwd_block_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, d_all, q, k,
+                       B, T, H, dq, accumulate_q, dk, accumulate_k);
+  else
+    hipLaunchKernelGGL(din_concat_bwd_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, d_all, q,
+                       k, B, T, H, dq, accumulate_q, dk, accumulate_k);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
@@ -250,8 +424,12 @@ extern "C" int ctr_din_attn_pool_fwd(const float* score, const int32_t* sl, cons
   CTR_REQUIRE(B >= 0 && T > 0 && H > 0, "ctr_din_attn_pool_fwd: bad size");
   if (B == 0) return CTR_OK;
   CTR_REQUIRE(score && sl && K && att_out && out, "ctr_din_attn_pool_fwd: null pointer");
-  hipLaunchKernelGGL(din_attn_pool_fwd_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, score,
-                     sl, K, B, T, H, att_out, out);
+  if (H <= 256 && 256 % H == 0 && T <= 8192)
+    hipLaunchKernelGGL(din_attn_pool_fwd_block_kernel, dim3((unsigned)B), dim3(256), (size_t)(T + 260) * sizeof(float),
+                       (hipStream_t)stream, score, sl, K, B, T, H, att_out, out);
+  else
+    hipLaunchKernelGGL(din_attn_pool_fwd_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, score,
+                       sl, K, B, T, H, att_out, out);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
@@ -261,8 +439,13 @@ extern "C" int ctr_din_attn_pool_bwd(const float* dout, const float* att, const 
   CTR_REQUIRE(B >= 0 && T > 0 && H > 0, "ctr_din_attn_pool_bwd: bad size");
   if (B == 0) return CTR_OK;
   CTR_REQUIRE(dout && att && sl && K && dscore && dK, "ctr_din_attn_pool_bwd: null pointer");
-  hipLaunchKernelGGL(din_attn_pool_bwd_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, dout,
-                     att, sl, K, B, T, H, dscore, dK, accumulate_k);
+  if (H <= 256 && 256 % H == 0 && H % 4 == 0 && T <= 8192 && ((uintptr_t)K % 16) == 0)
+    hipLaunchKernelGGL(din_attn_pool_bwd_block_kernel, dim3((unsigned)B), dim3(256),
+                       (size_t)(T + H + 4) * sizeof(float), (hipStream_t)stream, dout, att, sl, K, B, T, H, dscore, dK,
+                       accumulate_k);
+  else
+    hipLaunchKernelGGL(din_attn_pool_bwd_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, dout,
+                       att, sl, K, B, T, H, dscore, dK, accumulate_k);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }

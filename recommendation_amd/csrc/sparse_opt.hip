@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void sparse_apply_tail_kernel(
       if (ok[u]) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
       all = all && ok[u];
     }
-    // the run ends inside this round as soon as one slot misses (wave-uniform exit)
+    // the run ends inside this trip as soon as one slot misses (wave-uniform exit)
     if (__ballot(all) != __ballot(1)) break;
   }
 #pragma unroll
