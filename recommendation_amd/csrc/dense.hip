@@ -43,27 +43,31 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 }
 
 // block (64, 4): row phase ty sums chunks ty, ty+4, ...; the four phases are added in a fixed order
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nchunks, int K,
-                                                          float* __restrict__ out, int accumulate) {
-  __shared__ float red[4][64];
+constexpr int CS_PH = 16;   // chunk phases of the final sum: hundreds of partial rows over four phases made this
+                            // launch longer than the pass that produced them
+__global__ __launch_bounds__(64 * CS_PH) void colsum_final_kernel(const float* __restrict__ part, int nchunks, int K,
+                                                                 float* __restrict__ out, int accumulate) {
+  __shared__ float red[CS_PH][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + tx;
   float acc = 0.f;
   if (j < K) {
     int c = ty;
-    for (; c + 12 < nchunks; c += 16) {
-      float v[4];
+    for (; c + 7 * CS_PH < nchunks; c += 8 * CS_PH) {
+      float v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = part[(int64_t)(c + 4 * u) * K + j];
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(c + CS_PH * u) * K + j];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc += v[u];
+      for (int u = 0; u < 8; ++u) acc += v[u];
     }
-    for (; c < nchunks; c += 4) acc += part[(int64_t)c * K + j];
+    for (; c < nchunks; c += CS_PH) acc += part[(int64_t)c * K + j];
   }
   red[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && j < K) {
-    const float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < CS_PH; ++q) v += red[q][tx];
     out[j] = accumulate ? out[j] + v : v;
   }
 }
@@ -264,7 +268,7 @@ extern "C" int ctr_colsum(const float* X, int64_t ld, const float* w, int64_t w_
   float* part = (float*)workspace;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(K, 64), nchunks), dim3(256), 0, st, X, ld, w,
                      w_ld, w_group, B, K, rows_per_chunk, part);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(K, 64)), dim3(256), 0, st, part, nchunks, K,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(K, 64)), dim3(64 * CS_PH), 0, st, part, nchunks, K,
                      out, accumulate);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
