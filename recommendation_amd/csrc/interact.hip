@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void pnn_inner_kernel(const float* __restrict_
 //                  LDS tile once per sample.
 // PT, NT: 16-row tiles of p and of n.
 template <bool BWD, int PT, int NT>
-__global__ __launch_bounds__(256) void pnn_inner16_kernel(const float* __restrict__ z, int64_t z_ld,
+__global__ __launch_bounds__(256, 2) void pnn_inner16_kernel(const float* __restrict__ z, int64_t z_ld,
                                                          const float* __restrict__ w, int B, int N, int P,
                                                          float* __restrict__ usq, const float* __restrict__ coef,
                                                          int64_t coef_ld, float* __restrict__ dz, int64_t dz_ld,
@@ -138,16 +138,17 @@ __global__ __launch_bounds__(256) void pnn_inner16_kernel(const float* __restric
       const int pp = 16 * m + l16, n = 4 * s2 + g;
       wa[m][s2] = (pp < P && n < N) ? w[pp * N + n] : 0.f;
     }
-  float wt[BWD ? NT : 1][BWD ? 4 * PT : 1];
+  // W for the dZ product sits in LDS, padded to [16 PT][WS] with zeros (WS = 68: the four k-slots of a
+  // fragment read land 16 banks apart); as registers it pushed the backward past 256 and to one wave per SIMD
+  constexpr int WS = 68;
+  float* Wl = lds + WAVES * ((16 * PT + 16 * NT) * ES);
   f32x4 dwacc[BWD ? PT : 1][BWD ? NT : 1];
   if (BWD) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int q = 0; q < 4 * PT; ++q) {
-        const int n = 16 * t + l16, pp = 16 * (q >> 2) + 4 * g + (q & 3);
-        wt[t][q] = (pp < P && n < N) ? w[pp * N + n] : 0.f;
-      }
+    for (int q = threadIdx.x; q < 16 * PT * WS; q += 256) {
+      const int pp = q / WS, n = q - pp * WS;
+      Wl[q] = (pp < P && n < N) ? w[pp * N + n] : 0.f;
+    }
+    __syncthreads();
 #pragma unroll
     for (int m = 0; m < PT; ++m)
 #pragma unroll
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(256) void pnn_inner16_kernel(const float* __restric
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int t = 0; t < NT; ++t)
-            dza[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[t][4 * m + r], u[m][r], dza[t], 0, 0, 0);
+            dza[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[(16 * m + 4 * g + r) * WS + 16 * t + l16], u[m][r], dza[t], 0,
+                                                          0, 0);
       if (live) {
         float* dr = dz + b * dz_ld;
 #pragma unroll
@@ -823,7 +825,7 @@ extern "C" int ctr_pnn_inner_bwd(const float* z, int64_t z_ld, const float* w, c
   float* part = (float*)workspace;
   if (E == 16 && N <= 64 && P <= 64) {   // every contraction on the matrix cores
     const int pt = P <= 16 ? 1 : P <= 32 ? 2 : 4, nt = (N + 15) / 16;
-    const size_t lds16 = (size_t)WAVES * (16 * pt + 16 * nt) * 17 * sizeof(float);
+    const size_t lds16 = ((size_t)WAVES * (16 * pt + 16 * nt) * 17 + (size_t)16 * pt * 68) * sizeof(float);
 #define PB(PT_, NT_)                                                                                            \
   hipLaunchKernelGGL((pnn_inner16_kernel<true, PT_, NT_>), dim3(nb), dim3(256), lds16, st, z, z_ld, w, B, N, P,  \
                      (float*)nullptr, coef, coef_ld, dz, dz_ld, part)
