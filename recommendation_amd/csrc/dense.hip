@@ -5,7 +5,7 @@
 
 namespace ctr {
 
-constexpr int CS_ROWS = 512;  // rows per partial chunk
+constexpr int CS_ROWS = 64;   // rows per partial chunk (narrow matrices need many chunks to fill the GPU)
 
 // grid (ceil(K/64), nchunks); block (64, 4)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int64_t ld,
@@ -21,15 +21,15 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   if (j < K) {
     const int wj = w ? j / w_group : 0;
     int64_t r = r0 + ty;
-    for (; r + 12 < r1; r += 16) {   // four independent row loads in flight, added in row order
-      float v[4];
+    for (; r + 28 < r1; r += 32) {   // eight independent row loads in flight, added in row order
+      float v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         v[u] = X[(r + 4 * u) * ld + j];
         if (w) v[u] *= w[(r + 4 * u) * w_ld + wj];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc += v[u];
+      for (int u = 0; u < 8; ++u) acc += v[u];
     }
     for (; r < r1; r += 4) {
       float v = X[r * ld + j];
