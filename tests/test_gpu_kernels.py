@@ -559,3 +559,34 @@ def test_pnn_inner_product_term_forward_and_backward(ops_ws, B, N, E, P, per_sam
     assert rel_err(dzd[:, :N * E].cpu().numpy().reshape(B, N, E), dz_ref) < 1e-5
     assert rel_err(dw.cpu().numpy(), dw_ref) < 1e-5
     assert (dzd[:, N * E:] == 3.0).all()
+
+
+@pytest.mark.parametrize('B,N,E,rate', [(1001, 39, 16, 0.3), (5, 2, 16, 0.0), (130, 64, 16, 0.5), (66, 17, 16, 0.0),
+                                        (77, 39, 8, 0.3), (9, 5, 4, 0.0)])
+def test_afm_pair_layer_forward_and_backward(ops_ws, B, N, E, rate):
+    """x[e] = sum_{i<j} m_ij z_i[e] z_j[e] with the per-pair dropout multipliers of the counter hash; backward
+    dZ_i[e] = dx[e] sum_{j != i} m_ij z_j[e].  E = 16 takes the matrix-core kernel, other widths the LDS kernel."""
+    ops, ws = ops_ws
+    rng = np.random.default_rng(B + N)
+    z = rng.standard_normal((B, N, E)).astype(np.float32)
+    dx = rng.standard_normal((B, E)).astype(np.float32)
+    P = N * (N - 1) // 2
+    drop = ops.make_dropout(rate, 21, 4)
+    m = np.ones((B, P))
+    if rate:
+        m = O.keep_mask(21, 4, B * P, 1 - rate).reshape(B, P) / (1 - rate)
+    M = np.zeros((B, N, N))
+    iu = np.triu_indices(N, 1)                                # lexicographic (i, j), i < j: the kernel's pair order
+    M[:, iu[0], iu[1]] = m
+    M = M + M.transpose(0, 2, 1)
+    y = np.einsum('bij,bje->bie', M, z.astype(np.float64))
+    ld = N * E + 4
+    zd = torch.zeros(B, ld, device=DEV)
+    zd[:, :N * E] = dev(z.reshape(B, -1))
+    x = torch.zeros(B, E, device=DEV)
+    ops.afm_pair_fwd(zd[:, :N * E], x, N=N, E=E, pair_drop=drop)
+    assert rel_err(x.cpu().numpy(), 0.5 * (z * y).sum(1)) < 1e-5
+    dzd = torch.full((B, ld), 2.0, device=DEV)
+    ops.afm_pair_bwd(zd[:, :N * E], dev(dx), dzd[:, :N * E], N=N, E=E, pair_drop=drop)
+    assert rel_err(dzd[:, :N * E].cpu().numpy().reshape(B, N, E), dx[:, None, :] * y) < 1e-5
+    assert (dzd[:, N * E:] == 2.0).all()
