@@ -171,3 +171,23 @@ def test_afm_attention_over_pairs_trains_the_attention_variables(sess, dropout):
             assert abs(float(orc.run(Xc, Xf, y, True)) - float(m.run(sess, Xc, Xf, y, True))) < 1e-5
         for k, v in m.get_params().items():
             assert rel_err(v, orc.P[k].numpy()) < 1e-4, k
+
+
+def test_side_stream_weight_gradients_change_nothing(sess):
+    """The towers' weight gradients on the side stream give the same bits as everything on one stream."""
+    outs = []
+    for enabled in (True, False):
+        cfg = tiny_cfg('DeepFM', 'S')
+        cfg.adam_mode = 'tf1'
+        P = O.init_params('DeepFM', cfg, seed=9, std=0.3)
+        Xc, Xf, y = tiny_batch(cfg, B=64, seed=3)
+        m = _build(sess, 'DeepFM', cfg, P)
+        sess.side_enabled = enabled
+        try:
+            for _ in range(3):
+                m.run(sess, Xc, Xf, y, True)
+        finally:
+            sess.side_enabled = True
+        outs.append(m.get_params())
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
