@@ -159,7 +159,11 @@ def main():
     # Criteo-1TB cardinalities / 8 (one GPU of the 8-GPU shard), dim 64, 6 cross layers, 1024x3 tower.
     cards = CRITEO_KAGGLE if args.model != 'DCN' else scaled(CRITEO_1TB, 8 // min(world, 8))
     shape_name = 'Criteo-Kaggle' if args.model != 'DCN' else 'Criteo-1TB/%d' % (8 // min(world, 8))
+    if rank == 0:
+        print('[bench] building %s: %d table rows on %d rank(s)' % (args.model, sum(cards), world), file=sys.stderr, flush=True)
     model = build_model(args, sess, cards, rank, world)
+    if rank == 0:
+        print('[bench] model built, generating batches', file=sys.stderr, flush=True)
     B = args.batch
     batches = make_batches(cards, 13, B, 8, args.alpha, 20240601 + rank, dev)
 
@@ -171,6 +175,8 @@ def main():
     # distinct table rows touched per step (for the algorithmic bytes of the sparse update)
     offs = torch.as_tensor(np.concatenate([[0], np.cumsum(cards)[:-1]]), device=dev)
     uniq = float(np.mean([torch.unique(b[0].to(torch.int64) + offs).numel() for b in batches]))
+    if rank == 0:
+        print('[bench] warm-up', file=sys.stderr, flush=True)
     for i in range(args.warmup):
         model.train_step(*batches[i % len(batches)])
     # Untimed profiling pass: every operator between HIP events, to split the step by kernel and to
