@@ -94,6 +94,7 @@ class CTRModel:
         self._built = False
         self._ready = False
         self._bufs = {}
+        self._graphs = {}
 
     # ---- graph definition -----------------------------------------------------------------
     def build(self):
@@ -290,6 +291,36 @@ class CTRModel:
         self._loss(bufs, None, False)
         return bufs['y_out']
 
+    def predict_step_graphed(self, idx, xc):
+        """predict_step replayed from a captured HIP graph (one per batch size): the forward's launches are
+        recorded once on a capture stream and replayed as one graph launch - at serving batch sizes the step is
+        launch-bound and this is what removes the per-kernel host cost.  Inputs are copied into the graph's
+        static buffers; the result tensor is the graph's static output (read it before the next call).
+        Single-process only (a collective cannot be captured here); weights are read in place, so training
+        steps between calls are seen by the next replay."""
+        if self.world > 1:
+            return self.predict_step(idx, xc)
+        B = idx.shape[0]
+        entry = self._graphs.get(B)
+        if entry is None:
+            s_idx, s_xc = idx.clone(), xc.clone()
+            side = torch.cuda.Stream(self.session.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):             # warm-up off the default stream: buffers and workspace grow here
+                self.predict_step(s_idx, s_xc)
+                self.predict_step(s_idx, s_xc)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.predict_step(s_idx, s_xc)
+            entry = (graph, s_idx, s_xc, out)
+            self._graphs[B] = entry
+        graph, s_idx, s_xc, out = entry
+        s_idx.copy_(idx)
+        s_xc.copy_(xc)
+        graph.replay()
+        return out
+
     def run(self, session, X_cate, X_cont, y, is_train=False, step=None):
         self._ensure_initialized(session)
         idx, xc, yy = self._upload(X_cate, X_cont, y)
@@ -297,14 +328,14 @@ class CTRModel:
             raise ValueError('empty batch')
         if is_train:
             return np.float32(self.train_step(idx, xc, yy).item())
-        y_out = self.predict_step(idx, xc)
+        y_out = self.predict_step_graphed(idx, xc)      # evaluation batches are small: graph replay, not ~15 launches
         # tf.round is round-half-to-even; torch.round too
         return np.asarray(yy.cpu().numpy(), dtype=np.float32), torch.round(y_out).cpu().numpy()
 
     def predict_proba(self, session, X_cate, X_cont):
         self._ensure_initialized(session)
         idx, xc, _ = self._upload(X_cate, X_cont, np.zeros(len(X_cate), dtype=np.float32))
-        return self.predict_step(idx, xc).cpu().numpy()
+        return self.predict_step_graphed(idx, xc).cpu().numpy()
 
     # hooks
     LOSS_KIND = 0

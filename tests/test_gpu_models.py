@@ -191,3 +191,20 @@ def test_side_stream_weight_gradients_change_nothing(sess):
         outs.append(m.get_params())
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_graph_replayed_inference_matches_eager(sess):
+    """predict_step captured into a HIP graph and replayed gives the eager result, for new inputs and after a
+    training step changed the weights in place."""
+    cfg = tiny_cfg('DeepFM', 'S')
+    cfg.adam_mode = 'tf1'
+    P = O.init_params('DeepFM', cfg, seed=6, std=0.3)
+    m = _build(sess, 'DeepFM', cfg, P)
+    for seed in (1, 2):
+        Xc, Xf, y = tiny_batch(cfg, B=32, seed=seed)
+        idx, xc, yy = m._upload(Xc, Xf, y)
+        eager = m.predict_step(idx, xc).clone()
+        graphed = m.predict_step_graphed(idx, xc).clone()
+        assert torch.equal(eager, graphed)
+        m.train_step(idx, xc, yy)
+        assert torch.equal(m.predict_step(idx, xc).clone(), m.predict_step_graphed(idx, xc))
