@@ -45,6 +45,8 @@ typedef struct {
   uint64_t stream_id;
   uint32_t keep_threshold; /* floor(keep_prob * 2^24) */
   float scale;             /* 1 / keep_prob */
+  const uint64_t* seed_add; /* optional device word added to seed when the kernel runs (NULL: none): lets a
+                               captured HIP graph be replayed with a new step count */
 } ctr_dropout_t;
 
 /* ------------------------------------------------------------------------------------
@@ -164,6 +166,7 @@ typedef struct {
   float eps;    /* Adam (outside the sqrt, TF-1.x)                      */
   float l1;     /* FTRL l1_regularization_strength                      */
   float l2;     /* FTRL l2_regularization_strength                      */
+  const float* lr_dev; /* optional device float read instead of lr when the kernel runs (NULL: use lr) */
 } ctr_opt_t;
 
 /* For every run of equal keys in the sorted pairs: g = sum (in sorted order, so bitwise

@@ -20,12 +20,13 @@ vp = C.c_void_p
 
 class Dropout(C.Structure):
     _fields_ = [('seed', C.c_uint64), ('stream_id', C.c_uint64),
-                ('keep_threshold', C.c_uint32), ('scale', C.c_float)]
+                ('keep_threshold', C.c_uint32), ('scale', C.c_float), ('seed_add', C.c_void_p)]
 
 
 class Opt(C.Structure):
     _fields_ = [('kind', C.c_int), ('lr', C.c_float), ('beta1', C.c_float),
-                ('beta2', C.c_float), ('eps', C.c_float), ('l1', C.c_float), ('l2', C.c_float)]
+                ('beta2', C.c_float), ('eps', C.c_float), ('l1', C.c_float), ('l2', C.c_float),
+                ('lr_dev', C.c_void_p)]
 
 
 class Epilogue(C.Structure):

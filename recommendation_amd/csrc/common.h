@@ -58,6 +58,7 @@ __host__ __device__ static inline uint32_t hash24(uint64_t seed, uint64_t stream
 }
 
 struct Drop {
+  const uint64_t* seed_add;   // optional device word added to the seed (the step count of a replayed graph)
   uint64_t seed, stream_id;
   uint32_t thr;
   float scale;
@@ -66,9 +67,10 @@ struct Drop {
 
 static inline Drop make_drop(const ctr_dropout_t* d) {
   Drop r;
-  r.seed = 0; r.stream_id = 0; r.thr = 1u << 24; r.scale = 1.f; r.on = 0;
+  r.seed_add = nullptr; r.seed = 0; r.stream_id = 0; r.thr = 1u << 24; r.scale = 1.f; r.on = 0;
   if (d && d->keep_threshold > 0 && d->keep_threshold < (1u << 24)) {
     r.seed = d->seed; r.stream_id = d->stream_id; r.thr = d->keep_threshold; r.scale = d->scale; r.on = 1;
+    r.seed_add = d->seed_add;
   }
   return r;
 }
@@ -76,7 +78,7 @@ static inline Drop make_drop(const ctr_dropout_t* d) {
 // multiplier (0 or scale) of element `index` under dropout d
 __device__ static inline float drop_mul(const Drop& d, uint64_t index) {
   if (!d.on) return 1.f;
-  return hash24(d.seed, d.stream_id, index) < d.thr ? d.scale : 0.f;
+  return hash24(d.seed + (d.seed_add ? *d.seed_add : 0ull), d.stream_id, index) < d.thr ? d.scale : 0.f;
 }
 
 // x + (x of the lane CTRL names inside this lane's row of 16), on the VALU's data-parallel path (no LDS)

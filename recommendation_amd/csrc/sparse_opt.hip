@@ -9,13 +9,15 @@ namespace ctr {
 struct Opt {
   int kind;
   float lr, b1, b2, eps, l1, l2;
+  const float* lr_dev;   // when set, the step size is read from device memory (a captured graph replays with new values)
+  __device__ float LR() const { return lr_dev ? *lr_dev : lr; }
 };
 
 __device__ static inline void ftrl1(const Opt& o, float g, float& w, float& n, float& z) {
   const float nn = n + g * g;
-  z += g - (sqrtf(nn) - sqrtf(n)) / o.lr * w;
+  z += g - (sqrtf(nn) - sqrtf(n)) / o.LR() * w;
   const float sgn = z > 0.f ? 1.f : (z < 0.f ? -1.f : 0.f);
-  w = fabsf(z) <= o.l1 ? 0.f : -(z - sgn * o.l1) / (sqrtf(nn) / o.lr + 2.f * o.l2);
+  w = fabsf(z) <= o.l1 ? 0.f : -(z - sgn * o.l1) / (sqrtf(nn) / o.LR() + 2.f * o.l2);
   n = nn;
 }
 
@@ -26,18 +28,18 @@ __device__ static inline void opt_apply4(const Opt& o, float4 g, float4* w, floa
     m.z = o.b1 * m.z + (1.f - o.b1) * g.z; m.w = o.b1 * m.w + (1.f - o.b1) * g.w;
     v.x = o.b2 * v.x + (1.f - o.b2) * g.x * g.x; v.y = o.b2 * v.y + (1.f - o.b2) * g.y * g.y;
     v.z = o.b2 * v.z + (1.f - o.b2) * g.z * g.z; v.w = o.b2 * v.w + (1.f - o.b2) * g.w * g.w;
-    p.x -= o.lr * m.x / (sqrtf(v.x) + o.eps); p.y -= o.lr * m.y / (sqrtf(v.y) + o.eps);
-    p.z -= o.lr * m.z / (sqrtf(v.z) + o.eps); p.w -= o.lr * m.w / (sqrtf(v.w) + o.eps);
+    p.x -= o.LR() * m.x / (sqrtf(v.x) + o.eps); p.y -= o.LR() * m.y / (sqrtf(v.y) + o.eps);
+    p.z -= o.LR() * m.z / (sqrtf(v.z) + o.eps); p.w -= o.LR() * m.w / (sqrtf(v.w) + o.eps);
     *s0 = m; *s1 = v; *w = p;
   } else if (o.kind == CTR_OPT_ADAGRAD) {
     float4 a = *s0, p = *w;
     a.x += g.x * g.x; a.y += g.y * g.y; a.z += g.z * g.z; a.w += g.w * g.w;
-    p.x -= o.lr * g.x / sqrtf(a.x); p.y -= o.lr * g.y / sqrtf(a.y);
-    p.z -= o.lr * g.z / sqrtf(a.z); p.w -= o.lr * g.w / sqrtf(a.w);
+    p.x -= o.LR() * g.x / sqrtf(a.x); p.y -= o.LR() * g.y / sqrtf(a.y);
+    p.z -= o.LR() * g.z / sqrtf(a.z); p.w -= o.LR() * g.w / sqrtf(a.w);
     *s0 = a; *w = p;
   } else if (o.kind == CTR_OPT_SGD) {
     float4 p = *w;
-    p.x -= o.lr * g.x; p.y -= o.lr * g.y; p.z -= o.lr * g.z; p.w -= o.lr * g.w;
+    p.x -= o.LR() * g.x; p.y -= o.LR() * g.y; p.z -= o.LR() * g.z; p.w -= o.LR() * g.w;
     *w = p;
   } else if (o.kind == CTR_OPT_FTRL) {
     float4 p = *w, n = *s0, z = *s1;
@@ -212,17 +214,17 @@ __global__ __launch_bounds__(256) void dense_update_kernel(float* __restrict__ p
       const float m = o.b1 * s0[i] + (1.f - o.b1) * gi;
       const float v = o.b2 * s1[i] + (1.f - o.b2) * gi * gi;
       s0[i] = m; s1[i] = v;
-      p[i] -= o.lr * m / (sqrtf(v) + o.eps);
+      p[i] -= o.LR() * m / (sqrtf(v) + o.eps);
     } else if (o.kind == CTR_OPT_ADAGRAD) {
       const float a = s0[i] + gi * gi;
       s0[i] = a;
-      p[i] -= o.lr * gi / sqrtf(a);
+      p[i] -= o.LR() * gi / sqrtf(a);
     } else if (o.kind == CTR_OPT_FTRL) {
       float w = p[i], n = s0[i], z = s1[i];
       ftrl1(o, gi, w, n, z);
       p[i] = w; s0[i] = n; s1[i] = z;
     } else {
-      p[i] -= o.lr * gi;
+      p[i] -= o.LR() * gi;
     }
   }
 }
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(256) void dense_update_kernel(float* __restrict__ p
 static Opt make_opt(const ctr_opt_t* o) {
   Opt r;
   r.kind = o->kind; r.lr = o->lr; r.b1 = o->beta1; r.b2 = o->beta2; r.eps = o->eps; r.l1 = o->l1; r.l2 = o->l2;
+  r.lr_dev = o->lr_dev;
   return r;
 }
 

@@ -59,6 +59,9 @@ def get_checkpoint_state(directory):
     return full if os.path.exists(full + '.safetensors') else None
 
 
+GRAPH_MAX_BATCH = 16384     # above this a step is GPU-bound and a captured graph gains nothing
+
+
 class CTRModel:
     MODEL = None
     OPTIMIZER = 'adam'
@@ -95,6 +98,8 @@ class CTRModel:
         self._ready = False
         self._bufs = {}
         self._graphs = {}
+        self._train_graphs = {}
+        self._indirect = None            # (step word, lr word) on the device while a training graph is captured
 
     # ---- graph definition -----------------------------------------------------------------
     def build(self):
@@ -127,6 +132,7 @@ class CTRModel:
             raise RuntimeError('call build() first')
         dev = session.device
         self.session = session
+        self._graphs, self._train_graphs = {}, {}      # captured graphs point at the storage allocated below
         self.dense = DenseParams(self.dense_shapes, dev)
         if self.world > 1:
             from .distributed import RowShardedFront, ShardedFront, TorchComm
@@ -221,11 +227,16 @@ class CTRModel:
         """tf.train.exponential_decay(staircase=True) at the pre-update global_step."""
         return self.learning_rate * (self.decay_rate ** (self.global_step // self.decay_steps))
 
-    def _optimizer(self):
+    def _step_lr(self):
         lr = self._lr()
         if self.OPTIMIZER == 'adam':
             lr = adam_lr_t(lr, self.global_step + 1)
-        return ops.make_opt(OPT_KIND[self.OPTIMIZER], lr=lr)
+        return lr
+
+    def _optimizer(self):
+        if self._indirect is not None:       # captured graph: the kernels read the step size from device memory
+            return ops.make_opt(OPT_KIND[self.OPTIMIZER], lr=0.0, lr_dev=self._indirect[1])
+        return ops.make_opt(OPT_KIND[self.OPTIMIZER], lr=self._step_lr())
 
     def _upload(self, X_cate, X_cont, y):
         """Feed conversion of the reference placeholders: int64 -> int32, float64 -> float32."""
@@ -268,6 +279,8 @@ class CTRModel:
     def _drop(self, rate, stream_id, train):
         if not train:
             return None
+        if self._indirect is not None:       # captured graph: the step count is added on the device
+            return ops.make_dropout(rate, self.session.seed * 1000003, stream_id, seed_add=self._indirect[0])
         return ops.make_dropout(rate, self.session.seed * 1000003 + self.global_step, stream_id)
 
     def train_step(self, idx, xc, yy):
@@ -282,6 +295,47 @@ class CTRModel:
         if self.world > 1:
             self.comm.all_reduce_sum(self.dense.grad)       # loss gradient was pre-scaled by 1/world
         self.dense.apply(self._optimizer())
+        self.global_step += 1
+        return self._loss_dev
+
+    def train_step_graphed(self, idx, xc, yy):
+        """train_step replayed from a captured HIP graph (one per batch size).  What changes from step to step -
+        the dropout streams' step count and the (decayed, bias-corrected) step size - lives in two device words
+        the kernels read (ctr_dropout_t.seed_add, ctr_opt_t.lr_dev); the host writes them before each replay.
+        Same arithmetic and same dropout masks as train_step.  Single-process only."""
+        if self.world > 1:
+            return self.train_step(idx, xc, yy)
+        B = idx.shape[0]
+        entry = self._train_graphs.get(B)
+        if entry is None:
+            # first step at this batch size: an ordinary step (buffers and the workspace reach their final size),
+            # then the capture - which records launches without running them - for every later step
+            loss = self.train_step(idx, xc, yy)
+            dev = self.session.device
+            step_w = torch.zeros(1, dtype=torch.int64, device=dev)
+            lr_w = torch.zeros(1, dtype=torch.float32, device=dev)
+            s_idx, s_xc, s_yy = idx.clone(), xc.clone(), yy.clone()
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            side, step0 = self.session.side_enabled, self.global_step
+            self.session.side_enabled = False      # one stream inside the capture
+            self._indirect = (step_w, lr_w)
+            try:
+                with torch.cuda.graph(graph):
+                    self.train_step(s_idx, s_xc, s_yy)
+            finally:
+                self._indirect = None
+                self.session.side_enabled = side
+                self.global_step = step0           # the capture ran no kernel and does not count as a step
+            self._train_graphs[B] = (graph, s_idx, s_xc, s_yy, step_w, lr_w)
+            return loss
+        graph, s_idx, s_xc, s_yy, step_w, lr_w = entry
+        s_idx.copy_(idx)
+        s_xc.copy_(xc)
+        s_yy.copy_(yy)
+        step_w.copy_(torch.tensor([self.global_step], dtype=torch.int64))
+        lr_w.copy_(torch.tensor([self._step_lr()], dtype=torch.float32))
+        graph.replay()
         self.global_step += 1
         return self._loss_dev
 
@@ -327,7 +381,9 @@ class CTRModel:
         if idx.shape[0] == 0:
             raise ValueError('empty batch')
         if is_train:
-            return np.float32(self.train_step(idx, xc, yy).item())
+            # the reference's loop feeds small mini-batches (128 by default): launch-bound, so replay a graph
+            step = self.train_step_graphed if idx.shape[0] <= GRAPH_MAX_BATCH else self.train_step
+            return np.float32(step(idx, xc, yy).item())
         y_out = self.predict_step_graphed(idx, xc)      # evaluation batches are small: graph replay, not ~15 launches
         # tf.round is round-half-to-even; torch.round too
         return np.asarray(yy.cpu().numpy(), dtype=np.float32), torch.round(y_out).cpu().numpy()

@@ -107,13 +107,15 @@ def _rows(t, name, dtype=torch.float32):
     return _ptr(t, dtype, name), int(t.stride(0)) if t.shape[0] > 1 else max(int(t.stride(0)), t.shape[1])
 
 
-def make_dropout(rate, seed, stream_id):
-    """Dropout descriptor for tf.layers.dropout(rate) in training mode; None when rate == 0."""
+def make_dropout(rate, seed, stream_id, seed_add=None):
+    """Dropout descriptor for tf.layers.dropout(rate) in training mode; None when rate == 0.
+    seed_add: optional device int64[1] whose value is added to the seed when the kernel runs."""
     if rate is None or rate <= 0.0:
         return None
     keep = 1.0 - float(rate)
     return Dropout(seed=int(seed), stream_id=int(stream_id),
-                   keep_threshold=int(math.floor(keep * KEEP_ONE)), scale=1.0 / keep)
+                   keep_threshold=int(math.floor(keep * KEEP_ONE)), scale=1.0 / keep,
+                   seed_add=None if seed_add is None else seed_add.data_ptr())
 
 
 def _dp(d):
@@ -402,9 +404,10 @@ def rows_scatter(rows, perm, n, dst, *, F, E):
           'ctr_rows_scatter')
 
 
-def make_opt(kind, lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8, l1=0.0, l2=0.0):
+def make_opt(kind, lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8, l1=0.0, l2=0.0, lr_dev=None):
+    """lr_dev: optional device float32[1] read by the kernels instead of lr."""
     return Opt(kind=int(kind), lr=float(lr), beta1=float(beta1), beta2=float(beta2), eps=float(eps),
-               l1=float(l1), l2=float(l2))
+               l1=float(l1), l2=float(l2), lr_dev=None if lr_dev is None else lr_dev.data_ptr())
 
 
 @_timed
