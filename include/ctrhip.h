@@ -297,6 +297,13 @@ int ctr_esmm_head(const float* ctr_logit, const float* cvr_logit, const float* y
 int ctr_dense_update(float* param, const float* grad, float* slot0, float* slot1,
                      int64_t n, const ctr_opt_t* opt, void* stream);
 
+/* Writes the two device words a captured training step reads instead of by-value scalars
+ * (ctr_dropout_t.seed_add, ctr_opt_t.lr_dev), in stream order; either pointer may be NULL.
+ * Replaces: the feed of global_step into tf.train.exponential_decay and Adam's beta powers
+ * (DeepFM/DeepFM.py:94-100), which TF re-evaluates inside every session.run. */
+int ctr_set_step_words(uint64_t* seed_add, uint64_t seed_add_value, float* lr_dev, float lr_value,
+                       void* stream);
+
 /* ------------------------------------------------------------------------------------
  * DCN cross network, all layers fused (DCN/DCN.py:56-65 without the [B,D,D] product):
  *   x_{l+1} = x0 * (x_l . w_l) + b_l + x_l,   l = 0..L-1,   1 <= L <= 8,  D <= 8192

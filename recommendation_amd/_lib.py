@@ -70,6 +70,7 @@ SIGNATURES = {
     'ctr_loss_head': (i, [i, vp, vp, i, f, vp, vp, vp, vp, sz, vp]),
     'ctr_esmm_head': (i, [vp, vp, vp, i, f, vp, vp, vp, vp, vp, sz, vp]),
     'ctr_dense_update': (i, [vp, vp, vp, vp, i64, C.POINTER(Opt), vp]),
+    'ctr_set_step_words': (i, [vp, C.c_uint64, vp, C.c_float, vp]),
     'ctr_cross_fwd_workspace_bytes': (sz, [i, i]),
     'ctr_cross_fwd': (i, [vp, i64, vp, vp, i64, i, i, i, vp, i64, vp, vp, sz, vp]),
     'ctr_cross_bwd_workspace_bytes': (sz, [i, i, i]),

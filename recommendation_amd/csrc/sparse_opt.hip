@@ -320,3 +320,19 @@ extern "C" int ctr_dense_update(float* param, const float* grad, float* slot0, f
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
+
+// Per-step scalars of a replayed graph, written by a one-thread kernel from by-value arguments: stream-ordered
+// (no host buffer whose lifetime must outlast an asynchronous copy) and cheaper than two pageable copies.
+__global__ void set_step_words_kernel(uint64_t* seed_add, uint64_t seed_add_value, float* lr_dev, float lr_value) {
+  if (seed_add) *seed_add = seed_add_value;
+  if (lr_dev) *lr_dev = lr_value;
+}
+
+extern "C" int ctr_set_step_words(uint64_t* seed_add, uint64_t seed_add_value, float* lr_dev, float lr_value,
+                                  void* stream) {
+  if (!seed_add && !lr_dev) return CTR_OK;
+  hipLaunchKernelGGL(set_step_words_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, seed_add, seed_add_value,
+                     lr_dev, lr_value);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}

@@ -333,8 +333,7 @@ class CTRModel:
         s_idx.copy_(idx)
         s_xc.copy_(xc)
         s_yy.copy_(yy)
-        step_w.copy_(torch.tensor([self.global_step], dtype=torch.int64))
-        lr_w.copy_(torch.tensor([self._step_lr()], dtype=torch.float32))
+        ops.set_step_words(step_w, self.global_step, lr_w, self._step_lr())
         graph.replay()
         self.global_step += 1
         return self._loss_dev

@@ -123,15 +123,22 @@ def _dp(d):
 
 
 class Workspace:
-    """Grow-only device scratch buffer handed to the kernels that need one."""
+    """Grow-only device scratch buffer handed to the kernels that need one.  A buffer that has been outgrown
+    is kept, not freed: a captured graph may still hold its address (a step captured at a small batch is
+    replayed after a larger batch made the workspace grow).  Sizes at least double, so what is kept is less
+    than the live buffer."""
 
     def __init__(self, device):
         self.device = device
         self.buf = None
+        self.retired = []
 
     def get(self, nbytes):
         nbytes = int(nbytes)
         if self.buf is None or self.buf.numel() < nbytes:
+            if self.buf is not None:
+                self.retired.append(self.buf)
+                nbytes = max(nbytes, 2 * self.buf.numel())
             self.buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
         return C.c_void_p(self.buf.data_ptr()), self.buf.numel()
 
@@ -402,6 +409,13 @@ def rows_scatter(rows, perm, n, dst, *, F, E):
         raise ValueError('rows_scatter: perm must be int32 [n], rows contiguous with n*E words')
     check(lib().ctr_rows_scatter(_ptr(_words(rows)), _ptr(perm), int(n), int(F), int(E), dp, ld, _stream()),
           'ctr_rows_scatter')
+
+
+def set_step_words(seed_add, seed_add_value, lr_dev, lr_value):
+    """Stream-ordered write of the device words make_dropout(seed_add=) / make_opt(lr_dev=) point at."""
+    check(lib().ctr_set_step_words(None if seed_add is None else seed_add.data_ptr(), int(seed_add_value),
+                                   None if lr_dev is None else lr_dev.data_ptr(), float(lr_value), _stream()),
+          'ctr_set_step_words')
 
 
 def make_opt(kind, lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8, l1=0.0, l2=0.0, lr_dev=None):

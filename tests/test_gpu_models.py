@@ -232,3 +232,29 @@ def test_graph_replayed_training_matches_eager(sess, name, mode):
     assert outs[0][2] == outs[1][2] == 5
     for k in outs[0][1]:
         assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+
+
+@pytest.mark.gpu
+def test_graph_replay_survives_workspace_growth(sess):
+    """Train graph captured at a small batch, then a much larger evaluation batch makes the scratch workspace
+    grow; later replays must still match eager steps (the outgrown scratch buffer stays allocated)."""
+    outs = []
+    for graphed in (False, True):
+        cfg = tiny_cfg('DeepFM', 'S')
+        P = O.init_params('DeepFM', cfg, seed=3, std=0.3)
+        m = _build(sess, 'DeepFM', cfg, P)
+        fn = m.train_step_graphed if graphed else m.train_step
+        losses = []
+        for step in range(6):
+            Xc, Xf, y = tiny_batch(cfg, B=32, seed=step)
+            losses.append(float(fn(*m._upload(Xc, Xf, y)).item()))
+            if step == 2:
+                sess.ws.get(2 * sess.ws.buf.numel())                     # what a large batch would do
+                junk = torch.full((sess.ws.retired[-1].numel() // 4,), float('nan'), device=sess.device)
+                Xc2, Xf2, y2 = tiny_batch(cfg, B=4096, seed=99)
+                m.predict_step(*m._upload(Xc2, Xf2, y2)[:2])
+                del junk
+        outs.append((losses, m.get_params()))
+    assert outs[0][0] == outs[1][0]
+    for k in outs[0][1]:
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k

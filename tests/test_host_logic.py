@@ -56,3 +56,14 @@ def test_dense_params_flat_layout():
 def test_adam_lr_t():
     from recommendation_amd.engine import adam_lr_t
     assert np.isclose(adam_lr_t(0.001, 1), 0.001 * np.sqrt(1 - 0.999) / (1 - 0.9))
+
+
+def test_workspace_keeps_outgrown_buffers():
+    """A captured graph may hold the address of a scratch buffer that was later outgrown: it must stay allocated."""
+    from recommendation_amd.ops import Workspace
+    ws = Workspace('cpu')
+    p1, n1 = ws.get(100)
+    assert n1 >= 100 and ws.get(50)[0].value == p1.value          # no growth, same buffer
+    p2, n2 = ws.get(n1 + 1)
+    assert n2 >= 2 * n1 and p2.value != p1.value
+    assert [b.data_ptr() for b in ws.retired] == [p1.value]

@@ -19,6 +19,10 @@ else:
     ('dw0', 429, 256, B, 1, 0), ('dw1', 256, 128, B, 1, 0), ('dw2', 128, 64, B, 1, 0), ('dw3', 64, 32, B, 1, 0),
     ('sq4k', 4096, 4096, 4096, 0, 0),
   ]
+if len(sys.argv) > 1 and sys.argv[1] == 'dcn':         # the 1024-wide tower of the DCN shape at B = 8192
+    shapes = [('fwd0', 8192, 1024, 1677, 0, 0), ('fwd1', 8192, 1024, 1024, 0, 0),
+              ('dx0', 8192, 1677, 1024, 0, 1), ('dx1', 8192, 1024, 1024, 0, 1),
+              ('dw0', 1677, 1024, 8192, 1, 0), ('dw1', 1024, 1024, 8192, 1, 0)]
 if len(sys.argv) > 2 and sys.argv[1] == 'one':         # a single named shape, for counter passes
     shapes = [sh for sh in shapes if sh[0] in sys.argv[2:]]
 if len(sys.argv) > 1 and sys.argv[1] == 'wgrad':
