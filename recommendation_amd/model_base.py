@@ -317,15 +317,13 @@ class CTRModel:
             s_idx, s_xc, s_yy = idx.clone(), xc.clone(), yy.clone()
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
-            side, step0 = self.session.side_enabled, self.global_step
-            self.session.side_enabled = False      # one stream inside the capture
+            step0 = self.global_step
             self._indirect = (step_w, lr_w)
             try:
                 with torch.cuda.graph(graph):
                     self.train_step(s_idx, s_xc, s_yy)
             finally:
                 self._indirect = None
-                self.session.side_enabled = side
                 self.global_step = step0           # the capture ran no kernel and does not count as a step
             self._train_graphs[B] = (graph, s_idx, s_xc, s_yy, step_w, lr_w)
             return loss

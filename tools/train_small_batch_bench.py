@@ -18,7 +18,8 @@ def main():
     sess = ra.Session('cuda:0', seed=3)
     args = SimpleNamespace(model='DeepFM', embed=16, shard='table', comm='rccl')
     model = bench.build_model(args, sess, CRITEO_KAGGLE, 0, 1)
-    for B in (128, 1024, 4096, 16384):
+    sizes = [int(a) for a in sys.argv[1:]] or [128, 1024, 4096, 16384]
+    for B in sizes:
         batches = make_batches(CRITEO_KAGGLE, 13, B, 4, 1.05, 7, 'cuda:0')
         res = {}
         for name, fn in (('eager', model.train_step), ('graph', model.train_step_graphed)):
