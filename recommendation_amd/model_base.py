@@ -13,6 +13,7 @@ Extra, optional attributes read from `args` (absent in the reference's argparse 
 """
 from __future__ import annotations
 
+import gc
 import os
 from collections import OrderedDict
 
@@ -57,6 +58,20 @@ def get_checkpoint_state(directory):
     name = line.split('"')[1]
     full = os.path.join(directory, name)
     return full if os.path.exists(full + '.safetensors') else None
+
+
+def _capture(graph, fn):
+    """Record fn's launches into graph.  The cyclic garbage collector is held off meanwhile: were it to run inside
+    the capture and free an older model's graph, the runtime call that destroys it would be illegal there and the
+    process would abort (torch collects once on entering the capture, before it starts)."""
+    was_on = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            return fn()
+    finally:
+        if was_on:
+            gc.enable()
 
 
 GRAPH_MAX_BATCH = 16384     # above this a step is GPU-bound and a captured graph gains nothing
@@ -320,8 +335,7 @@ class CTRModel:
             step0 = self.global_step
             self._indirect = (step_w, lr_w)
             try:
-                with torch.cuda.graph(graph):
-                    self.train_step(s_idx, s_xc, s_yy)
+                _capture(graph, lambda: self.train_step(s_idx, s_xc, s_yy))
             finally:
                 self._indirect = None
                 self.global_step = step0           # the capture ran no kernel and does not count as a step
@@ -362,8 +376,7 @@ class CTRModel:
                 self.predict_step(s_idx, s_xc)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self.predict_step(s_idx, s_xc)
+            out = _capture(graph, lambda: self.predict_step(s_idx, s_xc))
             entry = (graph, s_idx, s_xc, out)
             self._graphs[B] = entry
         graph, s_idx, s_xc, out = entry
