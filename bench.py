@@ -115,7 +115,7 @@ def cpu_baseline(args, cards):
 def load_traffic():
     """HBM bytes per launch from the committed rocprofv3 PMC pass (FETCH_SIZE/WRITE_SIZE collected in
     separate runs, gfx950 x2 read correction; see tools/pmc_summary.py), keyed by kernel symbol."""
-    path = os.path.join(ROOT, 'profiles', 'r01_f_deepfm_c2_pmc_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r01_g_deepfm_c2_pmc_traffic.json')
     out = {}
     if os.path.exists(path):
         for k, v in json.load(open(path)).items():

@@ -21,7 +21,8 @@ else:
   ]
 if len(sys.argv) > 1 and sys.argv[1] == 'dcn':         # the 1024-wide tower of the DCN shape at B = 8192
     shapes = [('fwd0', 8192, 1024, 1677, 0, 0), ('fwd1', 8192, 1024, 1024, 0, 0),
-              ('dx0', 8192, 1677, 1024, 0, 1), ('dx1', 8192, 1024, 1024, 0, 1),
+              ('dx0', 8192, 1677, 1024, 0, 1), ('dx1', 8192, 1024, 1024, 0, 1), ('dx1m', 8192, 1024, 1024, 0, 1),
+              ('fwd1m', 8192, 1024, 1024, 0, 0),
               ('dw0', 1677, 1024, 8192, 1, 0), ('dw1', 1024, 1024, 8192, 1, 0)]
 if len(sys.argv) > 2 and sys.argv[1] == 'one':         # a single named shape, for counter passes
     shapes = [sh for sh in shapes if sh[0] in sys.argv[2:]]
@@ -35,14 +36,17 @@ for name, M, N, K, ta, tb in shapes:
     Bm = mk(N, K) if tb else mk(K, N)
     C = mk(M, N)
     bias = torch.randn(N, device='cuda')
+    kw = {}
+    if name.endswith('m'):                      # with the relu/dropout-backward mask epilogue
+        kw = dict(mask_src=mk(M, N), mask_scale=1.25)
     for _ in range(3):
-        ops.gemm(A, Bm, C, trans_a=bool(ta), trans_b=bool(tb), ws=ws)
+        ops.gemm(A, Bm, C, trans_a=bool(ta), trans_b=bool(tb), ws=ws, **kw)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 20
     e0.record()
     for _ in range(reps):
-        ops.gemm(A, Bm, C, trans_a=bool(ta), trans_b=bool(tb), ws=ws)
+        ops.gemm(A, Bm, C, trans_a=bool(ta), trans_b=bool(tb), ws=ws, **kw)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
