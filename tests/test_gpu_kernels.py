@@ -25,11 +25,14 @@ def ops_ws(sess):
     return ops, sess.ws
 
 
-@pytest.mark.parametrize('n,bits', [(1, 3), (63, 8), (64, 9), (4097, 17), (200000, 26), (70001, 32), (300000, 2)])
+@pytest.mark.parametrize('n,bits', [(1, 3), (63, 8), (64, 9), (4097, 17), (200000, 26), (70001, 32), (300000, 2),
+                                    (5000, 2), (8192, 26), (8193, 26), (777, 32)])
 def test_sort_pairs_stable_exact(ops_ws, n, bits):
     ops, ws = ops_ws
     rng = np.random.default_rng(n + bits)
     keys = rng.integers(0, 2 ** bits, n, dtype=np.uint64).astype(np.uint32)
+    if bits == 32:
+        keys[::50] = 0xFFFFFFFF      # the largest key, several times
     vals = np.arange(n, dtype=np.uint32)
     ko, vo = ops.sort_pairs(dev(keys.view(np.int32)), dev(vals.view(np.int32)), bits, ws)
     order = np.argsort(keys, kind='stable')
@@ -102,6 +105,40 @@ def test_embed_onehot_rmode_bit_exact(ops_ws):
     assert np.array_equal(zz[:, SV * E:SV * E + C], xc)
     pref = np.where((idx >= 0) & (idx < np.array(cards)[None]), offs[:-1][None] + idx, -1)
     assert np.array_equal(pos.cpu().numpy(), pref)
+
+
+@pytest.mark.parametrize('rmode', [False, True])
+@pytest.mark.parametrize('B', [1, 37, 128, 1638, 1639])
+def test_emb_sort_pairs_small_and_large_batches(ops_ws, B, rmode):
+    """(key, src) pairs of the table backward in stable key order, from one pair to several radix tiles, in both
+    table semantics; out-of-range ids get the sentinel key."""
+    ops, ws = ops_ws
+    rng = np.random.default_rng(B)
+    cards = [3, 50, 7, 1000, 20]
+    F = len(cards)
+    offs = np.zeros(F + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(cards)
+    total = int(offs[-1])
+    N = total if rmode else F
+    idx = np.stack([rng.integers(0, v, B) for v in cards], 1).astype(np.int32)
+    idx[0, 1] = -1
+    idx[B // 2, 3] = cards[3]
+    ok = (idx >= 0) & (idx < np.array(cards)[None])
+    b = np.arange(B, dtype=np.int64)[:, None]
+    f = np.arange(F, dtype=np.int64)[None]
+    if rmode:
+        k = np.where(ok, offs[:-1][None] + 1, total)
+        v = np.where(ok, b * N + offs[:-1][None] + idx, 0)
+    else:
+        k = np.where(ok, offs[:-1][None] + idx, total)
+        v = np.broadcast_to(b * N + f, (B, F))
+    k, v = k.reshape(-1).astype(np.uint32), np.ascontiguousarray(v).reshape(-1).astype(np.uint32)
+    order = np.argsort(k, kind='stable')
+    keys = torch.zeros(B * F, dtype=torch.int32, device=DEV)
+    src = torch.zeros(B * F, dtype=torch.int32, device=DEV)
+    ops.emb_sort(dev(idx), dev(offs), N=N, total_rows=total, rmode=rmode, keys_out=keys, src_out=src, ws=ws)
+    assert np.array_equal(keys.cpu().numpy().view(np.uint32), k[order])
+    assert np.array_equal(src.cpu().numpy().view(np.uint32), v[order])
 
 
 @pytest.mark.parametrize('skew', [False, True])
