@@ -1,0 +1,171 @@
+"""The hot path at the full Criteo-Kaggle shape (33.76 M table rows of 16 floats = 2.16 GB, so byte offsets pass
+2^31; batch 65536 x 26 fields): too large for the CPU oracle, so the checks are size-independent properties and
+comparisons with plain torch operators on the same GPU.  Row copies and index work must be bit-exact; fp32
+reductions within 1e-5 relative (max-norm) of a float64 evaluation."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+B, E = 65536, 16
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope='module')
+def shape(sess):
+    from recommendation_amd import ops
+    from recommendation_amd.synthetic import CRITEO_KAGGLE, make_batches
+    cards = list(CRITEO_KAGGLE)
+    F = len(cards)
+    offs = torch.zeros(F + 1, dtype=torch.int64)
+    offs[1:] = torch.cumsum(torch.tensor(cards, dtype=torch.int64), 0)
+    total = int(offs[-1])
+    idx = make_batches(cards, 13, B, 1, 1.05, 5, DEV)[0][0].clone()
+    idx[0, :] = 0                                                           # first row of every table
+    idx[1, :] = torch.tensor(cards, dtype=torch.int32, device=DEV) - 1      # last row: the highest addresses
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(1)
+    tables = torch.randn(total, E, generator=gen, device=DEV)
+    rows = (offs[:-1].to(DEV)[None] + idx.to(torch.int64)).reshape(-1)      # global row of every lookup
+    dz = torch.randn(B, F * E, generator=gen, device=DEV)
+    return SimpleNamespace(ops=ops, ws=sess.ws, cards=cards, F=F, offs=offs.to(DEV), total=total, idx=idx,
+                           tables=tables, rows=rows, gen=gen, dz=dz)
+
+
+@pytest.fixture(scope='module')
+def pairs(shape):
+    """(keys, src) of the table backward, sorted by the library."""
+    s = shape
+    n = B * s.F
+    keys = torch.zeros(n, dtype=torch.int32, device=DEV)
+    src = torch.zeros(n, dtype=torch.int32, device=DEV)
+    s.ops.emb_sort(s.idx, s.offs, N=s.F, total_rows=s.total, rmode=False, keys_out=keys, src_out=src, ws=s.ws)
+    return keys, src
+
+
+def test_gather_copies_the_addressed_rows(shape):
+    s = shape
+    ld = s.F * E + 16
+    z = torch.zeros(B, ld, device=DEV)
+    first = torch.zeros(B, s.F, device=DEV)
+    second = torch.zeros(B, E, device=DEV)
+    oor = torch.zeros(1, dtype=torch.int32, device=DEV)
+    s.ops.embed_fwd(s.tables, s.offs, s.idx, E=E, z_out=z, first_out=first, second_out=second, oor_count=oor)
+    ref = s.tables[s.rows].view(B, s.F, E)
+    assert torch.equal(z[:, :s.F * E].reshape(B, s.F, E), ref)
+    assert int(oor.item()) == 0
+    r64 = ref.double()
+    assert rel(first, r64.sum(2)) < 1e-5
+    assert rel(second, 0.5 * (r64.sum(1) ** 2 - (r64 ** 2).sum(1))) < 1e-5
+
+
+def test_sort_is_a_stable_permutation_of_the_lookups(shape, pairs):
+    s = shape
+    n = B * s.F
+    keys, src = pairs
+    k, p = keys.to(torch.int64), src.to(torch.int64)
+    assert bool((k[1:] >= k[:-1]).all())                                     # sorted
+    assert torch.equal(torch.sort(p).values, torch.arange(n, device=DEV))    # every lookup exactly once
+    assert torch.equal(k, s.rows[p])                                         # each key is its lookup's row
+    same = k[1:] == k[:-1]
+    assert bool((p[1:][same] > p[:-1][same]).all())                          # equal keys keep batch order
+
+
+def test_segment_reduce_matches_index_add_and_conserves_the_column_sums(shape, pairs):
+    s = shape
+    n = B * s.F
+    keys, src = pairs
+    dz = s.dz
+    grads = []
+    for _ in range(2):
+        g = torch.zeros(s.total, E, device=DEV)
+        s.ops.emb_sparse_apply(keys, src, n, N=s.F, E=E, total_rows=s.total, dz=dz, opt=s.ops.make_opt(0),
+                               slot0=g, ws=s.ws)
+        grads.append(g)
+    assert torch.equal(grads[0], grads[1])                                   # fixed summation order
+    g = grads[0]
+    flat = dz.view(n, E)
+    # checksum of checksums: nothing lost, nothing counted twice (fp32 row sums: rounding only)
+    assert rel(g.double().sum(0), flat.double().sum(0)) < 1e-5
+    # rows that received gradient are exactly the looked-up rows
+    touched = torch.zeros(s.total, dtype=torch.bool, device=DEV)
+    touched[s.rows] = True
+    assert not bool(g[~touched].any())
+    # per row against a float64 scatter-add of the same values
+    uniq, inv = torch.unique(s.rows, return_inverse=True)
+    ref = torch.zeros(uniq.numel(), E, dtype=torch.float64, device=DEV)
+    ref.index_add_(0, inv, flat.double())
+    assert rel(g[uniq], ref) < 1e-5
+
+
+def test_sparse_adam_touches_only_the_looked_up_rows(shape, pairs):
+    """Row-wise Adam on touched rows: the other 33.5 M rows keep their bits, the touched ones follow the
+    TF-1 update w -= lr_t * m / (sqrt(v) + eps) with m, v starting from zero."""
+    s = shape
+    n = B * s.F
+    keys, src = pairs
+    w = s.tables.clone()
+    m = torch.zeros_like(w)
+    v = torch.zeros_like(w)
+    lr_t, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    opt = s.ops.make_opt(1, lr=lr_t, beta1=b1, beta2=b2, eps=eps)
+    s.ops.emb_sparse_apply(keys, src, n, N=s.F, E=E, total_rows=s.total, dz=s.dz, opt=opt, tables=w, slot0=m,
+                           slot1=v, ws=s.ws)
+    uniq, inv = torch.unique(s.rows, return_inverse=True)
+    untouched = torch.ones(s.total, dtype=torch.bool, device=DEV)
+    untouched[uniq] = False
+    assert torch.equal(w[untouched], s.tables[untouched])
+    assert not bool(m[untouched].any()) and not bool(v[untouched].any())
+    g = torch.zeros(uniq.numel(), E, dtype=torch.float64, device=DEV)
+    g.index_add_(0, inv, s.dz.view(n, E).double())
+    m_ref = (1 - b1) * g
+    v_ref = (1 - b2) * g * g
+    assert rel(m[uniq], m_ref) < 1e-5
+    assert rel(v[uniq], v_ref) < 3e-5          # the square doubles the relative error of the fp32 row sum
+    # the first Adam step is close to lr_t * sign(g): ill-conditioned where a row sum nearly cancels, so the weight
+    # is checked against the formula applied to the kernel's own moments
+    w_ref = s.tables[uniq].double() - lr_t * m[uniq].double() / (v[uniq].double().sqrt() + eps)
+    assert rel(w[uniq], w_ref) < 1e-6
+
+
+def test_first_tower_product_matches_float64(shape):
+    """65536 x 429 x 256, the largest product of the step, with bias + relu, against float64 on the GPU."""
+    s = shape
+    x = torch.randn(B, 432, generator=s.gen, device=DEV)[:, :429]
+    w = torch.randn(429, 256, generator=s.gen, device=DEV) * 0.05
+    b = torch.randn(256, generator=s.gen, device=DEV)
+    out = torch.zeros(B, 256, device=DEV)
+    s.ops.gemm(x, w, out, bias=b, relu=True, ws=s.ws)
+    ref = torch.relu(x.double() @ w.double() + b.double())
+    assert rel(out, ref) < 1e-5
+    # linearity in the left operand: (2x) W = 2 (x W), exactly (a power of two scales every term)
+    out2 = torch.zeros(B, 256, device=DEV)
+    s.ops.gemm(x * 2, w, out2, ws=s.ws)
+    out1 = torch.zeros(B, 256, device=DEV)
+    s.ops.gemm(x, w, out1, ws=s.ws)
+    assert torch.equal(out2, out1 * 2)
+
+
+def test_training_steps_are_reproducible_at_full_size(sess):
+    """Two models built from the same seed take three steps on the same batches: same losses, bit for bit, and the
+    loss falls within the range of a binary log loss."""
+    import bench
+    from recommendation_amd.synthetic import CRITEO_KAGGLE, make_batches
+    batches = make_batches(list(CRITEO_KAGGLE), 13, B, 3, 1.05, 9, DEV)
+    runs = []
+    for _ in range(2):
+        args = SimpleNamespace(model='DeepFM', embed=16, shard='table', comm='rccl')
+        model = bench.build_model(args, sess, list(CRITEO_KAGGLE), 0, 1)
+        losses = [float(model.train_step(*b).item()) for b in batches]
+        runs.append(losses)
+        del model
+        torch.cuda.empty_cache()
+    assert runs[0] == runs[1]
+    assert all(0.0 < v < 2.0 for v in runs[0])
