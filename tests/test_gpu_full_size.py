@@ -153,6 +153,37 @@ def test_first_tower_product_matches_float64(shape):
     assert torch.equal(out2, out1 * 2)
 
 
+@pytest.mark.parametrize('M,N,K', [(429, 256, 65536), (256, 128, 65536), (128, 64, 65536), (64, 32, 65536),
+                                   (74, 1, 65536), (1677, 1024, 8192), (1024, 1024, 8192)])
+def test_weight_gradients_at_the_benchmark_shapes(shape, M, N, K):
+    """dW = X^T G and db = column sums of G over the whole batch (the long-K products: split over the batch and
+    reduced in a fixed order), for every tower layer of the DeepFM and DCN benchmark shapes."""
+    s = shape
+    x = torch.randn(K, (M + 3) // 4 * 4, generator=s.gen, device=DEV)[:, :M]
+    g = torch.randn(K, (N + 3) // 4 * 4, generator=s.gen, device=DEV)[:, :N] / K
+    outs = []
+    for _ in range(2):
+        dW, db = torch.full((M, N), 3.0, device=DEV), torch.full((N,), 3.0, device=DEV)
+        s.ops.dense_wgrad(x, g, dW, db, ws=s.ws)
+        outs.append((dW, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel(outs[0][0], x.double().t() @ g.double()) < 1e-5
+    assert rel(outs[0][1], g.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize('M,N,K', [(65536, 429, 256), (65536, 256, 128), (8192, 1024, 1024), (8192, 1677, 1024)])
+def test_activation_gradients_at_the_benchmark_shapes(shape, M, N, K):
+    """dX = (dY W^T) masked by the stored activation (relu + dropout backward in the epilogue)."""
+    s = shape
+    dy = torch.randn(M, K, generator=s.gen, device=DEV)
+    w = torch.randn(N, K, generator=s.gen, device=DEV) / 16
+    h = torch.relu(torch.randn(M, (N + 3) // 4 * 4, generator=s.gen, device=DEV))[:, :N]
+    dx = torch.zeros(M, (N + 3) // 4 * 4, device=DEV)[:, :N]
+    s.ops.gemm(dy, w, dx, trans_b=True, mask_src=h, mask_scale=1.25, ws=s.ws)
+    ref = (dy.double() @ w.double().t()) * torch.where(h > 0, 1.25, 0.0)
+    assert rel(dx, ref) < 1e-5
+
+
 def test_training_steps_are_reproducible_at_full_size(sess):
     """Two models built from the same seed take three steps on the same batches: same losses, bit for bit, and the
     loss falls within the range of a binary log loss."""

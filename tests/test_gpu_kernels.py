@@ -334,11 +334,13 @@ def test_colsum_rowdot_loss(ops_ws):
         assert rel_err(dx.cpu().numpy(), t.grad.numpy()) < 2e-5, kind
 
 
-@pytest.mark.parametrize('D,L', [(50, 3), (429, 3), (1677, 6), (300, 1), (2100, 8)])
-def test_cross_network_fwd_bwd(ops_ws, D, L):
+@pytest.mark.parametrize('D,L,B', [(50, 3, 37), (429, 3, 37), (1677, 6, 37), (300, 1, 37), (2100, 8, 37),
+                                   (1677, 6, 8192), (429, 3, 65536), (50, 2, 200)])
+def test_cross_network_fwd_bwd(ops_ws, D, L, B):
+    """B = 37: one chunk of samples; 200, 8192 and 65536: several chunks, the last two at the chunk-count cap and
+    at the benchmark shapes, so the partial sums of dw/db go through the staged final reduction."""
     ops, ws = ops_ws
     rng = np.random.default_rng(D + L)
-    B = 37
     x0 = (rng.standard_normal((B, D)) * 0.5).astype(np.float32)
     w = (rng.standard_normal((L, D)) * 0.05).astype(np.float32)
     b = (rng.standard_normal((L, D)) * 0.05).astype(np.float32)
@@ -438,7 +440,7 @@ def test_device_auc_and_logloss_match_the_host_metrics(ops_ws, n, ties):
 
 @pytest.mark.parametrize('M,K0,widths,rate', [(1000, 256, (64, 32, 16), 0.0), (77, 128, (64, 32), 0.2),
                                                (4099, 64, (64, 32, 16), 0.3), (513, 128, (64, 32), 0.2),
-                                               (65, 48, (64, 32), 0.0)])
+                                               (65, 48, (64, 32), 0.0), (65536, 128, (64, 32), 0.2)])
 def test_chained_tower_layers_match_layer_by_layer_gemms(ops_ws, M, K0, widths, rate):
     """one launch for the narrow layers == relu(h W + b) with the counter-hash dropout, layer by layer in float64"""
     ops, ws = ops_ws
@@ -474,7 +476,7 @@ def test_chained_tower_layers_match_layer_by_layer_gemms(ops_ws, M, K0, widths, 
 
 
 @pytest.mark.parametrize('B,K,mask_from', [(1000, 74, 42), (65, 255, -1), (4099, 17, 0), (3, 1, 1), (515, 2701, 1677), (33, 256, 100),
-                                           (70, 4096, -1)])
+                                           (70, 4096, -1), (65536, 74, 42), (8192, 2701, 1677)])
 def test_fused_output_unit_backward(ops_ws, B, K, mask_from):
     """dX = dl w^T with the relu/dropout mask on the tail columns, dw = X^T dl, db = sum dl, in one pass"""
     ops, ws = ops_ws
@@ -497,7 +499,8 @@ def test_fused_output_unit_backward(ops_ws, B, K, mask_from):
     assert abs(float(db.item()) - float(dl.astype(np.float64).sum())) < 1e-6
 
 
-@pytest.mark.parametrize('M,widths,offset', [(1000, (32, 64, 128), 0), (77, (16, 32, 64), 3), (4099, (32, 64, 128), 2)])
+@pytest.mark.parametrize('M,widths,offset', [(1000, (32, 64, 128), 0), (77, (16, 32, 64), 3), (4099, (32, 64, 128), 2),
+                                             (65536, (32, 64, 128), 0)])
 def test_chained_activation_gradients_match_layer_by_layer(ops_ws, M, widths, offset):
     """two dX steps in one launch == (g W^T) * relu/dropout mask, layer by layer in float64"""
     ops, ws = ops_ws
