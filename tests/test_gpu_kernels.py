@@ -571,7 +571,7 @@ def test_embed_assemble_and_routed_dz_match_the_plain_layout(ops_ws):
     assert (dz_other == 0).all()                           # every row of this Z belongs to a sharded field
 
 
-@pytest.mark.parametrize('B,N,E,P,per_sample', [(1001, 39, 16, 50, True), (7, 7, 16, 5, False), (130, 64, 16, 64, True),
+@pytest.mark.parametrize('B,N,E,P,per_sample', [(1001, 39, 16, 50, True), (65536, 39, 16, 50, True), (7, 7, 16, 5, False), (130, 64, 16, 64, True),
                                                 (66, 17, 16, 33, False), (258, 39, 8, 50, True), (33, 5, 32, 9, True)])
 def test_pnn_inner_product_term_forward_and_backward(ops_ws, B, N, E, P, per_sample):
     """u = W Z per sample: usq = sum_e u^2; given coef: dZ += W^T (coef * u), dW = sum_b (coef * u) Z^T.
@@ -601,7 +601,7 @@ def test_pnn_inner_product_term_forward_and_backward(ops_ws, B, N, E, P, per_sam
     assert (dzd[:, N * E:] == 3.0).all()
 
 
-@pytest.mark.parametrize('B,N,E,rate', [(1001, 39, 16, 0.3), (5, 2, 16, 0.0), (130, 64, 16, 0.5), (66, 17, 16, 0.0),
+@pytest.mark.parametrize('B,N,E,rate', [(1001, 39, 16, 0.3), (65536, 39, 16, 0.3), (5, 2, 16, 0.0), (130, 64, 16, 0.5), (66, 17, 16, 0.0),
                                         (77, 39, 8, 0.3), (9, 5, 4, 0.0)])
 def test_afm_pair_layer_forward_and_backward(ops_ws, B, N, E, rate):
     """x[e] = sum_{i<j} m_ij z_i[e] z_j[e] with the per-pair dropout multipliers of the counter hash; backward
