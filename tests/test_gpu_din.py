@@ -40,9 +40,11 @@ def _setup(sess, H, seed=0, item_count=40, cate_count=6, B=9, T=11):
     return m, orc, (u, i, y, hist, sl), (u, i, j, hist, sl)
 
 
-@pytest.mark.parametrize('H', [8, 32])
-def test_din_train_and_eval_match_oracle(sess, H):
-    m, orc, uij, uij_eval = _setup(sess, H)
+@pytest.mark.parametrize('H,B,T', [(8, 9, 11), (32, 9, 11), (32, 300, 200), (128, 64, 200)])
+def test_din_train_and_eval_match_oracle(sess, H, B, T):
+    """The last two cases have the history length of the Amazon-Books benchmark shape (T = 200): the per-sample
+    block kernels walk several tiles of positions."""
+    m, orc, uij, uij_eval = _setup(sess, H, B=B, T=T, item_count=40 if B < 100 else 5000, cate_count=6 if B < 100 else 80)
     auc_g, pn_g = m.eval(sess, uij_eval)
     auc_o, pn_o = orc.eval(uij_eval)
     assert abs(float(auc_g) - float(auc_o)) < 1e-6
