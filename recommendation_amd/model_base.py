@@ -335,13 +335,14 @@ class CTRModel:
             step0 = self.global_step
             self._indirect = (step_w, lr_w)
             try:
-                _capture(graph, lambda: self.train_step(s_idx, s_xc, s_yy))
+                with self.session.private_side() as side_objs:
+                    _capture(graph, lambda: self.train_step(s_idx, s_xc, s_yy))
             finally:
                 self._indirect = None
                 self.global_step = step0           # the capture ran no kernel and does not count as a step
-            self._train_graphs[B] = (graph, s_idx, s_xc, s_yy, step_w, lr_w)
+            self._train_graphs[B] = (graph, s_idx, s_xc, s_yy, step_w, lr_w, side_objs)
             return loss
-        graph, s_idx, s_xc, s_yy, step_w, lr_w = entry
+        graph, s_idx, s_xc, s_yy, step_w, lr_w, _ = entry
         s_idx.copy_(idx)
         s_xc.copy_(xc)
         s_yy.copy_(yy)

@@ -53,6 +53,19 @@ class Session:
         self._side_open = True
         return torch.cuda.stream(self._side)
 
+    @contextlib.contextmanager
+    def private_side(self):
+        """For a graph capture: a side stream and events of its own, so that nothing recorded into the graph is
+        ever recorded again eagerly or by another capture.  Yields the objects; the graph's owner keeps them alive."""
+        saved = (self._side, self._fork_ev, self._join_ev, self._side_open)
+        self._side = torch.cuda.Stream(self.device)
+        self._fork_ev, self._join_ev = torch.cuda.Event(), torch.cuda.Event()
+        self._side_open = False
+        try:
+            yield (self._side, self._fork_ev, self._join_ev)
+        finally:
+            self._side, self._fork_ev, self._join_ev, self._side_open = saved
+
     def side_join(self):
         """The current stream waits for everything issued to the side stream."""
         if self._side_open:

@@ -258,3 +258,45 @@ def test_graph_replay_survives_workspace_growth(sess):
     assert outs[0][0] == outs[1][0]
     for k in outs[0][1]:
         assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+
+
+def _criteo_like_cfg(name, variant):
+    """The reference's default architecture (256-128-64-32 tower, DeepFM/main.py:48-59 and siblings) on a
+    Criteo-like field layout: 26 categorical + 13 continuous fields, embedding width 16, S semantics - the shapes at
+    which the models take the chained tower kernels, the fused output unit and the matrix-core interaction kernels."""
+    cfg = no_dropout(O.default_cfg(name, embed_size=16, mode='S'))
+    rng = np.random.default_rng(11)
+    cfg.cate_list = [int(v) for v in rng.integers(3, 200, 26)]
+    cfg.cate_num, cfg.cont_num = 26, 13
+    cfg.adam_mode = 'tf1'
+    if variant == 'PNN_outer':
+        cfg.inner_product = False
+    return cfg
+
+
+@pytest.mark.parametrize('variant', ['DeepFM', 'DCN', 'NFM', 'ESMM', 'PNN', 'PNN_outer', 'AFM'])
+def test_reference_default_architecture_matches_oracle(sess, variant):
+    """Forward, loss, every gradient and three optimizer steps at the reference's default layer sizes, B = 300."""
+    name = variant.split('_')[0]
+    cfg = _criteo_like_cfg(name, variant)
+    P = O.init_params(name, cfg, seed=5, std=0.05)
+    Xc, Xf, y = tiny_batch(cfg, B=300, seed=2)
+    if name == 'AFM':          # AFM feeds log_loss an unbounded y_out (AFM/AFM.py:85-88): keep 0 < y_out < 1
+        Xf = np.abs(Xf) * 0.1
+        P = {k: np.abs(v) * 0.2 for k, v in P.items()}
+    orc = O.OracleModel(name, cfg, P, dtype=torch.float64)
+    m = _build(sess, name, cfg, P)
+    p_ref = orc.forward(Xc, Xf).y_out.numpy()
+    assert rel_err(m.predict_proba(sess, Xc, Xf), p_ref) < TOL
+    loss_ref, g_ref, _ = orc.loss_and_grads(Xc, Xf, y)
+    loss_gpu = m.run(sess, Xc, Xf, y, True)
+    assert abs(float(loss_gpu) - float(loss_ref)) < TOL * max(1.0, abs(float(loss_ref)))
+    for k, v in m.get_grads().items():
+        assert rel_err(v, g_ref[k].numpy()) < 5 * TOL, k
+    orc.run(Xc, Xf, y, True)
+    for _ in range(2):
+        l_o = orc.run(Xc, Xf, y, True)
+        l_g = m.run(sess, Xc, Xf, y, True)
+        assert abs(float(l_o) - float(l_g)) < 1e-5
+    for k, v in m.get_params().items():
+        assert rel_err(v, orc.P[k].numpy()) < 1e-4, k
