@@ -31,7 +31,7 @@ class StagedComm:
         t.copy_(c)
 
 
-def main(model_name, shard='table'):
+def main(model_name, shard='table', arch='tiny'):
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     import recommendation_amd as ra
@@ -51,23 +51,33 @@ def main(model_name, shard='table'):
     if model_name == 'PNN':
         cfg.hidden_layers, cfg.product_size = [16, 8], 6
     cfg.adam_mode = 'tf1'
-    P = O.init_params(model_name, cfg, seed=1, std=0.2)
+    std, Bg = 0.2, 64
+    if arch == 'default':        # the reference's default tower on a Criteo-like layout: chained / fused kernels, E = 16
+        cfg = O.default_cfg(model_name, embed_size=16, mode='S')
+        cfg.cate_list = [int(v) for v in np.random.default_rng(11).integers(3, 200, 26)]
+        cfg.cate_num, cfg.cont_num = 26, 13
+        for k in ('dropout_fm', 'dropout_deep', 'dropout_bi', 'dropout'):
+            if hasattr(cfg, k):
+                setattr(cfg, k, 0.0)
+        cfg.adam_mode = 'tf1'
+        std, Bg = 0.05, 256
+    F, C = cfg.cate_num, cfg.cont_num
+    P = O.init_params(model_name, cfg, seed=1, std=std)
     rng = np.random.default_rng(5)
-    Bg = 64
     Xc = np.stack([rng.integers(0, v, Bg) for v in cfg.cate_list], 1)
-    Xf = rng.standard_normal((Bg, 3))
+    Xf = rng.standard_normal((Bg, C))
     y = rng.integers(0, 2, Bg)
     sess = ra.Session('cuda:0', seed=3)
     import copy
     dcfg = copy.copy(cfg)
     dcfg.world_size, dcfg.rank, dcfg.comm, dcfg.shard = world, rank, StagedComm(), shard
-    m = cls(dcfg, 5, 3, cfg.cate_list)
+    m = cls(dcfg, F, C, cfg.cate_list)
     m.build()
     m.initialize(sess, params=P)
     lo, hi = rank * Bg // world, (rank + 1) * Bg // world
     for _ in range(3):
         m.run(sess, Xc[lo:hi], Xf[lo:hi], y[lo:hi], True)
-    single = cls(cfg, 5, 3, cfg.cate_list)
+    single = cls(cfg, F, C, cfg.cate_list)
     single.build()
     single.initialize(sess, params=P)
     for _ in range(3):
@@ -82,7 +92,7 @@ def main(model_name, shard='table'):
         assert v.shape == want.shape, (rank, k, v.shape, want.shape)
         assert rel_err(v, want) < 2e-5, (rank, k, rel_err(v, want))
         n_tab += k.startswith('embedding/embed_cate_w_')
-    assert n_tab == (5 if shard == 'row' else m.front.nf_own)
+    assert n_tab == (F if shard == 'row' else m.front.nf_own)
     dist.barrier()
     if rank == 0:
         print('DIST_OK %s %s' % (model_name, shard))
@@ -90,4 +100,4 @@ def main(model_name, shard='table'):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else 'table')
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else 'table', sys.argv[3] if len(sys.argv) > 3 else 'tiny')

@@ -9,12 +9,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('model,shard', [('DeepFM', 'table'), ('DCN', 'table'), ('PNN', 'table'),
-                                         ('DeepFM', 'row'), ('DCN', 'row'), ('PNN', 'row')])
-def test_two_ranks_match_one_rank(sess, model, shard):
+@pytest.mark.parametrize('model,shard,arch', [('DeepFM', 'table', 'tiny'), ('DCN', 'table', 'tiny'),
+                                              ('PNN', 'table', 'tiny'), ('DeepFM', 'row', 'tiny'),
+                                              ('DCN', 'row', 'tiny'), ('PNN', 'row', 'tiny'),
+                                              ('DeepFM', 'table', 'default'), ('DeepFM', 'row', 'default'),
+                                              ('DCN', 'table', 'default')])
+def test_two_ranks_match_one_rank(sess, model, shard, arch):
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-           '--master-addr', '127.0.0.1', '--master-port', '29731', os.path.join(ROOT, 'tests', 'dist_worker.py'), model, shard]
+           '--master-addr', '127.0.0.1', '--master-port', '29731', os.path.join(ROOT, 'tests', 'dist_worker.py'), model, shard, arch]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'DIST_OK %s %s' % (model, shard) in r.stdout
