@@ -263,6 +263,53 @@ def test_gemm_f32_all_layouts(ops_ws, shape, ta, tb):
     assert np.all(out[:, N:] == -1.0)                              # nothing written outside the view
 
 
+def _sweep_shapes():
+    """Seeded shapes on both sides of the kernel-plan switches (tile widths, pre-transposed weights, split-K, the
+    streaming weight-gradient kernel), plus ragged edges."""
+    rng = np.random.default_rng(2024)
+    out = []
+    for _ in range(28):
+        M = int(rng.choice([1, 31, 127, 128, 129, 700, 2047, 2048, 2500, 5000]))
+        N = int(rng.choice([1, 17, 64, 191, 192, 193, 256, 511, 512, 640, 1100]))
+        K = int(rng.choice([1, 15, 16, 100, 511, 512, 513, 1024, 3000, 20000]))
+        if M * N * K > 6e9:
+            K = 512
+        out.append((M, N, K, bool(rng.integers(2)), bool(rng.integers(2)), int(rng.integers(4))))
+    return out
+
+
+@pytest.mark.parametrize('M,N,K,ta,tb,epi', _sweep_shapes())
+def test_gemm_plan_boundaries(ops_ws, M, N, K, ta, tb, epi):
+    """fp32 products against float64 on the GPU, with a bias+relu, masked or accumulating epilogue."""
+    ops, ws = ops_ws
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(M * 31 + N * 7 + K)
+
+    def mk(r, c):
+        return torch.randn(r, (c + 3) // 4 * 4 + (4 if (r + c) % 3 == 0 else 0), generator=gen, device=DEV)[:, :c]
+    A = mk(K, M) if ta else mk(M, K)
+    Bm = mk(N, K) if tb else mk(K, N)
+    ref = (A.double().t() if ta else A.double()) @ (Bm.double().t() if tb else Bm.double())
+    C = torch.full((M, N + 3), 0.5, device=DEV)
+    kw = {}
+    if epi == 1:
+        bias = torch.randn(N, generator=gen, device=DEV)
+        kw = dict(bias=bias, relu=True)
+        ref = torch.relu(ref + bias.double())
+    elif epi == 2:
+        h = torch.relu(mk(M, N))
+        kw = dict(mask_src=h, mask_scale=1.25)
+        ref = ref * torch.where(h > 0, 1.25, 0.0)
+    elif epi == 3:
+        kw = dict(accumulate=True)
+        ref = ref + 0.5
+    ops.gemm(A, Bm, C[:, :N], trans_a=ta, trans_b=tb, ws=ws, **kw)
+    scale = float(((A.double().abs().t() if ta else A.double().abs()) @
+                   (Bm.double().abs().t() if tb else Bm.double().abs())).max())
+    assert float((C[:, :N].double() - ref).abs().max()) < 1e-5 * max(scale, 1e-30) + 1e-6
+    assert bool((C[:, N:] == 0.5).all())
+
+
 def test_gemm_epilogues(ops_ws):
     ops, ws = ops_ws
     rng = np.random.default_rng(5)
