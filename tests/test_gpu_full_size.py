@@ -154,10 +154,13 @@ def test_first_tower_product_matches_float64(shape):
 
 
 @pytest.mark.parametrize('M,N,K', [(429, 256, 65536), (256, 128, 65536), (128, 64, 65536), (64, 32, 65536),
-                                   (74, 1, 65536), (1677, 1024, 8192), (1024, 1024, 8192)])
+                                   (74, 1, 65536), (1677, 1024, 8192), (1024, 1024, 8192),
+                                   (128, 80, 409600), (80, 40, 409600), (40, 1, 409600), (512, 80, 409600),
+                                   (39, 256, 65536), (50, 32, 65536), (7, 5, 3), (300, 3, 100000)])
 def test_weight_gradients_at_the_benchmark_shapes(shape, M, N, K):
     """dW = X^T G and db = column sums of G over the whole batch (the long-K products: split over the batch and
-    reduced in a fixed order), for every tower layer of the DeepFM and DCN benchmark shapes."""
+    reduced in a fixed order), for every tower layer of the DeepFM and DCN benchmark shapes, the attention
+    layers of DIN at B*T = 409600 rows, and a few ragged shapes."""
     s = shape
     x = torch.randn(K, (M + 3) // 4 * 4, generator=s.gen, device=DEV)[:, :M]
     g = torch.randn(K, (N + 3) // 4 * 4, generator=s.gen, device=DEV)[:, :N] / K
