@@ -203,3 +203,47 @@ def test_training_steps_are_reproducible_at_full_size(sess):
         torch.cuda.empty_cache()
     assert runs[0] == runs[1]
     assert all(0.0 < v < 2.0 for v in runs[0])
+
+
+def test_wide_rows_in_a_table_past_4_gib(sess):
+    """E = 64 (the DCN benchmark width) in tables of 20 M rows x 256 bytes = 5.1 GB: byte offsets pass 2^32.
+    Gather, sort + segment reduce and the row-wise Adam update address the last rows correctly."""
+    from recommendation_amd import ops
+    E64, Bs = 64, 8192
+    cards = [10_000_000, 8_000_000, 2_000_000, 50, 3]
+    F = len(cards)
+    offs = torch.zeros(F + 1, dtype=torch.int64)
+    offs[1:] = torch.cumsum(torch.tensor(cards, dtype=torch.int64), 0)
+    total = int(offs[-1])
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(3)
+    idx = torch.stack([torch.randint(0, v, (Bs,), generator=gen, device=DEV) for v in cards], 1).to(torch.int32)
+    idx[0, :] = torch.tensor(cards, dtype=torch.int32, device=DEV) - 1          # the last row of every table
+    idx[1, :] = 0
+    tables = torch.randn(total, E64, generator=gen, device=DEV)
+    offs = offs.to(DEV)
+    rows = (offs[:-1][None] + idx.to(torch.int64)).reshape(-1)
+    z = torch.zeros(Bs, F * E64, device=DEV)
+    ops.embed_fwd(tables, offs, idx, E=E64, z_out=z)
+    assert torch.equal(z.view(Bs, F, E64), tables[rows].view(Bs, F, E64))
+    n = Bs * F
+    keys = torch.zeros(n, dtype=torch.int32, device=DEV)
+    src = torch.zeros(n, dtype=torch.int32, device=DEV)
+    ops.emb_sort(idx, offs, N=F, total_rows=total, rmode=False, keys_out=keys, src_out=src, ws=sess.ws)
+    assert torch.equal(keys.to(torch.int64), rows[src.to(torch.int64)])
+    dz = torch.randn(Bs, F * E64, generator=gen, device=DEV)
+    w, m, v = tables.clone(), torch.zeros_like(tables), torch.zeros_like(tables)
+    lr_t, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    ops.emb_sparse_apply(keys, src, n, N=F, E=E64, total_rows=total, dz=dz,
+                         opt=ops.make_opt(1, lr=lr_t, beta1=b1, beta2=b2, eps=eps), tables=w, slot0=m, slot1=v,
+                         ws=sess.ws)
+    uniq, inv = torch.unique(rows, return_inverse=True)
+    untouched = torch.ones(total, dtype=torch.bool, device=DEV)
+    untouched[uniq] = False
+    assert torch.equal(w[untouched], tables[untouched])
+    assert not bool(m[untouched].any())
+    g = torch.zeros(uniq.numel(), E64, dtype=torch.float64, device=DEV)
+    g.index_add_(0, inv, dz.view(n, E64).double())
+    assert rel(m[uniq], (1 - b1) * g) < 1e-5
+    w_ref = tables[uniq].double() - lr_t * m[uniq].double() / (v[uniq].double().sqrt() + eps)
+    assert rel(w[uniq], w_ref) < 1e-6
