@@ -60,6 +60,13 @@ def get_checkpoint_state(directory):
     return full if os.path.exists(full + '.safetensors') else None
 
 
+# Captured graphs are never destroyed: with this runtime, destroying the graphs of models that went out of use made
+# the first launch of a graph captured later segfault inside hipGraphLaunch (seen when one process captured several
+# models in turn).  A graph holds no buffers of its own here (every buffer it points at is owned by its model or
+# the session), so what stays is a few hundred launch records per captured batch size.
+_LIVE_GRAPHS = []
+
+
 def _capture(graph, fn):
     """Record fn's launches into graph.  The cyclic garbage collector is held off meanwhile: were it to run inside
     the capture and free an older model's graph, the runtime call that destroys it would be illegal there and the
@@ -70,6 +77,7 @@ def _capture(graph, fn):
         with torch.cuda.graph(graph):
             return fn()
     finally:
+        _LIVE_GRAPHS.append(graph)
         if was_on:
             gc.enable()
 
