@@ -122,6 +122,7 @@ class CTRModel:
         self._bufs = {}
         self._graphs = {}
         self._train_graphs = {}
+        self._stage = {}                 # pinned staging buffers of _upload, by (feed, shape)
         self._indirect = None            # (step word, lr word) on the device while a training graph is captured
 
     # ---- graph definition -----------------------------------------------------------------
@@ -261,21 +262,24 @@ class CTRModel:
             return ops.make_opt(OPT_KIND[self.OPTIMIZER], lr=0.0, lr_dev=self._indirect[1])
         return ops.make_opt(OPT_KIND[self.OPTIMIZER], lr=self._step_lr())
 
+    def _to_device(self, a, dtype, slot):
+        """Host array -> device tensor of `dtype`: one converting pass into a pinned staging buffer (kept per feed
+        and shape), then one copy the host waits for, so the buffer is free again on return."""
+        if isinstance(a, torch.Tensor) and a.is_cuda:
+            return a.to(dtype).contiguous()
+        src = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(np.asarray(a)))
+        key = (slot, tuple(src.shape))
+        stage = self._stage.get(key)
+        if stage is None:
+            stage = self._stage[key] = torch.empty(src.shape, dtype=dtype, pin_memory=True)
+        stage.copy_(src)
+        return stage.to(self.session.device)
+
     def _upload(self, X_cate, X_cont, y):
         """Feed conversion of the reference placeholders: int64 -> int32, float64 -> float32."""
-        dev = self.session.device
-        if isinstance(X_cate, torch.Tensor) and X_cate.is_cuda:
-            idx = X_cate.to(torch.int32).contiguous()
-        else:
-            idx = torch.as_tensor(np.ascontiguousarray(np.asarray(X_cate).astype(np.int32))).to(dev)
-        if isinstance(X_cont, torch.Tensor) and X_cont.is_cuda:
-            xc = X_cont.to(torch.float32).contiguous()
-        else:
-            xc = torch.as_tensor(np.ascontiguousarray(np.asarray(X_cont).astype(np.float32))).to(dev)
-        if isinstance(y, torch.Tensor) and y.is_cuda:
-            yy = y.to(torch.float32).contiguous()
-        else:
-            yy = torch.as_tensor(np.ascontiguousarray(np.asarray(y).astype(np.float32))).to(dev)
+        idx = self._to_device(X_cate, torch.int32, 'cate')
+        xc = self._to_device(X_cont, torch.float32, 'cont')
+        yy = self._to_device(y, torch.float32, 'y')
         if idx.dim() != 2 or idx.shape[1] != self.cate_num:
             raise ValueError('X_cate must be [B, %d]' % self.cate_num)
         if xc.dim() != 2 or xc.shape[1] != self.cont_num or xc.shape[0] != idx.shape[0]:
