@@ -552,6 +552,28 @@ class AdamTF1:
             params[k] = params[k] - lr_t * self.m[k] / (torch.sqrt(self.v[k]) + self.eps)
 
 
+class LazyAdamTF1(AdamTF1):
+    """Row-wise ("lazy") Adam for embedding tables: the TF-1.x Adam formulas above (same bias-corrected
+    step size lr_t of the GLOBAL update count t, eps outside the sqrt), applied only to the table rows a
+    batch looks up (in range); every other row keeps its weight, m and v bit for bit.  This is the sparse
+    update of tf.contrib.opt.LazyAdamOptimizer, NOT what the reference's tf.train.AdamOptimizer does
+    (DeepFM/DeepFM.py:32,100 decays m, v of every row: AdamTF1) - it is the form that exists at Criteo scale,
+    where a dense pass over the tables is 13 GB per step.  `rows[k]` (bool per row) marks the looked-up rows
+    of table k; variables without an entry in `rows` get the dense update."""
+
+    def apply(self, params, grads, lr, rows=None):
+        self.t += 1
+        lr_t = lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        for k, g in grads.items():
+            m = self.b1 * self.m[k] + (1.0 - self.b1) * g
+            v = self.b2 * self.v[k] + (1.0 - self.b2) * g * g
+            w = params[k] - lr_t * m / (torch.sqrt(v) + self.eps)
+            if rows is not None and k in rows:
+                sel = rows[k].view(-1, *([1] * (g.dim() - 1)))
+                m, v, w = torch.where(sel, m, self.m[k]), torch.where(sel, v, self.v[k]), torch.where(sel, w, params[k])
+            self.m[k], self.v[k], params[k] = m, v, w
+
+
 class AdagradTF1:
     """tf.train.AdagradOptimizer: accumulator starts at 0.1; no epsilon."""
 
@@ -809,8 +831,23 @@ class OracleModel:
     def __init__(self, model, cfg, params, dtype=torch.float64, literal=False):
         self.model, self.cfg, self.dtype, self.literal = model, cfg, dtype, literal
         self.P = OrderedDict((k, torch.as_tensor(np.asarray(v), dtype=dtype).clone()) for k, v in params.items())
-        self.opt = _OPT[OPTIMIZER[model]](self.P)
+        # cfg.adam_mode == 'lazy' (S semantics only; not a reference flag): row-wise Adam on the tables
+        self.lazy = OPTIMIZER[model] == 'adam' and getattr(cfg, 'adam_mode', 'tf1') == 'lazy'
+        if self.lazy and cfg.mode != 'S':
+            raise ValueError("adam_mode 'lazy' is defined for the standard lookup (mode 'S')")
+        self.opt = (LazyAdamTF1 if self.lazy else _OPT[OPTIMIZER[model]])(self.P)
         self.global_step = 0
+
+    def touched_rows(self, X_cate):
+        """name -> bool[V_f]: the rows of every table the batch looks up with an in-range id."""
+        xc = np.asarray(X_cate).astype(np.int32).astype(np.int64)
+        rows = {}
+        for f, v in enumerate(self.cfg.cate_list):
+            m = torch.zeros(int(v), dtype=torch.bool)
+            col = xc[:, f]
+            m[torch.as_tensor(col[(col >= 0) & (col < v)])] = True
+            rows['embedding/embed_cate_w_%d' % f] = m
+        return rows
 
     def _inputs(self, X_cate, X_cont, y):
         xc = torch.as_tensor(np.asarray(X_cate).astype(np.int32).astype(np.int64))   # feed narrows to int32
@@ -841,7 +878,10 @@ class OracleModel:
     def run(self, X_cate, X_cont, y, is_train=False, masks=None):
         if is_train:
             loss, g, _ = self.loss_and_grads(X_cate, X_cont, y, masks)
-            self.opt.apply(self.P, g, self.lr())
+            if self.lazy:
+                self.opt.apply(self.P, g, self.lr(), rows=self.touched_rows(X_cate))
+            else:
+                self.opt.apply(self.P, g, self.lr())
             self.global_step += 1
             return np.float32(loss.item())
         out = self.forward(X_cate, X_cont)

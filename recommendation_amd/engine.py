@@ -143,6 +143,7 @@ class EmbedFront:
         self.Ncat = tables.total_rows if mode == 'R' else tables.F
         self.N = self.Ncat + (self.C if cont_embed else 0)
         self.E = tables.E
+        self.oor_count = None     # optional device int32[1]: the standard lookup counts out-of-range ids here
 
     def forward(self, idx, x_cont, *, z_out, cont_tail=False, cont_w=None, first_out=None, s_out=None,
                 second_out=None, drop_first=None, drop_second=None, oor_count=None):
@@ -152,7 +153,7 @@ class EmbedFront:
             ops.embed_fwd(t.weight, t.row_offset, idx, x_cont, cont_w if self.cont_embed else None, E=E,
                           z_out=z_out, cont_tail=cont_tail, first_out=first_out, s_out=s_out,
                           second_out=second_out, drop_first=drop_first, drop_second=drop_second,
-                          oor_count=oor_count)
+                          oor_count=oor_count if oor_count is not None else self.oor_count)
             return
         if z_out is None:
             raise ValueError('R-mode needs the dense Z buffer')

@@ -75,9 +75,19 @@ def _capture(graph, fn):
     gc.disable()
     try:
         with torch.cuda.graph(graph):
-            return fn()
+            # A graph must own no memory: a tensor allocated while capturing would live in the graph's private pool
+            # and could be handed out again once the graph is gone.  Every buffer a step touches is allocated by
+            # the eager step that precedes the capture; this check keeps it that way.  (Counted from inside the
+            # context: entering it allocates torch's own two generator-state words.)
+            allocs0 = torch.cuda.memory_stats()['allocation.all.allocated']
+            out = fn()
+            grew = torch.cuda.memory_stats()['allocation.all.allocated'] - allocs0
+        if grew:
+            raise RuntimeError('%d device allocation(s) happened inside a graph capture' % grew)
+        if os.environ.get('CTR_GRAPH_KEEP', '1') != '0':
+            _LIVE_GRAPHS.append(graph)
+        return out
     finally:
-        _LIVE_GRAPHS.append(graph)
         if was_on:
             gc.enable()
 
@@ -116,6 +126,13 @@ class CTRModel:
             raise ValueError("shard must be 'table' or 'row'")
         if self.world > 1 and self.mode != 'S':
             raise ValueError("multi-GPU runs use mode 'S' (the dense R-mode block exists only at parity sizes)")
+        if self.mode == 'R' and any(v < 2 for v in self.cate_list):
+            # the block reads and trains row 1 of every table (DeepFM/DeepFM.py:49-52); the reference's loader
+            # guarantees V = n_unique + 1 >= 2 (DeepFM/main.py:40) and TF cannot look up row 1 of a 1-row table
+            raise ValueError("mode 'R' needs at least 2 rows in every table (cate_list = %s)" % (self.cate_list,))
+        # True: an id outside [0, V_f) raises IndexError from run() (what tf.nn.embedding_lookup does on the CPU);
+        # False (default for these six models, whose one-hot block is silent in the reference): zero row, counted
+        self.strict_ids = bool(getattr(args, 'strict_ids', False))
         self.global_step = 0
         self._built = False
         self._ready = False
@@ -172,8 +189,13 @@ class CTRModel:
             self._own = (0, self.cate_num)
         self.tables.init_slots(self.OPTIMIZER, dense_adam=(self.adam_mode == 'tf1'))
         self.dense.init_slots(self.OPTIMIZER)
-        self._loss_dev = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._oor = torch.zeros(1, dtype=torch.int32, device=dev)
+        # the two words the host reads back after a step share one buffer (one copy): the loss and the
+        # out-of-range-id counter of the standard lookup
+        self._scalars = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._loss_dev = self._scalars[:1]
+        self._oor = self._scalars[1:].view(torch.int32)
+        if self.mode == 'S' and self.world == 1:
+            self.front.oor_count = self._oor
         rng = np.random.Generator(np.random.PCG64(seed))
         init = OrderedDict()
         for k, s in self.variable_shapes().items():
@@ -406,10 +428,31 @@ class CTRModel:
         if is_train:
             # the reference's loop feeds small mini-batches (128 by default): launch-bound, so replay a graph
             step = self.train_step_graphed if idx.shape[0] <= GRAPH_MAX_BATCH else self.train_step
-            return np.float32(step(idx, xc, yy).item())
+            step(idx, xc, yy)
+            host = self._scalars.cpu()                  # loss + out-of-range counter in one copy
+            if self.strict_ids:
+                self._raise_on_bad_ids(int(host[1:].view(torch.int32)[0]))
+            return np.float32(host[0].item())
         y_out = self.predict_step_graphed(idx, xc)      # evaluation batches are small: graph replay, not ~15 launches
         # tf.round is round-half-to-even; torch.round too
-        return np.asarray(yy.cpu().numpy(), dtype=np.float32), torch.round(y_out).cpu().numpy()
+        pred = torch.round(y_out).cpu().numpy()
+        if self.strict_ids:
+            self._raise_on_bad_ids(int(self._oor.item()))
+        return np.asarray(yy.cpu().numpy(), dtype=np.float32), pred
+
+    def out_of_range_lookups(self, reset=True):
+        """How many lookups since the last reset carried an id outside [0, V_f) (standard lookup only; they read a
+        zero row and update nothing).  Synchronises the host."""
+        n = int(self._oor.item())
+        if reset and n:
+            self._oor.zero_()
+        return n
+
+    def _raise_on_bad_ids(self, n):
+        if n:
+            self._oor.zero_()
+            raise IndexError('%d lookup(s) with an id outside [0, cate_list[f]) in this batch (the rows were read as '
+                             'zeros and received no update)' % n)
 
     def predict_proba(self, session, X_cate, X_cont):
         self._ensure_initialized(session)

@@ -49,6 +49,7 @@ class DIN(object):
         self.dense_shapes = sh
         self.global_step = 0
         self.global_epoch_step = 0
+        self.strict_ids = bool(getattr(args, 'strict_ids', True))
         self._ready = False
         self._bufs = {}
 
@@ -72,7 +73,11 @@ class DIN(object):
         self.bias_table = EmbeddingTables([self.item_count], 4, dev)     # item_b lives in column 0
         self.dense = DenseParams(self.dense_shapes, dev)
         self.cate_list = torch.as_tensor(self.cate_list_host, device=dev)
-        self._loss_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        # loss + out-of-range-id counter, read back together (tf.nn.embedding_lookup raises on an id outside the
+        # table on the CPU, DIN/DIN.py:26-27,40-41; here the step runs and train()/eval() raise afterwards)
+        self._scalars = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._loss_dev = self._scalars[:1]
+        self._oor = self._scalars[1:].view(torch.int32)
         self._auc_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         rng = np.random.Generator(np.random.PCG64(seed))
         init = OrderedDict()
@@ -172,7 +177,7 @@ class DIN(object):
         """emb[k] = [item_emb_w[id], cate_emb_w[cate_list[id]]] for all ids (DIN/DIN.py:24-42)."""
         ops.din_build_idx(ids, self.cate_list, self.item_count, b['pair'])
         ops.embed_fwd(self.tables.weight, self.tables.row_offset, b['pair'][:ids.numel()], E=self.H // 2,
-                      z_out=b['emb'][:ids.numel()])
+                      z_out=b['emb'][:ids.numel()], oor_count=self._oor)
 
     def _user_vector(self, b, sl, B, T):
         """attention() + batch_normalization + dense (DIN/DIN.py:44-49); returns u_emb."""
@@ -217,7 +222,16 @@ class DIN(object):
         y = uij[2]
         if not (isinstance(y, torch.Tensor) and y.is_cuda):
             y = torch.as_tensor(np.asarray(y, dtype=np.float32)).to(sess.device)
-        return np.float32(self.train_step(i, y.to(torch.float32), hist, sl, l).item())
+        self.train_step(i, y.to(torch.float32), hist, sl, l)
+        host = self._scalars.cpu()
+        self._raise_on_bad_ids(int(host[1:].view(torch.int32)[0]))
+        return np.float32(host[0].item())
+
+    def _raise_on_bad_ids(self, n):
+        if n and self.strict_ids:
+            self._oor.zero_()
+            raise IndexError('%d lookup(s) with an item id outside [0, item_count) in this batch (read as zero rows)'
+                             % (n // 2))      # an item id is two lookups: item table and category table
 
     def train_step(self, i, y, hist, sl, l):
         """The same step on device tensors (int32 ids / lengths, float32 labels); returns the device
@@ -310,7 +324,8 @@ class DIN(object):
         # the negative item through the same FCN weights but its own Dice alphas (DIN/DIN.py:60-66)
         ops.din_build_idx(j, self.cate_list, self.item_count, b['pair'])
         jemb = torch.zeros(B, H, dtype=torch.float32, device=sess.device)
-        ops.embed_fwd(self.tables.weight, self.tables.row_offset, b['pair'][:B], E=H // 2, z_out=jemb)
+        ops.embed_fwd(self.tables.weight, self.tables.row_offset, b['pair'][:B], E=H // 2, z_out=jemb,
+                      oor_count=self._oor)
         self._item_bias(j, b['dib4'])
         self._fcn(b, jemb, 'j', B, keep=False)
         xj = torch.zeros(B, 1, dtype=torch.float32, device=sess.device)
@@ -322,7 +337,9 @@ class DIN(object):
         ops.copy2d(b['y_out'].view(B, 1), pn[:, :1])
         ops.loss_head(LOSS_SCE_LOGIT, xj.view(-1), None, y_out=b['y_out'])
         ops.copy2d(b['y_out'].view(B, 1), pn[:, 1:])
-        return np.float32(self._auc_dev.item()), pn.cpu().numpy()
+        pn_host = pn.cpu().numpy()
+        self._raise_on_bad_ids(int(self._oor.item()))
+        return np.float32(self._auc_dev.item()), pn_host
 
     def test(self, sess, uid, hist_i, sl):
         raise NotImplementedError('logits over all items (DIN/DIN.py:73-89,133-138) is outside the hot path')

@@ -34,6 +34,7 @@ class Wide_Deep:
         if len(self.cross_list) != self.cross_num or len(self.cate_list) != self.cate_num:
             raise ValueError('cross_list / cate_list do not match cross_num / cate_num')
         self.init_std = float(getattr(args, 'init_std', 0.01))
+        self.strict_ids = bool(getattr(args, 'strict_ids', True))
         self._built = self._ready = False
         self._bufs = {}
 
@@ -90,7 +91,12 @@ class Wide_Deep:
         self.deep_tables.init_slots('adagrad', dense_adam=False)
         self.deep_dense.init_slots('adagrad')
         self.tower = Tower(self.deep_dense, 'deep_net/deep_hidden', len(self.hidden_layers))
-        self._loss_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        # loss + out-of-range-id counter, read back together (tf.nn.embedding_lookup raises on such an id on the
+        # CPU, Wide_Deep/Wide_Deep.py:51,57,74; here the step runs and run() raises afterwards)
+        self._scalars = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._loss_dev = self._scalars[:1]
+        self._oor = self._scalars[1:].view(torch.int32)
+        self.wide_front.oor_count = self.deep_front.oor_count = self._oor
         rng = np.random.Generator(np.random.PCG64(seed))
         init = OrderedDict((k, truncated_normal(rng, s, self.init_std)) for k, s in self.variable_shapes().items())
         if params:
@@ -249,9 +255,18 @@ class Wide_Deep:
         if idx.shape[0] == 0:
             raise ValueError('empty batch')
         if is_train:
-            return np.float32(self.train_step(widx, idx, xc, yy).item())
-        y_out = self.predict_step(widx, idx, xc)
-        return np.asarray(yy.cpu().numpy(), dtype=np.float32), torch.round(y_out).cpu().numpy()
+            self.train_step(widx, idx, xc, yy)
+            host = self._scalars.cpu()
+            self._raise_on_bad_ids(int(host[1:].view(torch.int32)[0]))
+            return np.float32(host[0].item())
+        pred = torch.round(self.predict_step(widx, idx, xc)).cpu().numpy()
+        self._raise_on_bad_ids(int(self._oor.item()))
+        return np.asarray(yy.cpu().numpy(), dtype=np.float32), pred
+
+    def _raise_on_bad_ids(self, n):
+        if n and self.strict_ids:
+            self._oor.zero_()
+            raise IndexError('%d lookup(s) with an id outside its table in this batch (read as zero rows, no update)' % n)
 
     def predict_proba(self, session, X_cross, X_cate, X_cont):
         self._ensure_initialized(session)

@@ -45,3 +45,59 @@ def rel_err(a, b, floor=1e-30):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + floor))
+
+
+def elem_err(a, b, atol_scale=0.1):
+    """Element-wise companion of rel_err: max over elements of |a-b| / (|b| + atol_scale * max|b|).
+    An element much smaller than the tensor's largest is still held to a relative bound (against
+    atol_scale * max|b| at worst) instead of disappearing under the max-norm."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if b.size == 0:
+        return 0.0
+    den = np.abs(b) + atol_scale * np.max(np.abs(b)) + 1e-300
+    return float(np.max(np.abs(a - b) / den))
+
+
+def assert_close(a, b, tol, name='', elem_tol=None, atol_scale=0.1):
+    """Both bars: max-norm relative error < tol, and element-wise |a-b| < elem_tol * (|b| + atol_scale*max|b|)
+    (elem_tol defaults to 10 * tol: with atol_scale = 0.1 the element-wise bar is never looser than the
+    max-norm one at the small elements and holds every element above 10 % of the maximum to ~tol * 10)."""
+    r = rel_err(a, b)
+    assert r < tol, '%s: max-norm rel err %.3g >= %.3g' % (name, r, tol)
+    e = elem_err(a, b, atol_scale)
+    et = 10 * tol if elem_tol is None else elem_tol
+    assert e < et, '%s: element-wise err %.3g >= %.3g' % (name, e, et)
+
+
+def deepfm_masks(cfg, B, seed, N=None):
+    """Keep masks of one DeepFM training step from the counter hash the kernels use (streams 1, 2, 10+i)."""
+    import torch
+    N = cfg.cate_num if N is None else N
+    E = cfg.embed_size
+    masks = {'fm_first': O.keep_mask(seed, 1, B * N, 1 - cfg.dropout_fm).reshape(B, N),
+             'fm_second': O.keep_mask(seed, 2, B * E, 1 - cfg.dropout_fm).reshape(B, E)}
+    for i, L in enumerate(cfg.deep_layers):
+        masks['deep_%d' % i] = O.keep_mask(seed, 10 + i, B * L, 1 - cfg.dropout_deep).reshape(B, L)
+    return {k: torch.as_tensor(v) for k, v in masks.items()}
+
+
+def sync_oracle_from_gpu(orc, m):
+    """Teacher forcing for multi-step checks: copy the GPU model's weights, Adam/Adagrad slots and step count into
+    the oracle, so that the next step is compared from identical state.  Free-running trajectories of a relu network
+    separate chaotically (a 1e-7 weight difference flips a relu decision and moves a gradient column by per cents),
+    which says nothing about the arithmetic of a step."""
+    import torch
+    for k, v in m.get_params().items():
+        orc.P[k] = torch.as_tensor(v).to(orc.dtype)
+    opt = orc.opt
+    slots = [('m', 'slot0'), ('v', 'slot1')] if hasattr(opt, 'm') else [('acc', 'slot0')] if hasattr(opt, 'acc') else []
+    for attr, slot in slots:
+        dst = getattr(opt, attr)
+        for k in m.dense.shapes:
+            dst[k] = m.dense._view(getattr(m.dense, slot), k).cpu().to(orc.dtype)
+        for f in range(m.cate_num):
+            dst['embedding/embed_cate_w_%d' % f] = m.tables.table(f, getattr(m.tables, slot)).cpu().to(orc.dtype)
+    if hasattr(opt, 't'):
+        opt.t = m.global_step
+    orc.global_step = m.global_step

@@ -1,0 +1,185 @@
+"""Model-level parity at the BASELINE configurations that the small-shape suites do not reach:
+  c1  DeepFM exactly as the reference's CPU case: reference-exact (R) embedding block, B = 1024,
+      26 categorical fields of 101 values + 13 continuous, E = 8, default 256-128-64-32 tower
+      (DeepFM/DeepFM.py:42-100, DeepFM/main.py:48-59), TF-1.x Adam;
+  c3  the DCN *model* at its benchmark layer sizes: 6 cross layers, 1024x3 tower, E = 64 (DCN/DCN.py:56-89);
+  the optimizer bench.py times: row-wise ("lazy") Adam on batches that change every step, dropout on,
+      against the oracle's independent LazyAdamTF1.
+Tolerance: 1e-5 relative (max-norm) and the element-wise bar of helpers.assert_close, unless a line says why not."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctr_oracle as O
+from tests.helpers import assert_close, deepfm_masks, no_dropout, rel_err, sync_oracle_from_gpu
+from tests.test_gpu_models import _build
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _step_and_compare(sess, m, orc, batch, masks=None, tol=2e-6, graphed=None):
+    """One training step from identical state (helpers.sync_oracle_from_gpu): loss within 1e-5, and every weight
+    within `tol` absolute of the float64 oracle's step.  Why absolute: Adam moves a weight by
+    lr_t * m / (sqrt(v) + eps) with eps = 1e-8; at these gradient magnitudes (1e-9 .. 1e-4) many elements sit in
+    the eps-dominated range, where a gradient error dg (held to 1e-5 of the tensor's largest by the gradient
+    checks) moves the step by up to lr_t * 0.1 / eps * dg ~ 3e3 * dg - for any fp32 arithmetic.  2e-6 is under
+    1 % of one Adam step (lr_t >= 3e-4)."""
+    Xc, Xf, y = batch
+    sync_oracle_from_gpu(orc, m)
+    l_o = orc.run(Xc, Xf, y, True, masks)
+    if graphed is None:
+        l_g = float(m.run(sess, Xc, Xf, y, True))
+    else:
+        l_g = float((m.train_step_graphed if graphed else m.train_step)(*m._upload(Xc, Xf, y)).item())
+    assert abs(float(l_o) - l_g) < 1e-5 * max(1.0, abs(float(l_o)))
+    for k, v in m.get_params().items():
+        d = float(np.max(np.abs(v - orc.P[k].numpy())))
+        assert d < tol, '%s: |gpu - oracle| = %.3g after one step from identical state' % (k, d)
+
+
+def _c1_cfg():
+    cfg = O.default_cfg('DeepFM', embed_size=8, mode='R')          # flag defaults of DeepFM/main.py:48-59
+    cfg.cate_num, cfg.cont_num, cfg.cate_list = 26, 13, [101] * 26
+    cfg.adam_mode = 'tf1'
+    return cfg
+
+
+def _c1_batch(seed=20240601, B=1024):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    Xc = rng.integers(0, 101, (B, 26)).astype(np.int64)
+    Xf = rng.standard_normal((B, 13)).astype(np.float32).astype(np.float64)
+    y = (rng.random(B) < 0.25).astype(np.int64)
+    return Xc, Xf, y
+
+
+def test_c1_deepfm_rmode_b1024_39fields_e8(sess):
+    """BASELINE configs[0] on the GPU: forward, loss, every gradient and three TF-1.x Adam steps."""
+    cfg = no_dropout(_c1_cfg())
+    P = O.init_params('DeepFM', cfg, seed=1, std=0.01)             # truncated normal 0.01, weights and biases
+    Xc, Xf, y = _c1_batch()
+    orc = O.OracleModel('DeepFM', cfg, P, dtype=torch.float64)
+    m = _build(sess, 'DeepFM', cfg, P)
+    assert m.N == 2626 and m.total_size == 2626 * 8 + 13
+    out = orc.forward(Xc, Xf)
+    assert_close(m.predict_proba(sess, Xc, Xf), out.y_out.numpy(), TOL, 'y_out')
+    # the dense Z the reference materialises: copies of W_f[1] and zeros, bit for bit
+    idx, xc, yy = m._upload(Xc, Xf, y)
+    bufs = m._buffers(1024)
+    z_gpu = bufs['x0'][:, :2626 * 8].cpu().numpy().reshape(1024, 2626, 8)
+    z_ref = out.Z.to(torch.float32).numpy()
+    assert np.array_equal(z_gpu, z_ref)
+    loss_ref, g_ref, _ = orc.loss_and_grads(Xc, Xf, y)
+    loss_gpu = m.run(sess, Xc, Xf, y, True)
+    assert abs(float(loss_gpu) - float(loss_ref)) < TOL * max(1.0, abs(float(loss_ref)))
+    for k, v in m.get_grads().items():
+        assert_close(v, g_ref[k].numpy(), TOL, k)
+    # only row 1 of every table receives a gradient (DeepFM/DeepFM.py:49-52)
+    for f in range(26):
+        g = m.get_grads()['embedding/embed_cate_w_%d' % f]
+        assert np.all(g[0] == 0) and np.all(g[2:] == 0) and np.any(g[1] != 0)
+    orc.run(Xc, Xf, y, True)
+    for k, v in m.get_params().items():
+        assert float(np.max(np.abs(v - orc.P[k].numpy()))) < 2e-6, k
+    for s in range(3):                                   # three more steps, new batches, the last two graph replays
+        _step_and_compare(sess, m, orc, _c1_batch(20240601 + 1 + s))
+    assert m.global_step == 4
+
+
+def test_c1_deepfm_rmode_reference_dropout_rates(sess):
+    """Same configuration in training mode at the reference's dropout rates (0.5 / 0.2), the oracle fed the masks of
+    the shared counter hash."""
+    cfg = _c1_cfg()
+    P = O.init_params('DeepFM', cfg, seed=2, std=0.01)
+    Xc, Xf, y = _c1_batch(7)
+    m = _build(sess, 'DeepFM', cfg, P)
+    orc = O.OracleModel('DeepFM', cfg, P, dtype=torch.float64)
+    masks = deepfm_masks(cfg, 1024, sess.seed * 1000003 + 0, N=2626)
+    loss_ref, g_ref, _ = orc.loss_and_grads(Xc, Xf, y, masks)
+    loss_gpu = m.run(sess, Xc, Xf, y, True)
+    assert abs(float(loss_gpu) - float(loss_ref)) < TOL
+    for k, v in m.get_grads().items():
+        assert_close(v, g_ref[k].numpy(), TOL, k)
+
+
+def test_c3_dcn_model_6_cross_1024x3_e64(sess):
+    """The DCN model assembled at BASELINE configs[2]'s layer sizes (the kernels are checked at these shapes in
+    test_gpu_kernels / test_gpu_full_size; this is the whole graph): standard lookup, D = 26*64 + 13 = 1677."""
+    cfg = no_dropout(O.default_cfg('DCN', embed_size=64, mode='S'))
+    cfg.cross_layer_num, cfg.deep_layers = 6, [1024, 1024, 1024]
+    rng = np.random.default_rng(3)
+    cfg.cate_list = [int(v) for v in rng.integers(3, 300, 26)]
+    cfg.cate_num, cfg.cont_num = 26, 13
+    cfg.adam_mode = 'tf1'
+    P = O.init_params('DCN', cfg, seed=4, std=0.03)
+    B = 512
+    Xc = np.stack([rng.integers(0, v, B) for v in cfg.cate_list], 1).astype(np.int64)
+    Xc[0, 0], Xc[1, 5] = cfg.cate_list[0] + 2, -3                  # out-of-range ids: zero rows, no update
+    Xf = rng.standard_normal((B, 13))
+    y = rng.integers(0, 2, B)
+    orc = O.OracleModel('DCN', cfg, P, dtype=torch.float64)
+    m = _build(sess, 'DCN', cfg, P)
+    assert_close(m.predict_proba(sess, Xc, Xf), orc.forward(Xc, Xf).y_out.numpy(), TOL, 'y_out')
+    loss_ref, g_ref, _ = orc.loss_and_grads(Xc, Xf, y)
+    loss_gpu = m.run(sess, Xc, Xf, y, True)
+    assert abs(float(loss_gpu) - float(loss_ref)) < TOL * max(1.0, abs(float(loss_ref)))
+    for k, v in m.get_grads().items():
+        assert_close(v, g_ref[k].numpy(), TOL, k)
+    orc.run(Xc, Xf, y, True)
+    for k, v in m.get_params().items():
+        assert float(np.max(np.abs(v - orc.P[k].numpy()))) < 2e-6, k
+    for s in range(3):
+        Xc2 = np.stack([rng.integers(0, v, B) for v in cfg.cate_list], 1).astype(np.int64)
+        _step_and_compare(sess, m, orc, (Xc2, rng.standard_normal((B, 13)), rng.integers(0, 2, B)))
+    assert m.global_step == 4
+
+
+def _criteo_like(B, seed):
+    cfg = O.default_cfg('DeepFM', embed_size=16, mode='S')         # reference dropout rates stay on
+    rng = np.random.default_rng(11)
+    cfg.cate_list = [int(v) for v in rng.integers(40, 4000, 26)]
+    cfg.cate_num, cfg.cont_num = 26, 13
+    cfg.adam_mode = 'lazy'
+    cfg.decay_steps = 2                                            # the staircase decay moves inside the run
+    return cfg
+
+
+def _zipf_batch(cfg, B, seed):
+    rng = np.random.default_rng(seed)
+    # skewed ids: a few rows are hit in every batch, most rows in none or one (rows keep being frozen and thawed)
+    Xc = np.stack([np.minimum((rng.pareto(1.05, B)).astype(np.int64), v - 1) for v in cfg.cate_list], 1)
+    Xc[rng.integers(0, B), rng.integers(0, 26)] = -1
+    return Xc, rng.standard_normal((B, 13)), rng.integers(0, 2, B)
+
+
+@pytest.mark.parametrize('graphed', [False, True])
+def test_lazy_adam_on_changing_batches_matches_oracle(sess, graphed):
+    """The configuration bench.py times - S semantics, row-wise Adam on the looked-up rows, dropout on - for six
+    steps on six different batches against OracleModel with LazyAdamTF1, each step from identical state.  Rows no
+    batch looked up keep their initial bits and zero slots; `graphed` runs steps 2.. from the captured HIP graph
+    (run()'s path for B <= 16384)."""
+    B = 384
+    cfg = _criteo_like(B, 0)
+    P = O.init_params('DeepFM', cfg, seed=6, std=0.05)
+    orc = O.OracleModel('DeepFM', cfg, P, dtype=torch.float64)
+    assert orc.lazy
+    m = _build(sess, 'DeepFM', cfg, P)
+    touched = [np.zeros(v, dtype=bool) for v in cfg.cate_list]
+    for step in range(6):
+        Xc, Xf, y = _zipf_batch(cfg, B, 100 + step)
+        masks = deepfm_masks(cfg, B, sess.seed * 1000003 + step)
+        _step_and_compare(sess, m, orc, (Xc, Xf, y), masks, graphed=graphed)
+        for f, v in enumerate(cfg.cate_list):
+            col = Xc[:, f]
+            touched[f][col[(col >= 0) & (col < v)]] = True
+    assert m.global_step == 6
+    P_gpu = m.get_params()
+    s0 = m.tables.slot0.cpu().numpy()
+    off = m.tables.offsets_host
+    for f, v in enumerate(cfg.cate_list):
+        k = 'embedding/embed_cate_w_%d' % f
+        cold = ~touched[f]
+        assert cold.any() and touched[f].any()
+        assert np.array_equal(P_gpu[k][cold], np.asarray(P[k], dtype=np.float32)[cold]), k
+        blk = s0[off[f]:off[f + 1]]
+        assert np.all(blk[cold] == 0) and np.any(blk[touched[f]] != 0)

@@ -300,3 +300,24 @@ def test_reference_default_architecture_matches_oracle(sess, variant):
         assert abs(float(l_o) - float(l_g)) < 1e-5
     for k, v in m.get_params().items():
         assert rel_err(v, orc.P[k].numpy()) < 1e-4, k
+
+
+def test_out_of_range_ids_are_counted_and_optionally_rejected(sess):
+    """Standard lookup: an id outside [0, V_f) reads a zero row and is counted; with strict_ids run() raises
+    IndexError after the step (the reference's one-hot block is silent, its embedding_lookup call sites raise)."""
+    cfg = no_dropout(tiny_cfg('DeepFM', 'S'))
+    P = O.init_params('DeepFM', cfg, seed=3, std=0.3)
+    Xc, Xf, y = tiny_batch(cfg, B=8)                 # two out-of-range ids
+    m = _build(sess, 'DeepFM', cfg, P)
+    m.run(sess, Xc, Xf, y, True)
+    assert m.out_of_range_lookups() == 2 and m.out_of_range_lookups() == 0
+    cfg.strict_ids = True
+    m = _build(sess, 'DeepFM', cfg, P)
+    with pytest.raises(IndexError):
+        m.run(sess, Xc, Xf, y, True)
+    Xc2, Xf2, y2 = tiny_batch(cfg, B=8, oor=False)
+    assert np.isfinite(m.run(sess, Xc2, Xf2, y2, True))
+    with pytest.raises(ValueError):                  # the one-hot block reads row 1 of every table
+        cfg_r = tiny_cfg('DeepFM', 'R')
+        cfg_r.cate_list = [3, 1, 4]
+        _build(sess, 'DeepFM', cfg_r, None)

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 def _case(dropout=0.0, std=0.3):
     cfg = O.default_cfg('Wide_Deep', embed_size=4, hidden_layers=[8, 4], dropout=dropout)
     cfg.cross_list, cfg.cate_list, cfg.cont_num = [7, 4], [3, 5, 6], 2
+    cfg.strict_ids = False                         # the out-of-range id below reads a zero row instead of raising
     P = O.wide_deep_init_params(cfg, seed=2, std=std)
     rng = np.random.default_rng(1)
     B = 16
@@ -100,3 +101,14 @@ def test_wide_deep_dropout_and_checkpoint(sess, tmp_path):
     assert l1 == l2
     for (k, a), b in zip(m.get_params().items(), m2.get_params().values()):
         assert np.array_equal(a, b), k
+
+
+def test_wide_deep_raises_on_an_id_outside_its_table(sess):
+    """tf.nn.embedding_lookup (Wide_Deep/Wide_Deep.py:51,57,74) rejects an id outside the table; so does run()."""
+    cfg, P, Xr, Xc, Xf, y = _case()
+    cfg.strict_ids = True
+    m = _build(sess, cfg, P)
+    with pytest.raises(IndexError):
+        m.run(sess, Xr, Xc, Xf, y, True)
+    Xc[0, 1] = 2
+    assert np.isfinite(m.run(sess, Xr, Xc, Xf, y, True))      # the counter was reset; a clean batch passes

@@ -235,3 +235,39 @@ def test_wide_deep_oracle_gradients_match_finite_differences():
         lm = m.loss_and_grads(Xr, Xc, Xf, y)[0]
         m.P[k][idx] = old
         assert abs((lp - lm).item() / (2 * eps) - g[k][idx].item()) < 1e-7, k
+
+
+def test_lazy_adam_freezes_unseen_rows_and_equals_dense_adam_on_rows_seen_every_step():
+    """LazyAdamTF1: a row looked up at every step follows AdamTF1 exactly; a row never looked up keeps weight,
+    m and v; a row seen at steps 1 and 3 only skips step 2 altogether (TF-1.x Adam would decay m, v and move it)."""
+    import math
+    from collections import OrderedDict
+    torch.manual_seed(0)
+    W = OrderedDict(t=torch.randn(4, 3, dtype=torch.float64), d=torch.randn(5, dtype=torch.float64))
+    P1 = OrderedDict((k, v.clone()) for k, v in W.items())
+    P2 = OrderedDict((k, v.clone()) for k, v in W.items())
+    lazy, dense = O.LazyAdamTF1(P1), O.AdamTF1(P2)
+    seen = [torch.tensor([True, False, True, False]), torch.tensor([True, False, False, False]),
+            torch.tensor([True, False, True, False])]
+    gs = []
+    for s in seen:
+        g = OrderedDict(t=torch.randn(4, 3, dtype=torch.float64) * s.view(-1, 1), d=torch.randn(5, dtype=torch.float64))
+        gs.append(g['t'][2].clone())
+        lazy.apply(P1, g, 0.01, rows={'t': s})
+        dense.apply(P2, g, 0.01)
+    assert lazy.t == 3
+    assert torch.equal(P1['d'], P2['d'])                       # dense variable: identical
+    assert torch.equal(P1['t'][0], P2['t'][0])                 # seen every step: identical
+    assert torch.equal(P1['t'][1], W['t'][1]) and torch.equal(P1['t'][3], W['t'][3])
+    assert torch.all(lazy.m['t'][1] == 0) and torch.all(lazy.v['t'][1] == 0)
+    assert not torch.allclose(P1['t'][2], P2['t'][2])
+    # row 2 by hand: two updates, bias correction from the GLOBAL update counts 1 and 3
+    m = torch.zeros(3, dtype=torch.float64)
+    v = torch.zeros(3, dtype=torch.float64)
+    w = W['t'][2].clone()
+    for t in (1, 3):
+        g = gs[t - 1]
+        m = 0.9 * m + 0.1 * g
+        v = 0.999 * v + 0.001 * g * g
+        w = w - 0.01 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (torch.sqrt(v) + 1e-8)
+    assert torch.allclose(P1['t'][2], w, rtol=1e-14, atol=0)
