@@ -144,6 +144,17 @@ int ctr_emb_sort(const int32_t* idx, const int64_t* row_offset, int B, int F, in
                  int64_t total_rows, int rmode,
                  uint32_t* keys_out, uint32_t* src_out,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* ctr_emb_sort for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and the same result,
+ * bit for bit, as ctr_emb_sort, but the scratch is a 24 MiB array built into the library's device image (one copy
+ * per GPU, held until the process ends) instead of a caller workspace; the call allocates and frees nothing.
+ * Limit: B*F <= CTR_EMB_SORT_STATIC_MAX_ITEMS, larger inputs are rejected with CTR_EINVAL.  All calls on one GPU
+ * share that GPU's array: calls that overlap in time on one GPU (different streams) race; calls on one stream,
+ * or on different GPUs, do not.  The first call on a GPU resolves the array's address and must not come inside a
+ * stream capture. */
+#define CTR_EMB_SORT_STATIC_MAX_ITEMS 2097152
+int ctr_emb_sort_static(const int32_t* idx, const int64_t* row_offset, int B, int F, int N,
+                        int64_t total_rows, int rmode, uint32_t* keys_out, uint32_t* src_out, void* stream);
 /* Plain stable radix sort of (key, value) uint32 pairs on keys < 2^key_bits. */
 int ctr_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, int64_t n, int key_bits,
                    uint32_t* keys_out, uint32_t* vals_out,

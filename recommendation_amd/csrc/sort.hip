@@ -4,6 +4,7 @@
 // Stability inside a tile comes from wave-level peer masks (ballots over the digit bits)
 // plus per-wave running digit counters in LDS, so the result is bitwise reproducible.
 #include "common.h"
+#include <mutex>
 
 namespace ctr {
 
@@ -364,6 +365,53 @@ extern "C" int ctr_emb_sort(const int32_t* idx, const int64_t* row_offset, int B
   run_passes(ka, va, kb, vb, n, passes, w, st);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// The pair sort with its scratch in a file-scope device array instead of a caller-provided workspace, for
+// callers that cannot allocate device memory.  Each GPU holds its own copy of the array (at its own address)
+// from the moment the library is loaded on it until the process ends.
+// ---------------------------------------------------------------------------------------
+constexpr size_t SORT_STATIC_BYTES = (size_t)24 << 20;
+static __device__ __align__(256) unsigned char sort_static_scratch[SORT_STATIC_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+void* g_sort_scratch_ptr[MAX_DEVICES];      // device address of sort_static_scratch on each device, once resolved
+std::mutex g_sort_scratch_mutex;
+}  // namespace
+
+// Device address of the current device's copy of the array (resolved once per device, with that device current).
+static int sort_static_ptr(void** out) {
+  int dev = -1;
+  CTR_HIP(hipGetDevice(&dev));
+  CTR_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "ctr_emb_sort_static: device ordinal %d not supported", dev);
+  std::lock_guard<std::mutex> lock(g_sort_scratch_mutex);
+  if (!g_sort_scratch_ptr[dev]) {
+    void* p = nullptr;
+    CTR_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(sort_static_scratch)));
+    CTR_REQUIRE(p && ((uintptr_t)p % 256) == 0, "ctr_emb_sort_static: scratch symbol did not resolve");
+    g_sort_scratch_ptr[dev] = p;
+  }
+  *out = g_sort_scratch_ptr[dev];
+  return CTR_OK;
+}
+
+extern "C" int ctr_emb_sort_static(const int32_t* idx, const int64_t* row_offset, int B, int F, int N,
+                                   int64_t total_rows, int rmode, uint32_t* keys_out, uint32_t* src_out,
+                                   void* stream) {
+  const int64_t n = (int64_t)B * F;
+  CTR_REQUIRE(B >= 0 && F >= 0, "ctr_emb_sort_static: bad size");
+  CTR_REQUIRE(n <= CTR_EMB_SORT_STATIC_MAX_ITEMS && sort_ws_bytes(n) <= SORT_STATIC_BYTES,
+              "ctr_emb_sort_static: B*F = %lld exceeds the built-in scratch (at most %d lookups per call); "
+              "use ctr_emb_sort with a workspace", (long long)n, CTR_EMB_SORT_STATIC_MAX_ITEMS);
+  void* scratch = nullptr;
+  const int rc = sort_static_ptr(&scratch);
+  if (rc != CTR_OK) return rc;
+  // every word of the scratch that a pass reads (tile histograms, digit totals, ping-pong pairs) is written
+  // earlier in the same call, so nothing has to be cleared between calls
+  return ctr_emb_sort(idx, row_offset, B, F, N, total_rows, rmode, keys_out, src_out, scratch, SORT_STATIC_BYTES,
+                      stream);
 }
 
 extern "C" int ctr_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, int64_t n, int key_bits,
