@@ -32,6 +32,24 @@ def truncated_normal(rng, shape, std=0.01):
     return (x * std).astype(np.float32)
 
 
+class BufferCache(OrderedDict):
+    """Per-shape scratch buffers of a model, least recently used first, at most `maxsize` shapes: a caller whose
+    batch size (or DIN history length) changes all the time re-allocates instead of accumulating device memory."""
+
+    def __init__(self, maxsize=8):
+        super().__init__()
+        self.maxsize = maxsize
+
+    def lookup(self, key, make):
+        if key in self:
+            self.move_to_end(key)
+            return self[key]
+        while len(self) >= self.maxsize:
+            self.popitem(last=False)
+        self[key] = make()
+        return self[key]
+
+
 class DenseParams:
     """All dense variables of a model in ONE flat fp32 buffer (+ flat grad and optimizer
     slots), so the optimizer is a single launch and a data-parallel all-reduce is one call."""

@@ -60,11 +60,16 @@ def get_checkpoint_state(directory):
     return full if os.path.exists(full + '.safetensors') else None
 
 
-# Captured graphs are never destroyed: with this runtime, destroying the graphs of models that went out of use made
-# the first launch of a graph captured later segfault inside hipGraphLaunch (seen when one process captured several
-# models in turn).  A graph holds no buffers of its own here (every buffer it points at is owned by its model or
-# the session), so what stays is a few hundred launch records per captured batch size.
+# Captured graphs are kept until the process ends.  What is known: a graph owns no memory here (_capture asserts that
+# nothing is allocated while capturing; every buffer it points at belongs to its model or the session), and a
+# torch-free HIP program with the same fork/join capture survives capture -> destroy -> launch in every order
+# (tools/repro/graph_lifetime.cpp).  Still, with the graphs of collected models destroyed, 1 run in 11 of the GPU test
+# suite died inside hipGraphLaunch at the first replay of a newly captured graph; with the graphs kept, none did.
+# So graph executables are not destroyed, and their number is bounded instead: a model captures at most
+# GRAPH_SIZES_PER_MODEL batch sizes per direction and runs other sizes eagerly.
 _LIVE_GRAPHS = []
+GRAPH_SIZES_PER_MODEL = 4
+BUFFER_SIZES_PER_MODEL = 8      # per-batch-size activation buffers kept besides the captured sizes (LRU)
 
 
 def _capture(graph, fn):
@@ -84,7 +89,7 @@ def _capture(graph, fn):
             grew = torch.cuda.memory_stats()['allocation.all.allocated'] - allocs0
         if grew:
             raise RuntimeError('%d device allocation(s) happened inside a graph capture' % grew)
-        if os.environ.get('CTR_GRAPH_KEEP', '1') != '0':
+        if os.environ.get('CTR_GRAPH_KEEP', '1') != '0':     # '0': experiments on graph destruction only
             _LIVE_GRAPHS.append(graph)
         return out
     finally:
@@ -136,10 +141,10 @@ class CTRModel:
         self.global_step = 0
         self._built = False
         self._ready = False
-        self._bufs = {}
+        self._bufs = OrderedDict()       # per-batch-size buffers, least recently used first
         self._graphs = {}
         self._train_graphs = {}
-        self._stage = {}                 # pinned staging buffers of _upload, by (feed, shape)
+        self._stage = OrderedDict()      # pinned staging buffers of _upload, by (feed, shape), LRU
         self._indirect = None            # (step word, lr word) on the device while a training graph is captured
 
     # ---- graph definition -----------------------------------------------------------------
@@ -294,6 +299,10 @@ class CTRModel:
         stage = self._stage.get(key)
         if stage is None:
             stage = self._stage[key] = torch.empty(src.shape, dtype=dtype, pin_memory=True)
+            while len(self._stage) > 3 * BUFFER_SIZES_PER_MODEL:      # three feeds per batch size
+                self._stage.popitem(last=False)
+        else:
+            self._stage.move_to_end(key)
         stage.copy_(src)
         return stage.to(self.session.device)
 
@@ -311,7 +320,14 @@ class CTRModel:
         return idx, xc, yy
 
     def _buffers(self, B):
-        if B not in self._bufs:
+        if B in self._bufs:
+            self._bufs.move_to_end(B)
+        else:
+            # a caller with ever-changing batch sizes must not accumulate buffers: drop the least recently used
+            # size that no captured graph points at
+            free = [b for b in self._bufs if b not in self._graphs and b not in self._train_graphs]
+            while len(free) >= BUFFER_SIZES_PER_MODEL:
+                del self._bufs[free.pop(0)]
             dev = self.session.device
             bufs = dict(logit=torch.zeros(B, dtype=torch.float32, device=dev),
                         y_out=torch.zeros(B, dtype=torch.float32, device=dev),
@@ -352,10 +368,10 @@ class CTRModel:
         the dropout streams' step count and the (decayed, bias-corrected) step size - lives in two device words
         the kernels read (ctr_dropout_t.seed_add, ctr_opt_t.lr_dev); the host writes them before each replay.
         Same arithmetic and same dropout masks as train_step.  Single-process only."""
-        if self.world > 1:
-            return self.train_step(idx, xc, yy)
         B = idx.shape[0]
         entry = self._train_graphs.get(B)
+        if self.world > 1 or (entry is None and len(self._train_graphs) >= GRAPH_SIZES_PER_MODEL):
+            return self.train_step(idx, xc, yy)
         if entry is None:
             # first step at this batch size: an ordinary step (buffers and the workspace reach their final size),
             # then the capture - which records launches without running them - for every later step
@@ -398,10 +414,10 @@ class CTRModel:
         static buffers; the result tensor is the graph's static output (read it before the next call).
         Single-process only (a collective cannot be captured here); weights are read in place, so training
         steps between calls are seen by the next replay."""
-        if self.world > 1:
-            return self.predict_step(idx, xc)
         B = idx.shape[0]
         entry = self._graphs.get(B)
+        if self.world > 1 or (entry is None and len(self._graphs) >= GRAPH_SIZES_PER_MODEL):
+            return self.predict_step(idx, xc)
         if entry is None:
             s_idx, s_xc = idx.clone(), xc.clone()
             side = torch.cuda.Stream(self.session.device)

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from recommendation_amd import ops
-from recommendation_amd.engine import DenseParams, EmbedFront, EmbeddingTables, adam_lr_t
+from recommendation_amd.engine import BufferCache, DenseParams, EmbedFront, EmbeddingTables, adam_lr_t
 from recommendation_amd.model_base import Saver, truncated_normal
 from recommendation_amd._lib import LOSS_SIGMOID_SCE_PROB, OPT_ADAM
 
@@ -32,7 +32,7 @@ class NCF:
         self.decay_rate = float(args.decay_rate)
         self.init_std = float(getattr(args, 'init_std', 0.01))
         self._built = self._ready = False
-        self._bufs = {}
+        self._bufs = BufferCache()
 
     def build(self):
         E = self.embed_size
@@ -134,15 +134,16 @@ class NCF:
 
     # ---- step ------------------------------------------------------------------------------
     def _buffers(self, B):
-        if B not in self._bufs:
-            dev, E = self.session.device, self.embed_size
-            z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
-            self._bufs[B] = dict(a=z(B, 4 * E), da=z(B, 4 * E), mlp_in=z(B, 2 * E), dmlp_in=z(B, 2 * E),
-                                 h1=z(B, 2 * E), h2=z(B, E), concat=z(B, E + E // 2), dconcat=z(B, E + E // 2),
-                                 g1=z(B, 2 * E), g2=z(B, E), logit=z(B), dlogit=z(B), y_out=z(B),
-                                 keys=torch.zeros(2 * B, dtype=torch.int32, device=dev),
-                                 src=torch.zeros(2 * B, dtype=torch.int32, device=dev))
-        return self._bufs[B]
+        return self._bufs.lookup(B, lambda: self._make_buffers(B))
+
+    def _make_buffers(self, B):
+        dev, E = self.session.device, self.embed_size
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        return dict(a=z(B, 4 * E), da=z(B, 4 * E), mlp_in=z(B, 2 * E), dmlp_in=z(B, 2 * E),
+                             h1=z(B, 2 * E), h2=z(B, E), concat=z(B, E + E // 2), dconcat=z(B, E + E // 2),
+                             g1=z(B, 2 * E), g2=z(B, E), logit=z(B), dlogit=z(B), y_out=z(B),
+                             keys=torch.zeros(2 * B, dtype=torch.int32, device=dev),
+                             src=torch.zeros(2 * B, dtype=torch.int32, device=dev))
 
     def _drop(self, stream_id, train):
         if not train:

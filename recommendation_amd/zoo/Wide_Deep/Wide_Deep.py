@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from recommendation_amd import ops
-from recommendation_amd.engine import DenseParams, EmbedFront, EmbeddingTables, Tower, round_up
+from recommendation_amd.engine import BufferCache, DenseParams, EmbedFront, EmbeddingTables, Tower, round_up
 from recommendation_amd.model_base import Saver, truncated_normal
 from recommendation_amd._lib import LOSS_SIGMOID_SCE_PROB, OPT_ADAGRAD, OPT_FTRL
 
@@ -36,7 +36,7 @@ class Wide_Deep:
         self.init_std = float(getattr(args, 'init_std', 0.01))
         self.strict_ids = bool(getattr(args, 'strict_ids', True))
         self._built = self._ready = False
-        self._bufs = {}
+        self._bufs = BufferCache()
 
     # ---- graph definition ------------------------------------------------------------------
     def build(self):
@@ -165,17 +165,18 @@ class Wide_Deep:
         return self.learning_rate * (self.decay_rate ** (self.global_step // self.decay_steps))
 
     def _buffers(self, B):
-        if B not in self._bufs:
-            dev, E, Ls = self.session.device, self.embed_size, self.hidden_layers
-            z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
-            i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
-            self._bufs[B] = dict(
-                zw=z(B, self.Fw * E), dzw=z(B, self.Fw * E), x0=z(B, round_up(self.deep_in, 4)),
-                dx0=z(B, round_up(self.deep_in, 4)), acts=[z(B, L) for L in Ls], gbufs=[z(B, L) for L in Ls[:-1]],
-                dlast=z(B, Ls[-1]), wide_out=z(B), logit=z(B), dlogit=z(B), y_out=z(B),
-                wkeys=i32(B * self.Fw), wsrc=i32(B * self.Fw), dkeys=i32(B * self.cate_num),
-                dsrc=i32(B * self.cate_num))
-        return self._bufs[B]
+        return self._bufs.lookup(B, lambda: self._make_buffers(B))
+
+    def _make_buffers(self, B):
+        dev, E, Ls = self.session.device, self.embed_size, self.hidden_layers
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
+        return dict(
+            zw=z(B, self.Fw * E), dzw=z(B, self.Fw * E), x0=z(B, round_up(self.deep_in, 4)),
+            dx0=z(B, round_up(self.deep_in, 4)), acts=[z(B, L) for L in Ls], gbufs=[z(B, L) for L in Ls[:-1]],
+            dlast=z(B, Ls[-1]), wide_out=z(B), logit=z(B), dlogit=z(B), y_out=z(B),
+            wkeys=i32(B * self.Fw), wsrc=i32(B * self.Fw), dkeys=i32(B * self.cate_num),
+            dsrc=i32(B * self.cate_num))
 
     def _drop(self, stream_id, train):
         if not train:

@@ -9,6 +9,9 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    if os.environ.get('CTR_SEGV_TRACE'):      # debug aid: native stack on SIGSEGV (run with -p no:faulthandler)
+        import ctypes
+        ctypes.CDLL(os.path.join(ROOT, 'tools', 'repro', 'libsegvtrace.so')).segv_trace_install()
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 

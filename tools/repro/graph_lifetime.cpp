@@ -5,6 +5,8 @@
 //   graph_lifetime destroy   every graph exec is destroyed (then a device sync, as torch's destructor does)
 //   graph_lifetime nosync    destroyed without the sync
 //   graph_lifetime keep      all graph execs are kept to the end
+//   graph_lifetime late      graph r-1 is destroyed AFTER graph r was captured and instantiated, BEFORE r's first
+//                            launch (the order a garbage collector produces); latesync adds the device sync
 // Prints one line per round; exit code 0 when every replay produced the expected sums.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -63,6 +65,13 @@ int main(int argc, char** argv) {
     CK(hipMemsetAsync(a, 0, n * 4, run)); CK(hipMemsetAsync(b, 0, n * 4, run));
     CK(hipStreamSynchronize(run));
     if (capture(cap, a, b, word, n, main_k, side_k, &c)) return 2;
+    if (!strncmp(mode, "late", 4) && !live.empty()) {
+      Captured& o = live.back();
+      CK(hipGraphExecDestroy(o.exec));
+      CK(hipEventDestroy(o.fork)); CK(hipEventDestroy(o.join)); CK(hipStreamDestroy(o.side));
+      if (!strcmp(mode, "latesync")) CK(hipDeviceSynchronize());
+      live.pop_back();
+    }
     const int replays = 3;
     for (int i = 0; i < replays; ++i) CK(hipGraphLaunch(c.exec, run));
     float ha = -1, hb = -1;
@@ -73,7 +82,7 @@ int main(int argc, char** argv) {
     bad += !ok;
     printf("round %2d  main %2d side %2d  a=%g b=%g  %s\n", r, main_k, side_k, ha, hb, ok ? "ok" : "WRONG");
     fflush(stdout);
-    if (!strcmp(mode, "keep")) { live.push_back(c); continue; }
+    if (!strcmp(mode, "keep") || !strncmp(mode, "late", 4)) { live.push_back(c); continue; }
     CK(hipGraphExecDestroy(c.exec));
     CK(hipEventDestroy(c.fork)); CK(hipEventDestroy(c.join)); CK(hipStreamDestroy(c.side));
     if (!strcmp(mode, "destroy")) CK(hipDeviceSynchronize());
