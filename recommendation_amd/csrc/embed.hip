@@ -18,9 +18,123 @@ __device__ static inline float row_stride_sum(float x) {
   return x;
 }
 
-// DENSE: Z already sits in z_out (N = F rows per sample); only the reductions are computed.
+// x + (x of the lane that the mirror names inside this lane's row of 16): halves of 8 (0x141) or the whole row (0x140)
+constexpr int DPP_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+
+// Sum over the G consecutive lanes that hold one table row (G <= 16, aligned groups); every lane gets the total.
+template <int G>
+__device__ static inline float row_group_sum(float t) {
+  if (G >= 2) t = dpp_add<DPP_XOR1>(t);
+  if (G >= 4) t = dpp_add<DPP_XOR2>(t);
+  if (G >= 8) t = dpp_add<DPP_HALF_MIRROR>(t);     // the two quads of a half hold equal values by now
+  if (G >= 16) t = dpp_add<DPP_ROW_MIRROR>(t);
+  return t;
+}
+
+// Front end for E <= 64.  A row of 16 lanes (one DPP row) owns one sample, so a wave carries four samples and a
+// block sixteen; inside the row, G = E/4 lanes cover one table row (16 B per lane) and SLOTS = 16/G rows move per
+// step.  CH steps are issued together: first the CH ids of every lane, then the CH row loads they address, so a
+// lane keeps CH independent 16-byte loads in flight (a sample's rows do not wait for one another) and every
+// reduction of the FM terms stays inside the 16-lane row (data-parallel-path adds, no LDS, no cross-row swaps).
+// The field offsets sit in LDS.  DENSE: Z already sits in z_out (N = F rows per sample); only the reductions run.
 template <int G, bool DENSE>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(
+    const float* __restrict__ tables, const int64_t* __restrict__ row_offset,
+    const int32_t* __restrict__ idx, const float* __restrict__ x_cont,
+    const float* __restrict__ cont_w, int B, int F, int C, int E,
+    float* __restrict__ z_out, int64_t z_ld, int cont_tail,
+    float* __restrict__ first_out, int64_t first_ld, float* __restrict__ s_out,
+    float* __restrict__ second_out, int64_t second_ld, Drop d_first, Drop d_second,
+    int32_t* __restrict__ oor_count, const float* __restrict__ blk, const int64_t* __restrict__ fbase,
+    const int64_t* __restrict__ fstride) {
+  constexpr int SLOTS = 16 / G;
+  constexpr int CH = 8;
+  extern __shared__ int64_t offs_lds[];                     // [F + 1] first row of every field (gather path only)
+  const bool gathers = !DENSE && !blk && F > 0;
+  if (gathers) {
+    for (int f = threadIdx.x; f <= F; f += blockDim.x) offs_lds[f] = row_offset[f];
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  const int l16 = lane & 15;
+  const int g = l16 % G;
+  const int slot = l16 / G;
+  const int64_t b = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = b < B;
+  const int N = F + (cont_w ? C : 0);
+  float4 s = f4_zero(), q = f4_zero();
+  for (int n0 = 0; n0 < N; n0 += SLOTS * CH) {
+    int x[CH];
+    float4 z[CH];
+    if (gathers) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int n = n0 + u * SLOTS + slot;
+        x[u] = (live && n < F) ? idx[b * F + n] : -1;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int n = n0 + u * SLOTS + slot;
+      z[u] = f4_zero();
+      if (!live || n >= N) continue;
+      if (DENSE) {
+        z[u] = *reinterpret_cast<const float4*>(z_out + b * z_ld + (int64_t)n * E + g * 4);
+      } else if (n < F && blk) {   // rows already fetched by their owners, one block of columns per owner
+        z[u] = *reinterpret_cast<const float4*>(blk + fbase[n] + b * fstride[n] + g * 4);
+      } else if (n < F) {
+        const int64_t off = offs_lds[n];
+        const int64_t V = offs_lds[n + 1] - off;
+        if (x[u] >= 0 && x[u] < V) {
+          z[u] = *reinterpret_cast<const float4*>(tables + (off + x[u]) * E + g * 4);
+        } else if (oor_count && g == 0) {
+          atomicAdd(oor_count, 1);
+        }
+      } else {
+        const int c = n - F;
+        const float v = x_cont[b * C + c];
+        const float4 w = *reinterpret_cast<const float4*>(cont_w + (int64_t)c * E + g * 4);
+        z[u] = make_float4(w.x * v, w.y * v, w.z * v, w.w * v);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int n = n0 + u * SLOTS + slot;
+      const bool active = live && n < N;
+      const float4 zz = z[u];
+      if (!DENSE && z_out && active) *reinterpret_cast<float4*>(z_out + b * z_ld + (int64_t)n * E + g * 4) = zz;
+      s.x += zz.x; s.y += zz.y; s.z += zz.z; s.w += zz.w;
+      q.x += zz.x * zz.x; q.y += zz.y * zz.y; q.z += zz.z * zz.z; q.w += zz.w * zz.w;
+      if (first_out) {
+        const float t = row_group_sum<G>((zz.x + zz.y) + (zz.z + zz.w));
+        if (active && g == 0) first_out[b * first_ld + n] = t * drop_mul(d_first, (uint64_t)b * N + n);
+      }
+    }
+  }
+  if (s_out || second_out) {
+    // column sums over the row slots of the sample: lanes G apart inside the 16-lane row
+    s.x = row_stride_sum<G>(s.x); s.y = row_stride_sum<G>(s.y); s.z = row_stride_sum<G>(s.z); s.w = row_stride_sum<G>(s.w);
+    q.x = row_stride_sum<G>(q.x); q.y = row_stride_sum<G>(q.y); q.z = row_stride_sum<G>(q.z); q.w = row_stride_sum<G>(q.w);
+    if (live && slot == 0) {
+      if (s_out) *reinterpret_cast<float4*>(s_out + b * E + g * 4) = s;
+      if (second_out) {
+        const uint64_t base = (uint64_t)b * E + g * 4;
+        float* o = second_out + b * second_ld + g * 4;
+        o[0] = 0.5f * (s.x * s.x - q.x) * drop_mul(d_second, base + 0);
+        o[1] = 0.5f * (s.y * s.y - q.y) * drop_mul(d_second, base + 1);
+        o[2] = 0.5f * (s.z * s.z - q.z) * drop_mul(d_second, base + 2);
+        o[3] = 0.5f * (s.w * s.w - q.w) * drop_mul(d_second, base + 3);
+      }
+    }
+  }
+  if (!DENSE && cont_tail && z_out && live) {
+    for (int c = l16; c < C; c += 16) z_out[b * z_ld + (int64_t)N * E + c] = x_cont[b * C + c];
+  }
+}
+
+// Same front end for E = 128 and 256 (G = 32, 64 lanes per row): one wave per sample.
+template <int G, bool DENSE>
+__global__ __launch_bounds__(256) void embed_fwd_wide_kernel(
     const float* __restrict__ tables, const int64_t* __restrict__ row_offset,
     const int32_t* __restrict__ idx, const float* __restrict__ x_cont,
     const float* __restrict__ cont_w, int B, int F, int C, int E,
@@ -45,7 +159,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
     if (active && DENSE) {
       z = *reinterpret_cast<const float4*>(z_out + b * z_ld + (int64_t)n * E + g * 4);
     } else if (active) {
-      if (n < F && blk) {   // rows already fetched by their owners, one block of columns per owner
+      if (n < F && blk) {
         z = *reinterpret_cast<const float4*>(blk + fbase[n] + b * fstride[n] + g * 4);
       } else if (n < F) {
         const int x = idx[b * F + n];
@@ -68,47 +182,25 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
     q.x += z.x * z.x; q.y += z.y * z.y; q.z += z.z * z.z; q.w += z.w * z.w;
     if (first_out) {
       float t = (z.x + z.y) + (z.z + z.w);
-      if constexpr (G <= 4) {
-        if (G >= 2) t = dpp_add<DPP_XOR1>(t);
-        if (G >= 4) t = dpp_add<DPP_XOR2>(t);
-      } else {
 #pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) t += __shfl_xor(t, o);
-      }
+      for (int o = G / 2; o > 0; o >>= 1) t += __shfl_xor(t, o);
       if (active && g == 0) first_out[b * first_ld + n] = t * drop_mul(d_first, (uint64_t)b * N + n);
     }
   }
-  if constexpr (G <= 16) {
-    // Column sums over the wave's 64 / G row groups as a halving exchange: each swap leaves a lane with half
-    // as many values, summed over twice as many lanes.  Row k of 16 lanes ends with column 4g + (0, 2, 1, 3)[k]
-    // of both s and q, complete after the in-row sum.
-    float sv = row_swap_sum(half_swap_sum(s.x, s.y), half_swap_sum(s.z, s.w));
-    float qv = row_swap_sum(half_swap_sum(q.x, q.y), half_swap_sum(q.z, q.w));
-    sv = row_stride_sum<G>(sv);
-    qv = row_stride_sum<G>(qv);
-    const int row = lane >> 4, gg = lane & 15;
-    if (gg < G) {
-      const int col = gg * 4 + ((row & 1) << 1 | row >> 1);
-      if (s_out) s_out[b * E + col] = sv;
-      if (second_out)
-        second_out[b * second_ld + col] = 0.5f * (sv * sv - qv) * drop_mul(d_second, (uint64_t)b * E + col);
-    }
-  } else {
 #pragma unroll
-    for (int o = G; o < 64; o <<= 1) {
-      s.x += __shfl_xor(s.x, o); s.y += __shfl_xor(s.y, o); s.z += __shfl_xor(s.z, o); s.w += __shfl_xor(s.w, o);
-      q.x += __shfl_xor(q.x, o); q.y += __shfl_xor(q.y, o); q.z += __shfl_xor(q.z, o); q.w += __shfl_xor(q.w, o);
-    }
-    if (r == 0) {
-      if (s_out) *reinterpret_cast<float4*>(s_out + b * E + g * 4) = s;
-      if (second_out) {
-        const uint64_t base = (uint64_t)b * E + g * 4;
-        float* o = second_out + b * second_ld + g * 4;
-        o[0] = 0.5f * (s.x * s.x - q.x) * drop_mul(d_second, base + 0);
-        o[1] = 0.5f * (s.y * s.y - q.y) * drop_mul(d_second, base + 1);
-        o[2] = 0.5f * (s.z * s.z - q.z) * drop_mul(d_second, base + 2);
-        o[3] = 0.5f * (s.w * s.w - q.w) * drop_mul(d_second, base + 3);
-      }
+  for (int o = G; o < 64; o <<= 1) {
+    s.x += __shfl_xor(s.x, o); s.y += __shfl_xor(s.y, o); s.z += __shfl_xor(s.z, o); s.w += __shfl_xor(s.w, o);
+    q.x += __shfl_xor(q.x, o); q.y += __shfl_xor(q.y, o); q.z += __shfl_xor(q.z, o); q.w += __shfl_xor(q.w, o);
+  }
+  if (r == 0) {
+    if (s_out) *reinterpret_cast<float4*>(s_out + b * E + g * 4) = s;
+    if (second_out) {
+      const uint64_t base = (uint64_t)b * E + g * 4;
+      float* o = second_out + b * second_ld + g * 4;
+      o[0] = 0.5f * (s.x * s.x - q.x) * drop_mul(d_second, base + 0);
+      o[1] = 0.5f * (s.y * s.y - q.y) * drop_mul(d_second, base + 1);
+      o[2] = 0.5f * (s.z * s.z - q.z) * drop_mul(d_second, base + 2);
+      o[3] = 0.5f * (s.w * s.w - q.w) * drop_mul(d_second, base + 3);
     }
   }
   if (!DENSE && cont_tail && z_out) {
@@ -214,11 +306,17 @@ static int embed_fwd_impl(const float* tables, const int64_t* row_offset, const 
   const int N = F + (cont_w ? C : 0);
   CTR_REQUIRE(!z_out || z_ld >= (int64_t)N * E + (cont_tail ? C : 0), "ctr_embed_fwd: z_ld too small");
   if (B == 0) return CTR_OK;
+  CTR_REQUIRE(F <= 4096, "ctr_embed_fwd: at most 4096 fields");
   const Drop d1 = make_drop(drop_first), d2 = make_drop(drop_second);
-  const dim3 grid((unsigned)cdiv(B, 4)), block(256);
+  const dim3 grid((unsigned)cdiv(B, 16)), wgrid((unsigned)cdiv(B, 4)), block(256);
+  const size_t lds = (size_t)(F + 1) * sizeof(int64_t);
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(GG)                                                                                  \
-  hipLaunchKernelGGL((embed_fwd_kernel<GG, false>), grid, block, 0, st, tables, row_offset, idx, x_cont, \
+  hipLaunchKernelGGL((embed_fwd_kernel<GG, false>), grid, block, lds, st, tables, row_offset, idx, x_cont, \
+                     cont_w, B, F, C, E, z_out, z_ld, cont_tail, first_out, first_ld, s_out,       \
+                     second_out, second_ld, d1, d2, oor_count, blk, fbase, fstride)
+#define LAUNCHW(GG)                                                                                 \
+  hipLaunchKernelGGL((embed_fwd_wide_kernel<GG, false>), wgrid, block, 0, st, tables, row_offset, idx, x_cont, \
                      cont_w, B, F, C, E, z_out, z_ld, cont_tail, first_out, first_ld, s_out,       \
                      second_out, second_ld, d1, d2, oor_count, blk, fbase, fstride)
   switch (E / 4) {
@@ -227,10 +325,11 @@ static int embed_fwd_impl(const float* tables, const int64_t* row_offset, const 
     case 4: LAUNCH(4); break;
     case 8: LAUNCH(8); break;
     case 16: LAUNCH(16); break;
-    case 32: LAUNCH(32); break;
-    case 64: LAUNCH(64); break;
+    case 32: LAUNCHW(32); break;
+    case 64: LAUNCHW(64); break;
   }
 #undef LAUNCH
+#undef LAUNCHW
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
@@ -267,23 +366,23 @@ extern "C" int ctr_fm_fwd(const float* z, int64_t z_ld, int B, int N, int E, flo
   CTR_REQUIRE(z && z_ld % 4 == 0 && ((uintptr_t)z % 16) == 0 && z_ld >= (int64_t)N * E, "ctr_fm_fwd: z alignment/size");
   if (B == 0) return CTR_OK;
   const Drop d1 = make_drop(drop_first), d2 = make_drop(drop_second);
-  const dim3 grid((unsigned)cdiv(B, 4)), block(256);
+  const dim3 grid((unsigned)cdiv(B, 16)), wgrid((unsigned)cdiv(B, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   float* zz = const_cast<float*>(z);  // the DENSE instantiation only reads it
-#define LAUNCH(GG)                                                                                  \
-  hipLaunchKernelGGL((embed_fwd_kernel<GG, true>), grid, block, 0, st, (const float*)nullptr,      \
+#define LAUNCH(KERNEL, GRID, GG)                                                                    \
+  hipLaunchKernelGGL((KERNEL<GG, true>), GRID, block, 0, st, (const float*)nullptr,                 \
                      (const int64_t*)nullptr, (const int32_t*)nullptr, (const float*)nullptr,      \
                      (const float*)nullptr, B, N, 0, E, zz, z_ld, 0, first_out, first_ld, s_out,   \
                      second_out, second_ld, d1, d2, (int32_t*)nullptr, (const float*)nullptr,      \
                      (const int64_t*)nullptr, (const int64_t*)nullptr)
   switch (E / 4) {
-    case 1: LAUNCH(1); break;
-    case 2: LAUNCH(2); break;
-    case 4: LAUNCH(4); break;
-    case 8: LAUNCH(8); break;
-    case 16: LAUNCH(16); break;
-    case 32: LAUNCH(32); break;
-    case 64: LAUNCH(64); break;
+    case 1: LAUNCH(embed_fwd_kernel, grid, 1); break;
+    case 2: LAUNCH(embed_fwd_kernel, grid, 2); break;
+    case 4: LAUNCH(embed_fwd_kernel, grid, 4); break;
+    case 8: LAUNCH(embed_fwd_kernel, grid, 8); break;
+    case 16: LAUNCH(embed_fwd_kernel, grid, 16); break;
+    case 32: LAUNCH(embed_fwd_wide_kernel, wgrid, 32); break;
+    case 64: LAUNCH(embed_fwd_wide_kernel, wgrid, 64); break;
   }
 #undef LAUNCH
   CTR_LAUNCH_CHECK();

@@ -185,12 +185,19 @@ class EmbedFront:
             ops.fm_fwd(z_out, N=self.N, E=E, first_out=first_out, s_out=s_out, second_out=second_out,
                        drop_first=drop_first, drop_second=drop_second)
 
-    def backward_tables(self, idx, dz, keys, src, ws, opt, lazy):
+    def sort_pairs(self, idx, keys, src, ws):
+        """The (key, src) pair sort of the table backward; it reads only the ids, so a caller may run it early, on
+        another stream, and pass presorted=True to backward_tables."""
+        t = self.t
+        ops.emb_sort(idx, t.row_offset, N=self.N, total_rows=t.total_rows, rmode=(self.mode == 'R'),
+                     keys_out=keys, src_out=src, ws=ws)
+
+    def backward_tables(self, idx, dz, keys, src, ws, opt, lazy, presorted=False):
         """dz: [B, >= N*E] gradient with respect to Z.  Sort (key, src), segment-reduce, update."""
         t = self.t
         B, F = idx.shape
-        ops.emb_sort(idx, t.row_offset, N=self.N, total_rows=t.total_rows, rmode=(self.mode == 'R'),
-                     keys_out=keys, src_out=src, ws=ws)
+        if not presorted:
+            self.sort_pairs(idx, keys, src, ws)
         if opt.kind == OPT_ADAM and not lazy:
             t.grad.zero_()
             ops.emb_sparse_apply(keys, src, B * F, N=self.N, E=self.E, total_rows=t.total_rows, dz=dz,

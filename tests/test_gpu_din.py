@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import ctr_oracle as O
-from tests.helpers import rel_err
+from tests.helpers import assert_close, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -52,17 +52,23 @@ def test_din_train_and_eval_match_oracle(sess, H, B, T):
     loss_o, g_o, _ = orc.loss_and_grads(uij)
     loss_g = m.train(sess, uij, 0.1)
     assert abs(float(loss_g) - float(loss_o)) < 1e-5
+    gmax = max(float(g_o[k].abs().max()) for k in g_o)
     for k, v in m.get_grads().items():
         if k in g_o:      # the f3_att bias gradient is exactly 0 (softmax is shift invariant): absolute floor
             ref = g_o[k].numpy()
-            assert np.max(np.abs(v - ref)) < 5e-5 * np.max(np.abs(ref)) + 1e-8, k
+            if np.max(np.abs(ref)) < 1e-12:
+                assert np.max(np.abs(v)) < 1e-5 * gmax, k
+            else:
+                # the attention MLP's parameter gradients are fp32 sums over B*T = 60 000 rows of terms of both
+                # signs: 2e-5 there (measured 1.02e-5 on f1_att/bias at T = 200), 1e-5 everywhere else
+                assert_close(v, ref, 2e-5 if '_att/' in k else 1e-5, k)
     orc.train(uij, 0.1)
     for _ in range(2):
         lo = orc.train(uij, 0.1)
         lg = m.train(sess, uij, 0.1)
         assert abs(float(lo) - float(lg)) < 1e-5
     for k, v in m.get_params().items():
-        assert rel_err(v, orc.P[k].numpy()) < 5e-5, k
+        assert rel_err(v, orc.P[k].numpy()) < 1e-5, k          # plain SGD: no amplification of the gradient's rounding
 
 
 def test_din_padding_positions_do_not_matter(sess):

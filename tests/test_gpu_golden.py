@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.helpers import no_dropout, rel_err, tiny_cfg
+from tests.helpers import assert_close, no_dropout, rel_err, tiny_cfg
 
 pytestmark = pytest.mark.gpu
 FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*.npz')))
@@ -35,12 +35,18 @@ def test_hip_path_reproduces_golden(sess, path):
     assert rel_err(m.predict_proba(sess, Xc, Xf), g['y_out']) < 1e-5
     loss = m.run(sess, Xc, Xf, y, True)
     assert abs(float(loss) - float(g['loss'])) < 1e-5 * max(1.0, abs(float(g['loss'])))
+    gmax = max(float(np.max(np.abs(g['grad/' + k]))) for k in m.get_grads())
     for k, v in m.get_grads().items():
         # softmax gradients sum to zero: attention_b's gradient cancels exactly in R-mode's repeated rows
-        assert rel_err(v, g['grad/' + k], floor=1e-4 if 'pairs' in parts else 1e-30) < 5e-5, k
+        if 'pairs' in parts and 'attention' in k:
+            # gradients through the softmax over the pairs are sums of terms that cancel (sum_k da_k = 0; exactly,
+            # for attention_b in R-mode's repeated rows): their bar is 1e-5 of the model's largest gradient
+            assert np.max(np.abs(v - g['grad/' + k])) < 1e-5 * gmax, k
+        else:
+            assert_close(v, g['grad/' + k], 1e-5, k)
     for k, v in m.get_params().items():
-        assert rel_err(v, g['after1/' + k]) < 5e-5, k
+        assert rel_err(v, g['after1/' + k]) < 1e-5, k
     m.run(sess, Xc, Xf, y, True)
     m.run(sess, Xc, Xf, y, True)
     for k, v in m.get_params().items():
-        assert rel_err(v, g['after3/' + k]) < 1e-4, k
+        assert rel_err(v, g['after3/' + k]) < 1e-4, k        # free-running steps: see helpers.assert_weights_track

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import ctr_oracle as O
-from tests.helpers import rel_err
+from tests.helpers import assert_close, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -378,7 +378,7 @@ def test_colsum_rowdot_loss(ops_ws):
         ops.loss_head(kind, dev(xx), dev(y), y_out=yo, loss_out=lo, dx=dx, ws=ws)
         assert rel_err(yo.cpu().numpy(), p.detach().numpy()) < 1e-5, kind
         assert abs(float(lo.item()) - float(loss.item())) < 1e-5, kind
-        assert rel_err(dx.cpu().numpy(), t.grad.numpy()) < 2e-5, kind
+        assert_close(dx.cpu().numpy(), t.grad.numpy(), 1e-5, kind)
 
 
 @pytest.mark.parametrize('D,L,B', [(50, 3, 37), (429, 3, 37), (1677, 6, 37), (300, 1, 37), (2100, 8, 37),
@@ -445,11 +445,11 @@ def test_afm_attention_over_pairs_fwd_bwd(ops_ws, B, N, E, A, keep):
     dW, db, dh = torch.zeros(E, A, device=DEV), torch.zeros(A, device=DEV), torch.zeros(A, device=DEV)
     for _ in range(2):      # second call must overwrite, not accumulate
         ops.afm_attn_bwd(zp, dev(g), dev(W), dev(b), dev(h), dz, dW, db, dh, N=N, E=E, ws=ws, pair_drop=drop)
-    assert rel_err(dz.cpu().numpy()[:, :N * E], tz.grad.numpy().reshape(B, -1)) < 2e-5
+    assert_close(dz.cpu().numpy()[:, :N * E], tz.grad.numpy().reshape(B, -1), 1e-5, 'dz')
     assert (dz.cpu().numpy()[:, N * E:] == 7.0).all()
-    assert rel_err(dW.cpu().numpy(), tW.grad.numpy()) < 2e-5
-    assert rel_err(db.cpu().numpy(), tb.grad.numpy()) < 2e-5
-    assert rel_err(dh.cpu().numpy(), th.grad.numpy()) < 2e-5
+    assert_close(dW.cpu().numpy(), tW.grad.numpy(), 1e-5, 'dW')
+    assert_close(db.cpu().numpy(), tb.grad.numpy(), 1e-5, 'db')
+    assert_close(dh.cpu().numpy(), th.grad.numpy(), 1e-5, 'dh')
 
 
 def test_bad_arguments_are_rejected(ops_ws):

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import ctr_oracle as O
-from tests.helpers import no_dropout, rel_err, tiny_batch, tiny_cfg
+from tests.helpers import assert_close, assert_weights_track, no_dropout, rel_err, tiny_batch, tiny_cfg
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -54,7 +54,7 @@ def test_forward_grads_steps(sess, name, mode):
     assert abs(float(loss_gpu) - float(loss_ref)) < TOL * max(1.0, abs(float(loss_ref)))
     g_gpu = m.get_grads()
     for k, v in g_gpu.items():
-        assert rel_err(v, g_ref[k].numpy()) < 5 * TOL, k
+        assert_close(v, g_ref[k].numpy(), TOL, k)
     # three optimizer steps: weights track the oracle
     orc.run(Xc, Xf, y, True)
     for _ in range(2):
@@ -62,8 +62,7 @@ def test_forward_grads_steps(sess, name, mode):
         l_g = m.run(sess, Xc, Xf, y, True)
         assert abs(float(l_o) - float(l_g)) < 1e-5
     P_gpu = m.get_params()
-    for k, v in P_gpu.items():
-        assert rel_err(v, orc.P[k].numpy()) < 1e-4, k
+    assert_weights_track(P_gpu, orc.P)
     # eval path: (actual, round(y_out))
     a, pr = m.run(sess, Xc, Xf, y, False)
     a_o, pr_o = orc.run(Xc, Xf, y, False)
@@ -108,7 +107,7 @@ def test_deepfm_dropout_masks_match_hash(sess):
     loss_gpu = m.run(sess, Xc, Xf, y, True)
     assert abs(float(loss_gpu) - float(loss_ref)) < 1e-5
     for k, v in m.get_grads().items():
-        assert rel_err(v, g_ref[k].numpy()) < 5e-5, k
+        assert_close(v, g_ref[k].numpy(), TOL, k)
 
 
 def test_afm_pair_and_output_dropout_match_hash(sess):
@@ -131,7 +130,7 @@ def test_afm_pair_and_output_dropout_match_hash(sess):
     loss_gpu = m.run(sess, Xc, Xf, y, True)
     assert abs(float(loss_gpu) - float(loss_ref)) < 1e-5 * max(1.0, abs(float(loss_ref)))
     for k, v in m.get_grads().items():
-        assert rel_err(v, g_ref[k].numpy()) < 5e-5, k
+        assert_close(v, g_ref[k].numpy(), TOL, k)
 
 
 @pytest.mark.parametrize('dropout', [0.0, 0.4])
@@ -163,14 +162,13 @@ def test_afm_attention_over_pairs_trains_the_attention_variables(sess, dropout):
     assert abs(float(loss_gpu) - float(loss_ref)) < 1e-5 * max(1.0, abs(float(loss_ref)))
     g = m.get_grads()
     for k, v in g.items():
-        assert rel_err(v, g_ref[k].numpy()) < 5e-5, k
+        assert_close(v, g_ref[k].numpy(), TOL, k)
     assert np.abs(g['attention_based_pooling/attention_w']).max() > 0
     if not dropout:
         orc.run(Xc, Xf, y, True)
         for _ in range(2):
             assert abs(float(orc.run(Xc, Xf, y, True)) - float(m.run(sess, Xc, Xf, y, True))) < 1e-5
-        for k, v in m.get_params().items():
-            assert rel_err(v, orc.P[k].numpy()) < 1e-4, k
+        assert_weights_track(m.get_params(), orc.P)
 
 
 def test_side_stream_weight_gradients_change_nothing(sess):
@@ -292,14 +290,13 @@ def test_reference_default_architecture_matches_oracle(sess, variant):
     loss_gpu = m.run(sess, Xc, Xf, y, True)
     assert abs(float(loss_gpu) - float(loss_ref)) < TOL * max(1.0, abs(float(loss_ref)))
     for k, v in m.get_grads().items():
-        assert rel_err(v, g_ref[k].numpy()) < 5 * TOL, k
+        assert_close(v, g_ref[k].numpy(), TOL, k)
     orc.run(Xc, Xf, y, True)
     for _ in range(2):
         l_o = orc.run(Xc, Xf, y, True)
         l_g = m.run(sess, Xc, Xf, y, True)
         assert abs(float(l_o) - float(l_g)) < 1e-5
-    for k, v in m.get_params().items():
-        assert rel_err(v, orc.P[k].numpy()) < 1e-4, k
+    assert_weights_track(m.get_params(), orc.P)
 
 
 def test_out_of_range_ids_are_counted_and_optionally_rejected(sess):

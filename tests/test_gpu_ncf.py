@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import ctr_oracle as O
-from tests.helpers import rel_err
+from tests.helpers import assert_close, assert_weights_track, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -41,12 +41,11 @@ def test_ncf_forward_grads_and_adam_steps(sess):
     loss = m.run(sess, X, y, True)
     assert abs(float(loss) - float(loss_ref)) < 1e-5
     for k, v in m.get_grads().items():
-        assert rel_err(v, g_ref[k].numpy(), floor=1e-12) < 5e-5, k
+        assert_close(v, g_ref[k].numpy(), 1e-5, k)
     orc.run(X, y, True)
     for _ in range(2):
         assert abs(float(orc.run(X, y, True)) - float(m.run(sess, X, y, True))) < 1e-5
-    for k, v in m.get_params().items():
-        assert rel_err(v, orc.P[k].numpy()) < 1e-4, k
+    assert_weights_track(m.get_params(), orc.P)
     a, p = m.run(sess, X, y, False)
     a_o, p_o = orc.run(X, y, False)
     assert np.array_equal(a, a_o) and np.array_equal(p, p_o)
@@ -62,7 +61,7 @@ def test_ncf_dropout_masks_and_checkpoint(sess, tmp_path):
     loss_ref, g_ref, _ = O.OracleNCF(cfg, P).loss_and_grads(X, y, masks)
     assert abs(float(m.run(sess, X, y, True)) - float(loss_ref)) < 1e-5
     for k, v in m.get_grads().items():
-        assert rel_err(v, g_ref[k].numpy(), floor=1e-12) < 5e-5, k
+        assert_close(v, g_ref[k].numpy(), 1e-5, k)
     path = str(tmp_path / 'ncf.ckpt')
     m.saver.save(sess, path)
     m2 = _build(sess, cfg, P)

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import ctr_oracle as O
-from tests.helpers import rel_err
+from tests.helpers import assert_close, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -43,7 +43,7 @@ def test_wide_deep_forward_grads_and_steps(sess):
     loss = m.run(sess, Xr, Xc, Xf, y, True)
     assert abs(float(loss) - float(loss_ref)) < 1e-5
     for k, v in m.get_grads().items():
-        assert rel_err(v, g_ref[k].numpy(), floor=1e-12) < 5e-5, k
+        assert_close(v, g_ref[k].numpy(), 1e-5, k)
     orc.run(Xr, Xc, Xf, y, True)
     for _ in range(3):
         l_o, l_g = orc.run(Xr, Xc, Xf, y, True), m.run(sess, Xr, Xc, Xf, y, True)
