@@ -41,8 +41,9 @@ def parse():
                     help='DeepFM is the headline workload; the others time the same step for their family')
     ap.add_argument('--comm', default='rccl', choices=['rccl', 'host-staged'],
                     help='host-staged: gloo through host memory, to rehearse N>1 with all ranks on one GPU')
-    ap.add_argument('--shard', default='table', choices=['table', 'row'],
-                    help='N>1: whole tables per rank, or row r of every table on rank r %% N')
+    ap.add_argument('--shard', default=None, choices=['table', 'row'],
+                    help='N>1: whole tables per rank (default for the Criteo-Kaggle models), or row r of field f on rank '
+                         '(r + f) %% N (default for DCN: its Criteo-1TB tables do not fit one owner)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timers', action='store_true')
     return ap.parse_args()
@@ -131,6 +132,8 @@ def main():
         args.batch = 8192 if args.model == 'DCN' else 65536
     if not args.embed:
         args.embed = 64 if args.model == 'DCN' else 16
+    if args.shard is None:
+        args.shard = 'row' if args.model == 'DCN' else 'table'
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -203,6 +206,7 @@ def main():
     dt = time.perf_counter() - t0
     ops.set_timer(None)
     loss = float(model._loss_dev.item())
+    model.check_overflow()      # row-sharded tables: a fixed-capacity send bucket that overflowed is an error
     if world > 1:
         t = torch.tensor([dt], device='cpu' if args.comm == 'host-staged' else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

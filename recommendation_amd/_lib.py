@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libctrhip.so')
+# CTRHIP_LIB: another build of the same library (A/B timing of a kernel change); default: the in-tree build
+LIB_PATH = os.environ.get('CTRHIP_LIB') or os.path.join(_HERE, 'lib', 'libctrhip.so')
 
 c_f32p = C.c_void_p   # device pointers travel as integers
 c_i32p = C.c_void_p
@@ -98,6 +99,7 @@ SIGNATURES = {
     'ctr_auc_workspace_bytes': (sz, [i64]),
     'ctr_auc': (i, [vp, vp, i64, vp, vp, vp, sz, vp]),
     'ctr_shard_route': (i, [vp, vp, vp, i, i, i, vp, vp, vp]),
+    'ctr_shard_bucket': (i, [vp, vp, vp, i64, i, i64, vp, vp, vp, vp]),
     'ctr_rows_gather': (i, [vp, i64, vp, i64, i, i, vp, vp]),
     'ctr_rows_scatter': (i, [vp, vp, i64, i, i, vp, i64, vp]),
     'ctr_afm_attn_fwd': (i, [vp, i64, i, i, i, i, vp, vp, vp, DP, vp, vp]),

@@ -5,9 +5,10 @@
 
 namespace ctr {
 
-// lookup p = b*F + f with id x:  dest = x mod W,  local key = local_offset[dest][f] + x / W
-// (local_offset[j][f] = first row of field f inside rank j's concatenated shard).  An id outside
-// [0, V_f) keeps the zero-row semantics of the single-GPU gather: it goes to rank f mod W with key -1.
+// lookup p = b*F + f with id x:  dest = (x + f) mod W,  local key = local_offset[dest][f] + x / W
+// (local_offset[j][f] = first row of field f inside rank j's concatenated shard).  The owner is rotated by the
+// field number so that the hottest row of every field (often the same small id) does not land on one rank.  An id
+// outside [0, V_f) keeps the zero-row semantics of the single-GPU gather: it goes to rank f mod W with key -1.
 __global__ __launch_bounds__(256) void shard_route_kernel(const int32_t* __restrict__ idx,
                                                          const int64_t* __restrict__ row_offset,
                                                          const int32_t* __restrict__ local_offset, int64_t n, int F,
@@ -18,7 +19,7 @@ __global__ __launch_bounds__(256) void shard_route_kernel(const int32_t* __restr
     const int x = idx[p];
     const int64_t V = row_offset[f + 1] - row_offset[f];
     if (x >= 0 && x < V) {
-      const int d = x % W;
+      const int d = (int)(((int64_t)x + f) % W);
       dest[p] = (uint32_t)d;
       lkey[p] = local_offset[d * F + f] + x / W;
     } else {
@@ -28,7 +29,43 @@ __global__ __launch_bounds__(256) void shard_route_kernel(const int32_t* __restr
   }
 }
 
-// out[s, 0:E] = src[b, f*E : (f+1)*E] with (b, f) = divmod(perm[s], F); 32-bit words, any payload
+constexpr uint32_t EMPTY_SLOT = 0xFFFFFFFFu;   // a slot of a fixed-capacity bucket that no lookup fills
+
+// Fixed-capacity send buckets.  dest_sorted / perm: the lookups stably sorted by destination rank.  Lookup number r
+// of destination d goes to slot d*cap + r: slot_key = its key inside the owner's shard, slot_perm = its position
+// p = b*F + f in the batch.  Lookups beyond a bucket's capacity are dropped and counted in overflow (the caller
+// treats a non-zero count as an error).  Both outputs were filled with 0xFF bytes beforehand (empty slots).
+__global__ __launch_bounds__(256) void shard_bucket_kernel(const uint32_t* __restrict__ dest_sorted,
+                                                          const uint32_t* __restrict__ perm,
+                                                          const int32_t* __restrict__ lkey, int64_t n, int W, int64_t cap,
+                                                          int32_t* __restrict__ slot_key, uint32_t* __restrict__ slot_perm,
+                                                          int32_t* __restrict__ overflow) {
+  __shared__ int64_t start[64];        // first sorted position of every destination
+  if ((int)threadIdx.x < W) {
+    const uint32_t d = threadIdx.x;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (dest_sorted[mid] < d) lo = mid + 1; else hi = mid;
+    }
+    start[d] = lo;
+  }
+  __syncthreads();
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t d = dest_sorted[j];
+    const int64_t r = j - start[d];
+    if (r < cap) {
+      const uint32_t p = perm[j];
+      slot_key[d * cap + r] = lkey[p];
+      slot_perm[d * cap + r] = p;
+    } else {
+      atomicAdd(overflow, 1);
+    }
+  }
+}
+
+// out[s, 0:E] = src[b, f*E : (f+1)*E] with (b, f) = divmod(perm[s], F) (zeros where perm[s] marks an empty slot);
+// 32-bit words, any payload
 __global__ __launch_bounds__(256) void rows_gather_kernel(const uint32_t* __restrict__ src, int64_t ld,
                                                          const uint32_t* __restrict__ perm, int64_t n, int F, int E,
                                                          uint32_t* __restrict__ out) {
@@ -37,11 +74,11 @@ __global__ __launch_bounds__(256) void rows_gather_kernel(const uint32_t* __rest
     const int64_t s = q / E;
     const int e = (int)(q % E);
     const uint32_t p = perm[s];
-    out[q] = src[(int64_t)(p / (uint32_t)F) * ld + (int64_t)(p % (uint32_t)F) * E + e];
+    out[q] = p == EMPTY_SLOT ? 0u : src[(int64_t)(p / (uint32_t)F) * ld + (int64_t)(p % (uint32_t)F) * E + e];
   }
 }
 
-// dst[b, f*E : (f+1)*E] = rows[s, 0:E] with (b, f) = divmod(perm[s], F)
+// dst[b, f*E : (f+1)*E] = rows[s, 0:E] with (b, f) = divmod(perm[s], F); empty slots are skipped
 __global__ __launch_bounds__(256) void rows_scatter_kernel(const uint32_t* __restrict__ rows,
                                                           const uint32_t* __restrict__ perm, int64_t n, int F, int E,
                                                           uint32_t* __restrict__ dst, int64_t ld) {
@@ -50,7 +87,7 @@ __global__ __launch_bounds__(256) void rows_scatter_kernel(const uint32_t* __res
     const int64_t s = q / E;
     const int e = (int)(q % E);
     const uint32_t p = perm[s];
-    dst[(int64_t)(p / (uint32_t)F) * ld + (int64_t)(p % (uint32_t)F) * E + e] = rows[q];
+    if (p != EMPTY_SLOT) dst[(int64_t)(p / (uint32_t)F) * ld + (int64_t)(p % (uint32_t)F) * E + e] = rows[q];
   }
 }
 
@@ -71,6 +108,22 @@ extern "C" int ctr_shard_route(const int32_t* idx, const int64_t* row_offset, co
   CTR_REQUIRE(idx && row_offset && local_offset && dest_out && lkey_out, "ctr_shard_route: null pointer");
   hipLaunchKernelGGL(shard_route_kernel, dim3(grid_of(n)), dim3(256), 0, (hipStream_t)stream, idx, row_offset,
                      local_offset, n, F, W, dest_out, lkey_out);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_shard_bucket(const uint32_t* dest_sorted, const uint32_t* perm, const int32_t* lkey, int64_t n, int W,
+                                int64_t cap, int32_t* slot_key_out, uint32_t* slot_perm_out, int32_t* overflow_count,
+                                void* stream) {
+  CTR_REQUIRE(n >= 0 && W >= 1 && W <= 64 && cap >= 1, "ctr_shard_bucket: bad size (1 <= W <= 64, cap >= 1)");
+  CTR_REQUIRE(slot_key_out && slot_perm_out && overflow_count, "ctr_shard_bucket: null output");
+  hipStream_t st = (hipStream_t)stream;
+  CTR_HIP(hipMemsetAsync(slot_key_out, 0xFF, (size_t)W * cap * 4, st));
+  CTR_HIP(hipMemsetAsync(slot_perm_out, 0xFF, (size_t)W * cap * 4, st));
+  if (n == 0) return CTR_OK;
+  CTR_REQUIRE(dest_sorted && perm && lkey, "ctr_shard_bucket: null input");
+  hipLaunchKernelGGL(shard_bucket_kernel, dim3(grid_of(n)), dim3(256), 0, st, dest_sorted, perm, lkey, n, W, cap,
+                     slot_key_out, slot_perm_out, overflow_count);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }

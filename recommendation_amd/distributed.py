@@ -4,8 +4,8 @@ dense towers data-parallel.
 The reference is single-process (no collective anywhere), so this is new design; only the
 single-device numerics are inherited.  Layout:
 
-  * field f belongs to exactly one rank; ranks own CONTIGUOUS field ranges (balanced by field
-    count), so a rank's rows land in a contiguous column block of every sample's Z;
+  * field f belongs to exactly one rank; fields are dealt to ranks by table ROWS (largest table first, to the
+    least loaded rank: pack_fields), so the big tables of a Criteo-shape model end up on different ranks;
   * forward:  all-to-all of ids (each rank sends, per owner, its batch's ids of that owner's
     fields) -> the owner gathers rows for all W*B_loc samples with the ordinary gather kernel
     -> all-to-all of rows back -> strided copies assemble Z / the deep input;
@@ -17,10 +17,12 @@ single-device numerics are inherited.  Layout:
 Every split size is static (B_loc * fields-per-owner): no count exchange, no host sync.
 Collectives go through torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box).
 
-RowShardedFront is the alternative for tables too large or too skewed for one owner: row r of
-field f lives on rank r mod W (Zipf-hot rows spread over the ranks).  Its message sizes depend on
-the batch, so each step exchanges W counts and reads them on the host before the payload
-all-to-all-v.
+RowShardedFront is the layout for tables too large or too skewed for one owner: row r of field f
+lives on rank (r + f) mod W (Zipf-hot rows spread over the ranks; the rotation by f keeps the hottest
+row of every field off one rank).  Its traffic depends on the batch, so every rank sends each peer a
+FIXED-capacity bucket (B*F/W lookups times a slack factor, unfilled slots are zero rows): all splits are
+static here too - no count exchange and no host synchronisation; a bucket that overflows is counted on the
+device and reported at the step's end.
 """
 from __future__ import annotations
 
@@ -32,15 +34,17 @@ from .engine import EmbeddingTables
 from ._lib import OPT_ADAM, OPT_GRAD_ONLY
 
 
-def field_ranges(F, W):
-    """W contiguous [a, b) field ranges covering [0, F), sizes differing by at most one."""
-    base, rem = divmod(F, W)
-    out, a = [], 0
-    for j in range(W):
-        n = base + (1 if j < rem else 0)
-        out.append((a, a + n))
-        a += n
-    return out
+def pack_fields(cate_list, W):
+    """Fields dealt to W ranks by table rows: largest table first, each to the rank with the fewest rows so far
+    (ties: lowest rank).  Returns W ascending field lists.  With the Criteo-1TB cardinalities and W = 8 the four
+    tables above 100 M rows go to four different ranks (balancing by field COUNT put three of them on one)."""
+    load = [0] * W
+    out = [[] for _ in range(W)]
+    for f in sorted(range(len(cate_list)), key=lambda i: (-int(cate_list[i]), i)):
+        j = min(range(W), key=lambda r: (load[r], r))
+        out[j].append(f)
+        load[j] += int(cate_list[f])
+    return [sorted(fs) for fs in out]
 
 
 class TorchComm:
@@ -53,7 +57,8 @@ class TorchComm:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
 
-    def all_to_all(self, out, inp, out_splits, in_splits):
+    def all_to_all(self, out, inp, out_splits=None, in_splits=None):
+        """splits None: W equal parts (static sizes; nothing for the host to read)."""
         self.dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits,
                                     group=self.group)
 
@@ -73,9 +78,13 @@ class HostStagedComm:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
 
-    def all_to_all(self, out, inp, out_splits, in_splits):
+    def all_to_all(self, out, inp, out_splits=None, in_splits=None):
         o = torch.empty(out.shape, dtype=out.dtype)
         i = inp.detach().cpu()
+        if out_splits is None:
+            out_splits = [out.shape[0] // self.world] * self.world
+        if in_splits is None:
+            in_splits = [inp.shape[0] // self.world] * self.world
         outs, ins = list(o.split(out_splits)), list(i.split(in_splits))
         outs[self.rank].copy_(ins[self.rank])
         reqs = []
@@ -96,7 +105,7 @@ class HostStagedComm:
 
 
 class ShardedFront:
-    """Drop-in for engine.EmbedFront (S semantics) when the tables are sharded over ranks."""
+    """Drop-in for engine.EmbedFront (S semantics) when whole tables are dealt to ranks (pack_fields)."""
 
     def __init__(self, cate_list, E, cont_num, cont_embed, comm, device, backend=_ops):
         self.comm, self.ops = comm, backend
@@ -108,67 +117,70 @@ class ShardedFront:
         self.mode = 'S'
         self.Ncat = self.F
         self.N = self.F + (self.C if cont_embed else 0)
-        self.ranges = field_ranges(self.F, self.W)
-        self.a, self.b = self.ranges[self.rank]
-        self.nf_own = self.b - self.a
-        own = list(cate_list[self.a:self.b]) or [1]          # a rank without fields keeps a 1-row dummy
+        self.fields_of = pack_fields(cate_list, self.W)       # owner rank -> ascending field list
+        self.own_fields = self.fields_of[self.rank]
+        self.nf_own = len(self.own_fields)
+        own = [int(cate_list[f]) for f in self.own_fields] or [1]   # a rank without fields keeps a 1-row dummy
         self.t = EmbeddingTables(own, E, device)
         self.device = device
         self._buf = {}
 
     def owner_of(self, f):
-        for j, (a, b) in enumerate(self.ranges):
-            if a <= f < b:
+        for j, fs in enumerate(self.fields_of):
+            if f in fs:
                 return j
         raise IndexError(f)
 
     def _buffers(self, B):
         if B not in self._buf:
-            E, W = self.E, self.W
-            nf = [b - a for a, b in self.ranges]
+            E, W, F = self.E, self.W, self.F
+            nf = [len(fs) for fs in self.fields_of]
             dev = self.device
-            self._buf[B] = dict(
-                recv_idx=torch.zeros(W * B * self.nf_own, dtype=torch.int32, device=dev),
+            bf = dict(
+                send_idx=torch.zeros(max(B * F, 1), dtype=torch.int32, device=dev),
+                recv_idx=torch.zeros(max(W * B * self.nf_own, 1), dtype=torch.int32, device=dev),
                 rows=torch.zeros(W * B, max(self.nf_own, 1) * E, dtype=torch.float32, device=dev),
-                blocks=torch.zeros(B * self.F * E, dtype=torch.float32, device=dev),
+                blocks=torch.zeros(max(B * F * E, 1), dtype=torch.float32, device=dev),
                 grows=torch.zeros(W * B, max(self.nf_own, 1) * E, dtype=torch.float32, device=dev),
                 keys=torch.zeros(max(W * B * self.nf_own, 1), dtype=torch.int32, device=dev),
                 src=torch.zeros(max(W * B * self.nf_own, 1), dtype=torch.int32, device=dev),
                 idx_in=[B * n for n in nf], idx_out=[B * self.nf_own] * W,
                 row_in=[B * self.nf_own * E] * W, row_out=[B * n * E for n in nf])
-            # where row n of sample b sits in `blocks` (one [B, nf_j*E] block per owner j, owner after owner)
-            fbase, fstride, off = [], [], 0
-            for a, b in self.ranges:
-                for n in range(a, b):
-                    fbase.append(off + (n - a) * E)
-                    fstride.append((b - a) * E)
-                off += B * (b - a) * E
-            self._buf[B]['fbase'] = torch.tensor(fbase, dtype=torch.int64, device=dev)
-            self._buf[B]['fstride'] = torch.tensor(fstride, dtype=torch.int64, device=dev)
+            # send order: owner after owner, inside an owner sample after sample, inside a sample the owner's fields;
+            # send_perm[s] = b*F + f of the lookup in send slot s (one array serves ids and E-wide rows alike).
+            # fbase / fstride: where row f of sample b sits in `blocks` (one [B, nf_j*E] block per owner j)
+            perm = np.empty(B * F, dtype=np.int64)
+            fbase, fstride = [0] * F, [0] * F
+            pos, off = 0, 0
+            b_col = np.arange(B, dtype=np.int64)[:, None] * F
+            for fs in self.fields_of:
+                k = len(fs)
+                if k:
+                    perm[pos:pos + B * k] = (b_col + np.asarray(fs, dtype=np.int64)[None, :]).reshape(-1)
+                    for q, f in enumerate(fs):
+                        fbase[f] = off + q * E
+                        fstride[f] = k * E
+                pos += B * k
+                off += B * k * E
+            bf['send_perm'] = torch.as_tensor(perm.astype(np.int32), device=dev)
+            bf['fbase'] = torch.tensor(fbase, dtype=torch.int64, device=dev)
+            bf['fstride'] = torch.tensor(fstride, dtype=torch.int64, device=dev)
+            self._buf[B] = bf
         return self._buf[B]
-
-    def _block_views(self, flat, B):
-        """Per-owner [B, nf_j*E] views of a flat buffer laid out owner after owner."""
-        views, off = [], 0
-        for a, b in self.ranges:
-            n = B * (b - a) * self.E
-            views.append(flat[off:off + n].view(B, (b - a) * self.E) if b > a else None)
-            off += n
-        return views
 
     def forward(self, idx, x_cont, *, z_out, cont_tail=False, cont_w=None, first_out=None, s_out=None,
                 second_out=None, drop_first=None, drop_second=None, oor_count=None):
         if z_out is None:
             raise ValueError('the sharded front end assembles Z in z_out; it cannot be None')
-        ops, E, W = self.ops, self.E, self.W
+        ops, E, W, F = self.ops, self.E, self.W, self.F
         B = idx.shape[0]
         bf = self._buffers(B)
-        send_idx = torch.cat([idx[:, a:b].reshape(-1) for a, b in self.ranges])
-        self.comm.all_to_all(bf['recv_idx'], send_idx, bf['idx_out'], bf['idx_in'])
+        ops.rows_gather(idx, bf['send_perm'], B * F, bf['send_idx'], F=F, E=1)        # ids in send order
+        self.comm.all_to_all(bf['recv_idx'][:W * B * self.nf_own], bf['send_idx'][:B * F], bf['idx_out'], bf['idx_in'])
         if self.nf_own:
-            ops.embed_fwd(self.t.weight, self.t.row_offset, bf['recv_idx'].view(W * B, self.nf_own), E=E,
-                          z_out=bf['rows'], oor_count=oor_count)
-        self.comm.all_to_all(bf['blocks'], bf['rows'].view(-1)[:W * B * self.nf_own * E], bf['row_out'],
+            ops.embed_fwd(self.t.weight, self.t.row_offset, bf['recv_idx'][:W * B * self.nf_own].view(W * B, self.nf_own),
+                          E=E, z_out=bf['rows'], oor_count=oor_count)
+        self.comm.all_to_all(bf['blocks'][:B * F * E], bf['rows'].view(-1)[:W * B * self.nf_own * E], bf['row_out'],
                              bf['row_in'])
         # one pass: owner blocks -> Z rows, continuous rows / tail, FM sums, dropout
         ops.embed_assemble_fwd(bf['blocks'], bf['fbase'], bf['fstride'], x_cont if (self.cont_embed or cont_tail) else None,
@@ -183,19 +195,17 @@ class ShardedFront:
         return dict(blocks_out=bf['blocks'], fbase=bf['fbase'], fstride=bf['fstride'], F=self.F)
 
     def backward_tables(self, idx, dz, keys, src, ws, opt, lazy, dz_in_blocks=False):
-        ops, E, W = self.ops, self.E, self.W
+        ops, E, W, F = self.ops, self.E, self.W, self.F
         B = idx.shape[0]
         bf = self._buffers(B)
         if not dz_in_blocks:
-            for (a, b), blk in zip(self.ranges, self._block_views(bf['blocks'], B)):
-                if blk is not None:
-                    ops.copy2d(dz[:, a * E:b * E], blk)
-        self.comm.all_to_all(bf['grows'].view(-1)[:W * B * self.nf_own * E], bf['blocks'], bf['row_in'],
+            ops.rows_gather(dz, bf['send_perm'], B * F, bf['blocks'], F=F, E=E)     # dZ rows in send order
+        self.comm.all_to_all(bf['grows'].view(-1)[:W * B * self.nf_own * E], bf['blocks'][:B * F * E], bf['row_in'],
                              bf['row_out'])
         if not self.nf_own:
             return
         t, n_items = self.t, W * B * self.nf_own
-        ops.emb_sort(bf['recv_idx'].view(W * B, self.nf_own), t.row_offset, N=self.nf_own,
+        ops.emb_sort(bf['recv_idx'][:n_items].view(W * B, self.nf_own), t.row_offset, N=self.nf_own,
                      total_rows=t.total_rows, rmode=False, keys_out=bf['keys'], src_out=bf['src'], ws=ws)
         if opt.kind == OPT_ADAM and not lazy:
             t.grad.zero_()
@@ -212,10 +222,22 @@ class ShardedFront:
                         w_group=E, ws=ws)
 
 
+def row_owner_start(f, rank, W):
+    """Smallest row r >= 0 of field f that rank `rank` owns: (r + f) mod W == rank.  Its rows are
+    r = start, start + W, ... at local rows r // W = 0, 1, ..."""
+    return (rank - f) % W
+
+
 def row_shard_layout(cate_list, W):
-    """Per rank j: the number of rows of each field it owns (rows r with r % W == j) and the first
+    """Per rank j: the number of rows of each field it owns (rows r with (r + f) % W == j) and the first
     local row of each field inside its concatenated shard."""
-    cards = [[(int(v) - j + W - 1) // W if int(v) > j else 0 for v in cate_list] for j in range(W)]
+    cards = []
+    for j in range(W):
+        row = []
+        for f, v in enumerate(cate_list):
+            s = row_owner_start(f, j, W)
+            row.append((int(v) - s + W - 1) // W if int(v) > s else 0)
+        cards.append(row)
     offs = [np.concatenate([[0], np.cumsum(c)]).astype(np.int64) for c in cards]
     return cards, offs
 
@@ -223,15 +245,21 @@ def row_shard_layout(cate_list, W):
 class RowShardedFront:
     """Drop-in for engine.EmbedFront (S semantics) with every table sharded by row over the ranks.
 
-    forward : route each lookup (dest = id mod W, key = row inside the owner's shard) -> stable sort
-              by dest -> all-to-all-v of keys -> the owner gathers rows with the ordinary gather kernel
-              -> all-to-all-v of rows back -> scatter into Z in lookup order.
-    backward: gather dZ rows in the same send order -> all-to-all-v to the owners -> the ordinary
-              sort + segment-reduce + fused optimizer on the owner's shard."""
+    forward : route each lookup (dest = (id + f) mod W, key = row inside the owner's shard) -> stable sort
+              by dest -> fixed-capacity buckets (cap slots per peer) -> all-to-all of keys (equal splits) ->
+              the owner gathers rows with the ordinary gather kernel (empty slots: zero rows) -> all-to-all
+              of rows back -> scatter into Z in lookup order.
+    backward: gather dZ rows into the same slots -> all-to-all to the owners -> the ordinary
+              sort + segment-reduce + fused optimizer on the owner's shard.
+    Nothing on this path depends on the batch's ids on the host: no count exchange, no synchronisation,
+    no allocation after the first step at a batch size.  `overflow` (device int32) counts lookups that did
+    not fit their bucket; check_overflow() raises when it is non-zero (raise `slack`)."""
 
-    def __init__(self, cate_list, E, cont_num, cont_embed, comm, device, backend=_ops):
+    def __init__(self, cate_list, E, cont_num, cont_embed, comm, device, backend=_ops, slack=1.5):
         self.comm, self.ops = comm, backend
         self.W, self.rank = comm.world, comm.rank
+        if self.W > 64:
+            raise ValueError('row sharding supports up to 64 ranks')
         self.cate_list = [int(v) for v in cate_list]
         self.F = len(self.cate_list)
         self.E = int(E)
@@ -240,6 +268,7 @@ class RowShardedFront:
         self.mode = 'S'
         self.Ncat = self.F
         self.N = self.F + (self.C if cont_embed else 0)
+        self.slack = float(slack)
         self.cards_loc, self.offs_loc = row_shard_layout(self.cate_list, self.W)
         # one spare row keeps the shard non-empty on ranks that own nothing
         self.t = EmbeddingTables(list(self.cards_loc[self.rank]) + [1], E, device)
@@ -250,32 +279,29 @@ class RowShardedFront:
         self.shard_offset = torch.as_tensor(np.array([0, max(self.total_local, 1)], dtype=np.int64), device=device)
         self.device = device
         self.key_bits = max(1, int(self.W - 1).bit_length())
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
         self._buf = {}
-        self._cap = 0
-        self._last = None
+        self._own_ws = None
 
     def local_rows(self, f):
         """Global row ids of field f held by this rank, in local order."""
-        return np.arange(self.rank, self.cate_list[f], self.W)
+        return np.arange(row_owner_start(f, self.rank, self.W), self.cate_list[f], self.W)
+
+    def capacity(self, B):
+        """Slots per destination rank: the even share of B*F lookups times the slack, a multiple of 64."""
+        n = B * self.F
+        return min(max(n, 1), (int(np.ceil(n / self.W * self.slack)) + 63) // 64 * 64)
 
     def _buffers(self, B):
         if B not in self._buf:
-            n, E, dev = B * self.F, self.E, self.device
+            n, E, W, dev = B * self.F, self.E, self.W, self.device
+            cap = self.capacity(B)
             i32 = lambda k: torch.zeros(max(k, 1), dtype=torch.int32, device=dev)
-            self._buf[B] = dict(dest=i32(n), lkey=i32(n), send_keys=i32(n),
-                                arange=torch.arange(max(n, 1), dtype=torch.int32, device=dev),
-                                back=torch.zeros(max(n, 1), E, dtype=torch.float32, device=dev))
+            f32 = lambda r: torch.zeros(max(r, 1), E, dtype=torch.float32, device=dev)
+            self._buf[B] = dict(cap=cap, dest=i32(n), lkey=i32(n), arange=torch.arange(max(n, 1), dtype=torch.int32, device=dev),
+                                send_keys=i32(W * cap), slot_perm=i32(W * cap), recv_keys=i32(W * cap),
+                                rows=f32(W * cap), back=f32(W * cap), skeys=i32(W * cap), ssrc=i32(W * cap))
         return self._buf[B]
-
-    def _grow(self, n_recv):
-        if n_recv > self._cap:
-            cap = max(int(n_recv * 1.25) + 64, 1024)
-            dev = self.device
-            self._recv_keys = torch.zeros(cap, dtype=torch.int32, device=dev)
-            self._rows = torch.zeros(cap, self.E, dtype=torch.float32, device=dev)
-            self._skeys = torch.zeros(cap, dtype=torch.int32, device=dev)
-            self._ssrc = torch.zeros(cap, dtype=torch.int32, device=dev)
-            self._cap = cap
 
     def forward(self, idx, x_cont, *, z_out, cont_tail=False, cont_w=None, first_out=None, s_out=None,
                 second_out=None, drop_first=None, drop_second=None, oor_count=None, ws=None):
@@ -285,27 +311,19 @@ class RowShardedFront:
         B = idx.shape[0]
         n = B * F
         bf = self._buffers(B)
+        cap = bf['cap']
         ws = ws if ws is not None else self._ws()
         ops.shard_route(idx, self.full_offset, self.local_offset, W, bf['dest'], bf['lkey'])
         sdest, perm = ops.sort_pairs(bf['dest'][:n], bf['arange'][:n], self.key_bits, ws)
-        ops.rows_gather(bf['lkey'][:n].view(B, F), perm, n, bf['send_keys'], F=F, E=1)
-        send_counts = torch.bincount(sdest, minlength=W).to(torch.int64)
-        recv_counts = torch.zeros_like(send_counts)
-        self.comm.all_to_all(recv_counts, send_counts, [1] * W, [1] * W)
-        sc = [int(v) for v in send_counts.tolist()]           # host reads the W counts: one sync per step
-        rc = [int(v) for v in recv_counts.tolist()]
-        n_recv = sum(rc)
-        self._grow(n_recv)
-        self.comm.all_to_all(self._recv_keys[:n_recv], bf['send_keys'][:n], rc, sc)
-        if n_recv:
-            ops.embed_fwd(self.t.weight, self.shard_offset, self._recv_keys[:n_recv].view(n_recv, 1), E=E,
-                          z_out=self._rows[:n_recv], oor_count=oor_count)
-        self.comm.all_to_all(bf['back'].view(-1)[:n * E], self._rows.view(-1)[:n_recv * E],
-                             [c * E for c in sc], [c * E for c in rc])
-        ops.rows_scatter(bf['back'], perm, n, z_out, F=F, E=E)
-        self._last = (perm, sc, rc, n_recv)
+        ops.shard_bucket(sdest, perm, bf['lkey'], n, W, cap, bf['send_keys'], bf['slot_perm'], self.overflow)
+        self.comm.all_to_all(bf['recv_keys'][:W * cap], bf['send_keys'][:W * cap])
+        # empty slots carry key -1: zero rows (they are not out-of-range ids, so they are not counted)
+        ops.embed_fwd(self.t.weight, self.shard_offset, bf['recv_keys'][:W * cap].view(W * cap, 1), E=E,
+                      z_out=bf['rows'][:W * cap])
+        self.comm.all_to_all(bf['back'].view(-1)[:W * cap * E], bf['rows'].view(-1)[:W * cap * E])
+        ops.rows_scatter(bf['back'], bf['slot_perm'], W * cap, z_out, F=F, E=E)
         if self.cont_embed:
-            ops.embed_fwd(self.t.weight, self.t.row_offset[:1], idx[:, :0].contiguous(), x_cont, cont_w, E=E,
+            ops.embed_fwd(self.t.weight, self.t.row_offset[:1], idx[:, :0], x_cont, cont_w, E=E,
                           z_out=z_out[:, F * E:], cont_tail=cont_tail)
         elif cont_tail:
             ops.copy2d(x_cont, z_out[:, F * E:F * E + self.C])
@@ -314,31 +332,36 @@ class RowShardedFront:
                        drop_first=drop_first, drop_second=drop_second)
 
     def _ws(self):
-        if not hasattr(self, '_own_ws'):
+        if self._own_ws is None:
             self._own_ws = self.ops.Workspace(self.device)
         return self._own_ws
 
+    def check_overflow(self):
+        """Raises when a send bucket overflowed since the last check (synchronises the host)."""
+        n = int(self.overflow.item())
+        if n:
+            self.overflow.zero_()
+            raise RuntimeError('%d lookup(s) did not fit the fixed-capacity send buckets of the row-sharded tables '
+                               '(slack %.2f); raise args.shard_slack' % (n, self.slack))
+
     def backward_tables(self, idx, dz, keys, src, ws, opt, lazy):
-        ops, E, F = self.ops, self.E, self.F
+        ops, E, F, W = self.ops, self.E, self.F, self.W
         B = idx.shape[0]
-        n = B * F
         bf = self._buffers(B)
-        perm, sc, rc, n_recv = self._last
-        ops.rows_gather(dz, perm, n, bf['back'], F=F, E=E)
-        self.comm.all_to_all(self._rows.view(-1)[:n_recv * E], bf['back'].view(-1)[:n * E],
-                             [c * E for c in rc], [c * E for c in sc])
-        if not n_recv:
-            return
+        cap = bf['cap']
+        n_recv = W * cap
+        ops.rows_gather(dz, bf['slot_perm'], n_recv, bf['back'], F=F, E=E)            # empty slots: zero rows
+        self.comm.all_to_all(bf['rows'].view(-1)[:n_recv * E], bf['back'].view(-1)[:n_recv * E])
         t, total = self.t, max(self.total_local, 1)
-        ops.emb_sort(self._recv_keys[:n_recv].view(n_recv, 1), self.shard_offset, N=1, total_rows=total, rmode=False,
-                     keys_out=self._skeys, src_out=self._ssrc, ws=ws)
+        ops.emb_sort(bf['recv_keys'][:n_recv].view(n_recv, 1), self.shard_offset, N=1, total_rows=total, rmode=False,
+                     keys_out=bf['skeys'], src_out=bf['ssrc'], ws=ws)
         if opt.kind == OPT_ADAM and not lazy:
             t.grad.zero_()
-            ops.emb_sparse_apply(self._skeys, self._ssrc, n_recv, N=1, E=E, total_rows=total, dz=self._rows[:n_recv],
+            ops.emb_sparse_apply(bf['skeys'], bf['ssrc'], n_recv, N=1, E=E, total_rows=total, dz=bf['rows'][:n_recv],
                                  opt=ops.make_opt(OPT_GRAD_ONLY), slot0=t.grad, ws=ws)
             ops.dense_update(t.weight, t.grad, opt, t.slot0, t.slot1)
         else:
-            ops.emb_sparse_apply(self._skeys, self._ssrc, n_recv, N=1, E=E, total_rows=total, dz=self._rows[:n_recv],
+            ops.emb_sparse_apply(bf['skeys'], bf['ssrc'], n_recv, N=1, E=E, total_rows=total, dz=bf['rows'][:n_recv],
                                  opt=opt, tables=t.weight, slot0=t.slot0, slot1=t.slot1, ws=ws)
 
     def backward_cont_w(self, dz, x_cont, g_cont_w, ws):

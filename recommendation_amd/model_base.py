@@ -14,6 +14,7 @@ Extra, optional attributes read from `args` (absent in the reference's argparse 
 from __future__ import annotations
 
 import gc
+import json
 import os
 from collections import OrderedDict
 
@@ -27,24 +28,104 @@ from ._lib import OPT_ADAM
 
 class Saver:
     """Stand-in for tf.train.Saver (DeepFM/DeepFM.py:25, DeepFM/main.py:74-80,129):
-    save(sess, path) / restore(sess, path).  Variables are stored by their reference names
-    (plus optimizer slots and global_step) in one safetensors file at `path`."""
+    save(sess, path) / restore(sess, path).  Variables are stored by their reference names (plus optimizer
+    slots and global_step) in safetensors files.
+
+    One process: one file, `path`.safetensors.  W > 1 ranks (sharded tables): every rank writes its own shard,
+    `path`.rank{r}-of-{W}.safetensors (its table rows and their optimizer slots, plus the replicated dense
+    variables), and rank 0 writes `path`.manifest.json (world size, layout, which rank holds what).  restore()
+    reads whatever layout the checkpoint has and re-shards it into the running model's layout: same layout ->
+    each rank reads its own file; another world size or layout -> each rank assembles its rows from the shard
+    files that hold them, one table at a time."""
 
     def __init__(self, model):
         self.model = model
 
     def save(self, sess, path):
         from safetensors.torch import save_file
-        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        save_file(self.model._state_dict(), path + '.safetensors')
-        with open(os.path.join(os.path.dirname(os.path.abspath(path)), 'checkpoint'), 'w') as f:
-            f.write('model_checkpoint_path: "%s"\n' % os.path.basename(path))
+        m = self.model
+        world, rank = getattr(m, 'world', 1), getattr(m, 'rank', 0)
+        d = os.path.dirname(os.path.abspath(path))
+        os.makedirs(d, exist_ok=True)
+        if world == 1:
+            save_file(m._state_dict(), path + '.safetensors')
+        else:
+            save_file(m._state_dict(), '%s.rank%d-of-%d.safetensors' % (path, rank, world))
+            if rank == 0:
+                with open(path + '.manifest.json', 'w') as f:
+                    json.dump(m._layout(), f)
+        if rank == 0:
+            with open(os.path.join(d, 'checkpoint'), 'w') as f:
+                f.write('model_checkpoint_path: "%s"\n' % os.path.basename(path))
         return path
 
     def restore(self, sess, path):
-        from safetensors.torch import load_file
         self.model._ensure_initialized(sess)
-        self.model._load_state_dict(load_file(path + '.safetensors'))
+        if hasattr(self.model, '_load_checkpoint'):
+            self.model._load_checkpoint(path)
+        else:                                               # single-process model classes with a flat state
+            from safetensors.torch import load_file
+            self.model._load_state_dict(load_file(path + '.safetensors'))
+
+
+class _ShardReader:
+    """Reads table rows (or their optimizer slots) of one field out of a checkpoint in any layout."""
+
+    def __init__(self, path):
+        from safetensors import safe_open
+        self._open = lambda p: safe_open(p, 'pt', device='cpu')
+        self.path = path
+        if os.path.exists(path + '.manifest.json'):
+            with open(path + '.manifest.json') as f:
+                self.layout = json.load(f)
+            W = self.layout['world']
+            self.files = ['%s.rank%d-of-%d.safetensors' % (path, r, W) for r in range(W)]
+        else:
+            self.layout = dict(world=1, shard='table')
+            self.files = [path + '.safetensors']
+        for p in self.files:
+            if not os.path.exists(p):
+                raise FileNotFoundError('checkpoint shard %s is missing' % p)
+        self._handles = {}
+
+    def handle(self, r):
+        if r not in self._handles:
+            self._handles[r] = self._open(self.files[r])
+        return self._handles[r]
+
+    def _one(self, r, f, slot, cate_list):
+        """Rows of field f (weights: slot None; optimizer slot 0/1) held by old rank r, or None if it has no such slot."""
+        h = self.handle(r)
+        name = 'embedding/embed_cate_w_%d' % f
+        if slot is None:
+            return h.get_tensor(name)
+        per_field = 'tables/slot%d/%d' % (slot, f)
+        if per_field in h.keys():
+            return h.get_tensor(per_field)
+        flat = 'tables/slot%d' % slot                      # one-process files keep the slots of all fields in one array
+        if flat in h.keys() and self.layout['world'] == 1:
+            off = int(np.sum(cate_list[:f]))
+            return h.get_slice(flat)[off:off + int(cate_list[f])]
+        return None
+
+    def field(self, f, slot, cate_list):
+        """The WHOLE table of field f ([V_f, E]; weights or an optimizer slot), assembled from the shard files."""
+        lay, W = self.layout, self.layout['world']
+        if W == 1:
+            return self._one(0, f, slot, cate_list)
+        if lay['shard'] == 'table':
+            owner = next(r for r, fs in enumerate(lay['fields_of']) if f in fs)
+            return self._one(owner, f, slot, cate_list)
+        parts = [self._one(r, f, slot, cate_list) for r in range(W)]
+        if parts[0] is None:
+            return None
+        full = torch.empty(int(cate_list[f]), parts[0].shape[1], dtype=parts[0].dtype)
+        for r, part in enumerate(parts):                 # old rank r holds rows (r - f) % W, + W, ...
+            full[(r - f) % W::W] = part
+        return full
+
+    def same_layout(self, layout):
+        return all(self.layout.get(k) == layout.get(k) for k in ('world', 'shard', 'fields_of'))
 
 
 def get_checkpoint_state(directory):
@@ -57,7 +138,7 @@ def get_checkpoint_state(directory):
         line = f.readline()
     name = line.split('"')[1]
     full = os.path.join(directory, name)
-    return full if os.path.exists(full + '.safetensors') else None
+    return full if os.path.exists(full + '.safetensors') or os.path.exists(full + '.manifest.json') else None
 
 
 # Captured graphs are kept until the process ends.  What is known: a graph owns no memory here (_capture asserts that
@@ -184,14 +265,18 @@ class CTRModel:
             from .distributed import RowShardedFront, ShardedFront, TorchComm
             if self.comm is None:
                 self.comm = TorchComm()
-            cls = RowShardedFront if self.shard == 'row' else ShardedFront
-            self.front = cls(self.cate_list, self.embed_size, self.cont_num, self.CONT_EMBED, self.comm, dev)
+            if self.shard == 'row':
+                self.front = RowShardedFront(self.cate_list, self.embed_size, self.cont_num, self.CONT_EMBED, self.comm,
+                                             dev, slack=float(getattr(self.args, 'shard_slack', 1.5)))
+            else:
+                self.front = ShardedFront(self.cate_list, self.embed_size, self.cont_num, self.CONT_EMBED, self.comm, dev)
             self.tables = self.front.t                      # this rank's shard
-            self._own = (0, self.cate_num) if self.shard == 'row' else (self.front.a, self.front.b)
+            # global field number of every local table (row sharding: every rank holds a slice of every field)
+            self._own_fields = list(range(self.cate_num)) if self.shard == 'row' else list(self.front.own_fields)
         else:
             self.tables = EmbeddingTables(self.cate_list, self.embed_size, dev)
             self.front = EmbedFront(self.tables, self.mode, self.cont_num, self.CONT_EMBED)
-            self._own = (0, self.cate_num)
+            self._own_fields = list(range(self.cate_num))
         self.tables.init_slots(self.OPTIMIZER, dense_adam=(self.adam_mode == 'tf1'))
         self.dense.init_slots(self.OPTIMIZER)
         # the two words the host reads back after a step share one buffer (one copy): the loss and the
@@ -203,16 +288,29 @@ class CTRModel:
             self.front.oor_count = self._oor
         rng = np.random.Generator(np.random.PCG64(seed))
         init = OrderedDict()
-        for k, s in self.variable_shapes().items():
+        table_names = set('embedding/embed_cate_w_%d' % i for i in range(self.cate_num))
+        for k, s in self.dense_shapes.items():
             init[k] = truncated_normal(rng, s, self.init_std)
+        shapes = self.variable_shapes()
         if params:
             for k, v in params.items():
-                if k not in init:
+                if k not in shapes:
                     raise KeyError('unknown variable %s' % k)
                 v = np.asarray(v, dtype=np.float32)
-                if tuple(v.shape) != tuple(init[k].shape):
-                    raise ValueError('%s: shape %s != %s' % (k, v.shape, init[k].shape))
+                if tuple(v.shape) != tuple(shapes[k]):
+                    raise ValueError('%s: shape %s != %s' % (k, v.shape, shapes[k]))
                 init[k] = v
+        # tables that were not injected are initialised on the device, shard by shard (a Criteo-1TB-shape shard is
+        # tens of GB: it never exists on the host); same distribution, its own seeded stream per (field, rank)
+        gen = torch.Generator(device=dev)
+        lo = self.init_std * 2.0
+        for fl, f in enumerate(self._own_fields):
+            if 'embedding/embed_cate_w_%d' % f in init:
+                continue
+            gen.manual_seed(int(seed) * 1000003 + f * 7919 + self.rank)
+            t = self.tables.table(fl)
+            if t.numel():
+                torch.nn.init.trunc_normal_(t, 0.0, self.init_std, -lo, lo, generator=gen)
         self.set_params(init)
         self.global_step = 0
         self._ready = True
@@ -232,17 +330,17 @@ class CTRModel:
                 f = int(k.rsplit('_', 1)[1])
                 if self.world > 1 and self.shard == 'row':
                     if t.shape[0] == self.cate_list[f]:     # a full table: keep this rank's rows
-                        t = t[self.rank::self.world]
+                        t = t[(self.rank - f) % self.world::self.world]
                     self.tables.table(f).copy_(t)
-                elif self._own[0] <= f < self._own[1]:
-                    self.tables.table(f - self._own[0]).copy_(t)
+                elif f in self._own_fields:
+                    self.tables.table(self._own_fields.index(f)).copy_(t)
             else:
                 self.dense.p(k).copy_(t.reshape(self.dense.shapes[k]))
 
     def get_params(self):
         out = OrderedDict()
-        for f in range(*self._own):                       # sharded: only the fields this rank owns
-            out['embedding/embed_cate_w_%d' % f] = self.tables.table(f - self._own[0]).cpu().numpy()
+        for fl, f in enumerate(self._own_fields):         # sharded: only the fields (or row slices) this rank owns
+            out['embedding/embed_cate_w_%d' % f] = self.tables.table(fl).cpu().numpy()
         for k in self.dense.shapes:
             out[k] = self.dense.p(k).cpu().numpy()
         return out
@@ -251,27 +349,64 @@ class CTRModel:
         """Dense-variable gradients of the last training step (tables: only with adam_mode 'tf1')."""
         out = OrderedDict((k, self.dense.g(k).cpu().numpy()) for k in self.dense.shapes)
         if self.tables.grad is not None:
-            for f in range(*self._own):
-                out['embedding/embed_cate_w_%d' % f] = self.tables.table(f - self._own[0], self.tables.grad).cpu().numpy()
+            for fl, f in enumerate(self._own_fields):
+                out['embedding/embed_cate_w_%d' % f] = self.tables.table(fl, self.tables.grad).cpu().numpy()
         return out
+
+    def _layout(self):
+        """What a reader needs to find rows in this model's checkpoint shards."""
+        lay = dict(world=self.world, shard=self.shard if self.world > 1 else 'table', cate_list=self.cate_list,
+                   embed_size=self.embed_size, optimizer=self.OPTIMIZER)
+        if self.world > 1 and self.shard == 'table':
+            lay['fields_of'] = [list(fs) for fs in self.front.fields_of]
+        return lay
 
     def _state_dict(self):
         sd = OrderedDict((k, torch.as_tensor(v)) for k, v in self.get_params().items())
         sd['optimization/Variable'] = torch.tensor([self.global_step], dtype=torch.int64)
-        for name, t in (('tables/slot0', self.tables.slot0), ('tables/slot1', self.tables.slot1),
-                        ('dense/slot0', self.dense.slot0), ('dense/slot1', self.dense.slot1)):
+        for name, t in (('dense/slot0', self.dense.slot0), ('dense/slot1', self.dense.slot1)):
             if t is not None:
                 sd[name] = t.detach().cpu()
+        for s, t in enumerate((self.tables.slot0, self.tables.slot1)):
+            if t is None:
+                continue
+            if self.world == 1:
+                sd['tables/slot%d' % s] = t.detach().cpu()
+            else:                                         # per field, so that another layout can pick rows out
+                for fl, f in enumerate(self._own_fields):
+                    sd['tables/slot%d/%d' % (s, f)] = self.tables.table(fl, t).detach().cpu().contiguous()
         return sd
 
-    def _load_state_dict(self, sd):
-        names = set(self.variable_shapes())
-        self.set_params({k: v.numpy() for k, v in sd.items() if k in names})
-        self.global_step = int(sd['optimization/Variable'][0])
-        for name, t in (('tables/slot0', self.tables.slot0), ('tables/slot1', self.tables.slot1),
-                        ('dense/slot0', self.dense.slot0), ('dense/slot1', self.dense.slot1)):
-            if t is not None and name in sd:
-                t.copy_(sd[name])
+    def _local_rows(self, f, full):
+        """This rank's share of the whole table `full` of field f."""
+        if self.world > 1 and self.shard == 'row':
+            return full[(self.rank - f) % self.world::self.world]
+        return full
+
+    def _load_checkpoint(self, path):
+        rd = _ShardReader(path)
+        lay = rd.layout
+        if 'cate_list' in lay and list(lay['cate_list']) != self.cate_list:
+            raise ValueError('checkpoint was written for other table sizes')
+        own = rd.handle(self.rank) if rd.same_layout(self._layout()) else None    # same layout: this rank's own file
+        h0 = rd.handle(0)
+        dense = {k: h0.get_tensor(k).numpy() for k in self.dense.shapes}
+        self.set_params(dense)
+        self.global_step = int(h0.get_tensor('optimization/Variable')[0])
+        for name, t in (('dense/slot0', self.dense.slot0), ('dense/slot1', self.dense.slot1)):
+            if t is not None and name in h0.keys():
+                t.copy_(h0.get_tensor(name))
+        for fl, f in enumerate(self._own_fields):
+            for slot, buf in ((None, self.tables.weight), (0, self.tables.slot0), (1, self.tables.slot1)):
+                if buf is None:
+                    continue
+                if own is not None:
+                    rows = rd._one(self.rank, f, slot, self.cate_list)
+                else:
+                    full = rd.field(f, slot, self.cate_list)
+                    rows = None if full is None else self._local_rows(f, full)
+                if rows is not None:
+                    self.tables.table(fl, buf).copy_(rows)
 
     # ---- step ------------------------------------------------------------------------------
     def _lr(self):
@@ -446,6 +581,7 @@ class CTRModel:
             step = self.train_step_graphed if idx.shape[0] <= GRAPH_MAX_BATCH else self.train_step
             step(idx, xc, yy)
             host = self._scalars.cpu()                  # loss + out-of-range counter in one copy
+            self.check_overflow()
             if self.strict_ids:
                 self._raise_on_bad_ids(int(host[1:].view(torch.int32)[0]))
             return np.float32(host[0].item())
@@ -455,6 +591,11 @@ class CTRModel:
         if self.strict_ids:
             self._raise_on_bad_ids(int(self._oor.item()))
         return np.asarray(yy.cpu().numpy(), dtype=np.float32), pred
+
+    def check_overflow(self):
+        """Row-sharded tables send fixed-capacity buckets; raises if one overflowed since the last check (host sync)."""
+        if hasattr(self.front, 'check_overflow'):
+            self.front.check_overflow()
 
     def out_of_range_lookups(self, reset=True):
         """How many lookups since the last reset carried an id outside [0, V_f) (standard lookup only; they read a

@@ -385,6 +385,17 @@ def shard_route(idx, row_offset, local_offset, W, dest_out, lkey_out):
                                 _ptr(dest_out), _ptr(lkey_out), _stream()), 'ctr_shard_route')
 
 
+def shard_bucket(dest_sorted, perm, lkey, n, W, cap, slot_key, slot_perm, overflow):
+    """Fixed-capacity send buckets (cap slots per destination rank) from lookups sorted by destination."""
+    for t in (dest_sorted, perm, lkey, slot_key, slot_perm, overflow):
+        if t.dtype != torch.int32:
+            raise TypeError('shard_bucket moves int32 words')
+    if slot_key.numel() < W * cap or slot_perm.numel() < W * cap or dest_sorted.numel() < n or perm.numel() < n:
+        raise ValueError('shard_bucket: buffers too small')
+    check(lib().ctr_shard_bucket(_ptr(dest_sorted), _ptr(perm), _ptr(lkey), int(n), int(W), int(cap), _ptr(slot_key),
+                                 _ptr(slot_perm), _ptr(overflow), _stream()), 'ctr_shard_bucket')
+
+
 def _words(t):
     if t.element_size() != 4:
         raise TypeError('rows_gather / rows_scatter move 32-bit words')

@@ -44,7 +44,8 @@ class TorchBackend:
         x = idx.long()
         V = (row_offset[1:] - row_offset[:-1]).view(1, F)
         ok = (x >= 0) & (x < V)
-        d = torch.where(ok, x % W, torch.arange(F).view(1, F).expand(B, F) % W)
+        fcol = torch.arange(F).view(1, F).expand(B, F)
+        d = torch.where(ok, (x + fcol) % W, fcol % W)
         key = torch.where(ok, local_offset.long()[d, torch.arange(F).view(1, F).expand(B, F)] + x // W,
                           torch.full_like(x, -1))
         dest_out[:B * F] = d.reshape(-1).int()
@@ -56,15 +57,32 @@ class TorchBackend:
 
     def rows_gather(self, src, perm, n, out, *, F, E):
         p = perm[:n].long()
+        live = p >= 0                                # -1 = an empty slot: zero row
+        ps = torch.where(live, p, torch.zeros_like(p))
         flat = out.view(-1)
         for e in range(E):
-            flat[torch.arange(n) * E + e] = src[p // F, (p % F) * E + e]
+            v = src[ps // F, (ps % F) * E + e]
+            flat[torch.arange(n) * E + e] = torch.where(live, v, torch.zeros_like(v))
 
     def rows_scatter(self, rows, perm, n, dst, *, F, E):
         p = perm[:n].long()
-        r = rows.reshape(-1, E)
+        live = p >= 0
+        r = rows.reshape(-1, E)[:n][live]
+        p = p[live]
         for e in range(E):
-            dst[p // F, (p % F) * E + e] = r[:n, e]
+            dst[p // F, (p % F) * E + e] = r[:, e]
+
+    def shard_bucket(self, dest_sorted, perm, lkey, n, W, cap, slot_key, slot_perm, overflow):
+        slot_key[:W * cap] = -1
+        slot_perm[:W * cap] = -1
+        d = dest_sorted[:n].long()
+        start = torch.searchsorted(d, torch.arange(W))
+        r = torch.arange(n) - start[d]
+        ok = r < cap
+        slot = (d * cap + r)[ok]
+        slot_key[slot] = lkey[perm[:n].long()[ok]]
+        slot_perm[slot] = perm[:n][ok]
+        overflow += int((~ok).sum())
 
     def copy2d(self, src, dst, accumulate=False):
         dst[:, :src.shape[1]] = src
@@ -91,7 +109,7 @@ class TorchBackend:
         for f in range(idx.shape[1]):
             off = int(self._off[f])
             ok = idx[:, f] >= 0
-            tables.index_add_(0, off + idx[ok, f].long(), -opt.lr * dz[ok, f * E:(f + 1) * E])
+            tables.index_add_(0, off + idx[ok, f].long(), -opt.lr * dz[:idx.shape[0]][ok, f * E:(f + 1) * E])
 
 
 def p2p_all_to_all(out, inp, out_splits, in_splits, rank, world):
@@ -112,7 +130,7 @@ def p2p_all_to_all(out, inp, out_splits, in_splits, rank, world):
 def _worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from recommendation_amd.distributed import ShardedFront, field_ranges
+    from recommendation_amd.distributed import ShardedFront, pack_fields
 
     class Comm:
         def __init__(self):
@@ -128,9 +146,9 @@ def _worker(rank, world, port, ret):
     rng = np.random.default_rng(0)                       # same tables on both ranks
     full = [torch.tensor(rng.standard_normal((v, E)), dtype=torch.float32) for v in cards]
     front = ShardedFront(cards, E, C, False, Comm(), torch.device('cpu'), backend=TorchBackend())
-    a, b = front.a, front.b
-    assert (a, b) == field_ranges(5, world)[rank]
-    front.t.weight.copy_(torch.cat(full[a:b]))
+    own = front.own_fields
+    assert own == pack_fields(cards, world)[rank] and own == ([1, 2] if rank == 0 else [0, 3, 4])
+    front.t.weight.copy_(torch.cat([full[f] for f in own]))
     r2 = np.random.default_rng(100 + rank)               # different batch per rank
     idx = torch.tensor(np.stack([r2.integers(0, v, B) for v in cards], 1), dtype=torch.int32)
     xc = torch.tensor(r2.standard_normal((B, C)), dtype=torch.float32)
@@ -145,11 +163,11 @@ def _worker(rank, world, port, ret):
     all_dz = [torch.zeros_like(dz) for _ in range(world)]
     dist.all_gather(all_idx, idx)
     dist.all_gather(all_dz, dz)
-    for f in range(a, b):
+    for fl, f in enumerate(own):
         exp = full[f].clone()
         for i2, d2 in zip(all_idx, all_dz):
             exp.index_add_(0, i2[:, f].long(), -0.5 * d2[:, f * E:(f + 1) * E])
-        got = front.t.table(f - a)
+        got = front.t.table(fl)
         assert torch.allclose(got, exp, atol=1e-6), (rank, f)
     dist.barrier()
     dist.destroy_process_group()
@@ -164,7 +182,9 @@ def _row_worker(rank, world, port, ret):
         def __init__(self):
             self.world, self.rank = world, rank
 
-        def all_to_all(self, out, inp, out_splits, in_splits):
+        def all_to_all(self, out, inp, out_splits=None, in_splits=None):
+            out_splits = out_splits or [out.shape[0] // world] * world
+            in_splits = in_splits or [inp.shape[0] // world] * world
             p2p_all_to_all(out, inp, out_splits, in_splits, rank, world)
 
     cards, E, C, B = [5, 9, 1, 7, 3], 4, 2, 6               # field 2 has one row: rank 1 owns none of it
@@ -174,8 +194,8 @@ def _row_worker(rank, world, port, ret):
     loc_cards, _ = row_shard_layout(cards, world)
     assert [sum(c[f] for c in loc_cards) for f in range(5)] == cards
     for f in range(5):
-        assert list(front.local_rows(f)) == list(range(rank, cards[f], world))
-        front.t.table(f).copy_(full[f][rank::world])
+        assert list(front.local_rows(f)) == [r for r in range(cards[f]) if (r + f) % world == rank]
+        front.t.table(f).copy_(full[f][(rank - f) % world::world])
     r2 = np.random.default_rng(100 + rank)
     idx = torch.tensor(np.stack([r2.integers(0, v, B) for v in cards], 1), dtype=torch.int32)
     idx[0, 1] = 99                                           # out of range: zero row, no update
@@ -198,7 +218,16 @@ def _row_worker(rank, world, port, ret):
         for i2, d2 in zip(all_idx, all_dz):
             ok = i2[:, f] < cards[f]
             exp.index_add_(0, i2[ok, f].long(), -0.5 * d2[ok, f * E:(f + 1) * E])
-        assert torch.allclose(front.t.table(f), exp[rank::world], atol=1e-6), (rank, f)
+        assert torch.allclose(front.t.table(f), exp[(rank - f) % world::world], atol=1e-6), (rank, f)
+    assert int(front.overflow) == 0
+    # a bucket that cannot hold its share is counted, not silently dropped
+    tight = RowShardedFront(cards, E, C, False, Comm(), torch.device('cpu'), backend=TorchBackend(), slack=0.1)
+    tight.capacity = lambda B: 1
+    hot = torch.zeros(B, len(cards), dtype=torch.int32)     # every lookup of a field goes to one rank
+    tight.forward(hot, xc, z_out=torch.zeros_like(z), cont_tail=True)
+    assert int(tight.overflow) > 0
+    with pytest.raises(RuntimeError):
+        tight.check_overflow()
     dist.barrier()
     dist.destroy_process_group()
 
@@ -211,8 +240,14 @@ def test_sharded_front_plan_world2():
     mp.spawn(_worker, args=(2, 29741, None), nprocs=2, join=True)
 
 
-def test_field_ranges():
-    from recommendation_amd.distributed import field_ranges
-    assert field_ranges(26, 8) == [(0, 4), (4, 8), (8, 11), (11, 14), (14, 17), (17, 20), (20, 23), (23, 26)]
-    assert field_ranges(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
-    assert field_ranges(5, 1) == [(0, 5)]
+def test_pack_fields_balances_rows():
+    from recommendation_amd.distributed import pack_fields
+    from recommendation_amd.synthetic import CRITEO_1TB
+    packs = pack_fields(CRITEO_1TB, 8)
+    assert sorted(f for p in packs for f in p) == list(range(26))
+    loads = [sum(CRITEO_1TB[f] for f in p) for p in packs]
+    big = [f for f in range(26) if CRITEO_1TB[f] > 100_000_000]          # four tables above 100 M rows
+    assert len({next(j for j, p in enumerate(packs) if f in p) for f in big}) == 4
+    assert max(loads) == max(CRITEO_1TB)                                 # the largest table alone sets the maximum
+    assert pack_fields([5, 9, 4, 7, 3], 2) == [[1, 2], [0, 3, 4]]
+    assert pack_fields([3, 2, 1], 4) == [[0], [1], [2], []]

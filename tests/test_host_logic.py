@@ -67,3 +67,56 @@ def test_workspace_keeps_outgrown_buffers():
     p2, n2 = ws.get(n1 + 1)
     assert n2 >= 2 * n1 and p2.value != p1.value
     assert [b.data_ptr() for b in ws.retired] == [p1.value]
+
+
+def test_checkpoint_shard_reader_reassembles_tables_from_any_layout(tmp_path):
+    """Per-rank shard files + manifest (written here by hand in the documented layout): whole tables come back
+    from a row-sharded, a table-sharded and a one-process checkpoint."""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    from recommendation_amd.model_base import _ShardReader, get_checkpoint_state
+    from recommendation_amd.distributed import pack_fields, row_shard_layout
+    cards, E = [5, 9, 1, 7], 2
+    rng = np.random.default_rng(0)
+    full = [torch.tensor(rng.standard_normal((v, E)), dtype=torch.float32) for v in cards]
+    slot = [t * 2 for t in full]
+    # row layout, W = 3: rank r holds rows with (row + f) % 3 == r
+    W = 3
+    loc, _ = row_shard_layout(cards, W)
+    p = str(tmp_path / 'row.ckpt')
+    for r in range(W):
+        sd = {'optimization/Variable': torch.tensor([4])}
+        for f in range(4):
+            sd['embedding/embed_cate_w_%d' % f] = full[f][(r - f) % W::W].contiguous()
+            sd['tables/slot0/%d' % f] = slot[f][(r - f) % W::W].contiguous()
+            assert sd['embedding/embed_cate_w_%d' % f].shape[0] == loc[r][f]
+        save_file(sd, '%s.rank%d-of-%d.safetensors' % (p, r, W))
+    json.dump(dict(world=W, shard='row', cate_list=cards, embed_size=E), open(p + '.manifest.json', 'w'))
+    rd = _ShardReader(p)
+    for f in range(4):
+        assert torch.equal(rd.field(f, None, cards), full[f]) and torch.equal(rd.field(f, 0, cards), slot[f])
+        assert rd.field(f, 1, cards) is None
+    # table layout, W = 2
+    p2 = str(tmp_path / 'tab.ckpt')
+    packs = pack_fields(cards, 2)
+    for r in range(2):
+        sd = {'embedding/embed_cate_w_%d' % f: full[f] for f in packs[r]}
+        sd.update({'tables/slot0/%d' % f: slot[f] for f in packs[r]})
+        save_file(sd, '%s.rank%d-of-2.safetensors' % (p2, r))
+    json.dump(dict(world=2, shard='table', cate_list=cards, embed_size=E, fields_of=packs), open(p2 + '.manifest.json', 'w'))
+    rd = _ShardReader(p2)
+    assert all(torch.equal(rd.field(f, None, cards), full[f]) and torch.equal(rd.field(f, 0, cards), slot[f]) for f in range(4))
+    assert rd.same_layout(dict(world=2, shard='table', fields_of=packs)) and not rd.same_layout(dict(world=2, shard='row'))
+    # one process: flat slot array
+    p3 = str(tmp_path / 'one.ckpt')
+    sd = {'embedding/embed_cate_w_%d' % f: full[f] for f in range(4)}
+    sd['tables/slot0'] = torch.cat(slot)
+    save_file(sd, p3 + '.safetensors')
+    rd = _ShardReader(p3)
+    assert all(torch.equal(rd.field(f, 0, cards), slot[f]) for f in range(4))
+    open(str(tmp_path / 'checkpoint'), 'w').write('model_checkpoint_path: "row.ckpt"\n')
+    assert get_checkpoint_state(str(tmp_path)) == p
+    with pytest.raises(FileNotFoundError):
+        os.remove('%s.rank1-of-3.safetensors' % p)
+        _ShardReader(p)
