@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Headline benchmark: DeepFM training step on Criteo-Kaggle-shape synthetic data.
+"""Headline benchmark: DeepFM training step on Criteo-Kaggle-shape synthetic data (and, at N = 1, the DCN step at
+the Criteo-1TB per-GPU share beside it).
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -11,6 +12,7 @@ Rank 0 prints ONE JSON line (see README/DESIGN for the fields).
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -25,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 PROFILE_STEPS = 5
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec
+HBM_COPY_GBS = 6290.0          # what a streaming copy reaches on this part (the achievable ceiling)
 MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA (exact fp32) dense peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak; the split GEMM spends 6 bf16 MFMAs per fp32 product
 
@@ -46,6 +49,7 @@ def parse():
                          '(r + f) %% N (default for DCN: its Criteo-1TB tables do not fit one owner)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timers', action='store_true')
+    ap.add_argument('--no-dcn', action='store_true', help='N = 1, DeepFM: skip the DCN leg reported under "dcn"')
     return ap.parse_args()
 
 
@@ -63,66 +67,250 @@ MODEL_ARGS = {
 }
 
 
-def build_model(args, sess, cards, rank, world):
+def build_model(variant, embed, shard, comm, sess, cards, rank, world):
     import importlib
     import recommendation_amd as ra
     ra.enable_zoo_imports()
-    name = args.model.split('_')[0]
-    margs = SimpleNamespace(embed_size=args.embed, regular_rate=0.1, learning_rate=0.001, decay_steps=10000,
-                            decay_rate=0.99, mode='S', adam_mode='lazy', init_std=0.01, **MODEL_ARGS[args.model])
+    name = variant.split('_')[0]
+    margs = SimpleNamespace(embed_size=embed, regular_rate=0.1, learning_rate=0.001, decay_steps=10000,
+                            decay_rate=0.99, mode='S', adam_mode='lazy', init_std=0.01, **MODEL_ARGS[variant])
     cls = getattr(importlib.import_module('%s.%s' % (name, name)), name)
     if world > 1:
-        margs.world_size, margs.rank, margs.shard = world, rank, args.shard
-        if args.comm == 'host-staged':
+        margs.world_size, margs.rank, margs.shard = world, rank, shard
+        if comm == 'host-staged':
             from recommendation_amd.distributed import HostStagedComm
             margs.comm = HostStagedComm()
     m = cls(margs, len(cards), 13, cards)
     m.build()
     m.initialize(sess, seed=1234)
+    if name == 'AFM':
+        # AFM feeds log_loss an un-squashed y_out (AFM/AFM.py:85-88): with weights of both signs y_out goes negative
+        # and the loss is NaN.  Positive weights (and positive dense inputs, below) keep 0 < y_out < 1, so the step
+        # that is timed trains on finite numbers.
+        m.tables.weight.abs_()
+        m.dense.flat.abs_()
     return m
 
 
 def cpu_baseline(args, cards):
-    """The oracle (CPU restatement of the reference graph; TensorFlow is unavailable) timed on
-    the host's cores on a bounded sample of the same workload."""
+    """The oracle (CPU restatement of the reference graph; TensorFlow is unavailable) timed on the host's cores on
+    bounded samples: (c1) the reference's own CPU case exactly as its graph executes it - reference-exact embedding
+    block with the dense [B, sum(V), E] tensors, B = 1024, 26 x 101 + 13 fields, E = 8, TF-1.x Adam; and the headline
+    workload's shape scaled to the host (standard lookup, tables 1/64, B = 4096, row-wise Adam as on the GPU)."""
     from oracle import ctr_oracle as O
     from recommendation_amd.synthetic import scaled
     threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
-    div = 64
-    small = scaled(cards, div)
-    B = 4096
-    cfg = O.default_cfg('DeepFM', embed_size=args.embed, mode='S')
-    cfg.cate_num, cfg.cont_num, cfg.cate_list = len(small), 13, small
+
+    def timed(m, batch, budget_s, max_steps):
+        m.run(*batch, True)
+        t0 = time.perf_counter()
+        n = 0
+        while n < 3 or (time.perf_counter() - t0 < budget_s and n < max_steps):
+            m.run(*batch, True)
+            n += 1
+        return n, time.perf_counter() - t0
+
     rng = np.random.default_rng(0)
-    P = O.init_params('DeepFM', cfg, seed=0)
-    m = O.OracleModel('DeepFM', cfg, P, dtype=torch.float32)
-    Xc = np.stack([rng.integers(0, v, B) for v in small], 1)
-    Xf = rng.standard_normal((B, 13)).astype(np.float32)
-    y = rng.integers(0, 2, B)
-    m.run(Xc, Xf, y, True)
-    t0 = time.perf_counter()
-    n = 0
-    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 50):
-        m.run(Xc, Xf, y, True)
-        n += 1
-    dt = time.perf_counter() - t0
-    return dict(value=B * n / dt, unit='samples/s', cores=threads, kind='port',
-                sample='CPU restatement of the reference graph (TensorFlow unavailable): DeepFM S-mode, '
-                       'torch-CPU fp32, B=%d, %d steps, table rows scaled 1/%d (sum V=%d), TF1 dense Adam'
-                       % (B, n, div, int(np.sum(small))))
+    # c1: DeepFM/main.py defaults on 26 categorical fields of 101 values + 13 continuous
+    c1 = O.default_cfg('DeepFM', embed_size=8, mode='R')
+    c1.cate_num, c1.cont_num, c1.cate_list = 26, 13, [101] * 26
+    m1 = O.OracleModel('DeepFM', c1, O.init_params('DeepFM', c1, seed=0), dtype=torch.float32)
+    b1 = (rng.integers(0, 101, (1024, 26)), rng.standard_normal((1024, 13)).astype(np.float32), rng.integers(0, 2, 1024))
+    n1, dt1 = timed(m1, b1, 8.0, 40)
+    del m1
+    div, B = 64, 4096
+    small = scaled(cards, div)
+    cfg = O.default_cfg('DeepFM', embed_size=args.embed, mode='S')
+    cfg.cate_num, cfg.cont_num, cfg.cate_list, cfg.adam_mode = len(small), 13, small, 'lazy'
+    m = O.OracleModel('DeepFM', cfg, O.init_params('DeepFM', cfg, seed=0), dtype=torch.float32)
+    b2 = (np.stack([rng.integers(0, v, B) for v in small], 1), rng.standard_normal((B, 13)).astype(np.float32),
+          rng.integers(0, 2, B))
+    n2, dt2 = timed(m, b2, 10.0, 50)
+    return dict(value=B * n2 / dt2, unit='samples/s', cores=threads, kind='port',
+                sample='CPU restatement of the reference graph (TensorFlow unavailable): DeepFM standard lookup, '
+                       'torch-CPU fp32, B=%d, %d steps, table rows scaled 1/%d (sum V=%d), row-wise Adam'
+                       % (B, n2, div, int(np.sum(small))),
+                c1=dict(value=1024 * n1 / dt1, unit='samples/s', cores=threads, kind='port',
+                        sample='BASELINE configs[0] as the reference graph executes it: reference-exact embedding block '
+                               '(dense [1024, 2626, 8] tensors), 26 x 101 + 13 fields, E=8, default tower, TF-1.x Adam, '
+                               'torch-CPU fp32, %d steps' % n1))
 
 
-def load_traffic():
-    """HBM bytes per launch from the committed rocprofv3 PMC pass (FETCH_SIZE/WRITE_SIZE collected in
-    separate runs, gfx950 x2 read correction; see tools/pmc_summary.py), keyed by kernel symbol."""
-    path = os.path.join(ROOT, 'profiles', 'r01_g_deepfm_c2_pmc_traffic.json')
+def load_traffic(model):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this model's bench run (FETCH_SIZE / WRITE_SIZE
+    collected in separate runs, gfx950 x2 read correction; tools/pmc_summary.py), keyed by kernel symbol; the newest
+    profiles/*_<model>_*pmc_traffic.json wins.  Empty when no pass of this model is committed."""
+    tag = {'DeepFM': 'deepfm', 'DCN': 'dcn'}.get(model)
     out = {}
-    if os.path.exists(path):
-        for k, v in json.load(open(path)).items():
-            for sym in ('embed_fwd_kernel', 'sparse_apply_kernel', 'embed_bwd_dz_kernel'):
+    if tag is None:
+        return out
+    paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_%s_*pmc_traffic.json' % tag)))
+    if paths:
+        for k, v in json.load(open(paths[-1])).items():
+            for sym in ('embed_fwd_kernel', 'sparse_apply_kernel', 'embed_bwd_dz_kernel', 'cross_fwd_kernel',
+                        'cross_bwd_kernel'):
                 if sym + '<' in k or sym + '(' in k:
                     out[sym] = out.get(sym, 0) + v['hbm_bytes_per_launch']
+        out['_file'] = os.path.basename(paths[-1])
+    return out
+
+
+def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embed, shard):
+    """Builds the model, warms up, profiles per operator (untimed), then times `steps` steps.  Returns the result dict
+    (rank 0) or None."""
+    from recommendation_amd import ops
+    from recommendation_amd.synthetic import CRITEO_1TB, CRITEO_KAGGLE, make_batches, scaled
+    dev = sess.device
+    is_dcn = variant == 'DCN'
+    # DeepFM: BASELINE configs[1] (Criteo-Kaggle cardinalities).  DCN: configs[2] per-GPU share —
+    # Criteo-1TB cardinalities / 8 (one GPU of the 8-GPU shard), dim 64, 6 cross layers, 1024x3 tower.
+    cards = CRITEO_KAGGLE if not is_dcn else scaled(CRITEO_1TB, 8 // min(world, 8))
+    shape_name = 'Criteo-Kaggle' if not is_dcn else 'Criteo-1TB/%d' % (8 // min(world, 8))
+    if rank == 0:
+        print('[bench] building %s: %d table rows on %d rank(s)' % (variant, sum(cards), world), file=sys.stderr, flush=True)
+    model = build_model(variant, embed, shard, args.comm, sess, cards, rank, world)
+    B = batch
+    batches = make_batches(cards, 13, B, 8, args.alpha, 20240601 + rank, dev)
+    if variant.startswith('AFM'):
+        batches = [(i, x.abs_().mul_(0.1), y) for i, x, y in batches]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # distinct table rows touched per step (for the algorithmic bytes of the sparse update)
+    offs = torch.as_tensor(np.concatenate([[0], np.cumsum(cards)[:-1]]), device=dev)
+    uniq = float(np.mean([torch.unique(b[0].to(torch.int64) + offs).numel() for b in batches]))
+    if rank == 0:
+        print('[bench] %s warm-up' % variant, file=sys.stderr, flush=True)
+    for i in range(warmup):
+        model.train_step(*batches[i % len(batches)])
+    # Untimed profiling pass: every operator between HIP events, to split the step by kernel and to
+    # find the dominant one.  The timed region then keeps events only around that kernel and the
+    # embedding / interaction kernels (a pair of events per operator costs ~10 % of a 1 ms step).
+    profile, timer, dom_name = None, None, None
+    watched = {'embed_fwd', 'emb_sparse_apply', 'cross_fwd', 'cross_bwd'}
+    if not args.no_kernel_timers:
+        prof = ops.KernelTimer(pool=PROFILE_STEPS * 200)
+        ops.set_timer(prof)
+        sess.side_enabled = False      # one stream: every operator's time is its own, not a shared GPU's
+        for i in range(PROFILE_STEPS):
+            model.train_step(*batches[i % len(batches)])
+        sess.side_enabled = True
+        ops.set_timer(None)
+        profile = prof.summary()
+        dom_name = max(profile, key=lambda n: profile[n]['total_ms'])
+        timer = ops.KernelTimer(only=watched | {dom_name}, pool=steps * 12)
+        ops.set_timer(timer)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        model.train_step(*batches[i % len(batches)])
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.set_timer(None)
+    loss = float(model._loss_dev.item())
+    model.check_overflow()      # row-sharded tables: a fixed-capacity send bucket that overflowed is an error
+    if world > 1:
+        t = torch.tensor([dt], device='cpu' if args.comm == 'host-staged' else dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return None
+    out = dict(value=world * B * steps / dt, unit='samples/s', steps=steps, warmup=warmup, ms_per_step=1e3 * dt / steps,
+               config=dict(workload='%s %s shape: 13 dense + 26 sparse fields, sum(V)=%d rows, '
+                                    'embed dim %d, per-GPU batch %d, Zipf(%.2f) ids, fwd+bwd+Adam (sparse rows: '
+                                    'row-wise Adam on touched rows), dropout at the reference rates'
+                                    % (variant, shape_name, int(np.sum(cards)), embed, B, args.alpha),
+                           global_batch=world * B,
+                           parallelism='dp%d + %s-sharded tables' % (world, shard) if world > 1 else 'single'),
+               final_loss=loss if np.isfinite(loss) else None)
+    if timer is None:
+        return out
+    ks = timer.summary()
+    F, E = len(cards), embed
+    D = F * E + 13
+    traffic = load_traffic(variant)
+    from recommendation_amd import _lib
+    gemm_mode = int(_lib.load().ctr_get_gemm_mode())
+    # algorithmic HBM bytes per launch (per sample: ids + row read + row write for the gather; key + src + gradient
+    # row per lookup and read + write of W, m, v per unique row for the update; x0 in / x_L out for the cross forward,
+    # x0, g in and dx0 read-modify-write for its backward; the pair sort: 8-byte pairs written once, then read and
+    # written once per radix pass)
+    algo = {'embed_fwd': F * (4 + E * 4 + E * 4) * B,
+            'emb_sparse_apply': int(F * B * (8 + E * 4) + uniq * 6 * E * 4),
+            'embed_bwd_dz': 3 * F * E * 4 * B,
+            'emb_sort': F * B * (4 + 8 + 3 * 16),
+            'cross_fwd': 2 * D * 4 * B, 'cross_bwd': 4 * D * 4 * B}
+    sym = {'embed_fwd': 'embed_fwd_kernel', 'emb_sparse_apply': 'sparse_apply_kernel', 'cross_fwd': 'cross_fwd_kernel',
+           'cross_bwd': 'cross_bwd_kernel', 'embed_bwd_dz': 'embed_bwd_dz_kernel'}
+    label = {'embed_fwd': 'embed_fwd_kernel (gather + FM first/second order + concat)',
+             'emb_sparse_apply': 'sparse_apply_kernel (+tail): segment-reduce + row-wise Adam',
+             'cross_fwd': 'cross_fwd_kernel (all cross layers, one pass)',
+             'cross_bwd': 'cross_bwd_kernel (+ the fixed-order dw/db reduction)'}
+
+    def hbm_roof(name, avg_us):
+        nbytes = algo[name]
+        ach = nbytes / (avg_us * 1e-6) / 1e9
+        return dict(kernel=label.get(name, name), bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=ach / HBM_PEAK_GBS, frac_of_measured_copy_peak=ach / HBM_COPY_GBS,
+                    traffic=traffic.get(sym.get(name)), avg_us=avg_us, bytes_per_launch=nbytes)
+
+    def mfma_roof(name, M, N, K, avg_us):
+        # fp32-equivalent flops against the dense fp32 MFMA peak (the path's dtype).  In split mode the
+        # kernel issues six bf16 MFMAs per fp32 product, so what it occupies of the matrix cores is
+        # 6 * achieved / bf16 peak, reported beside it.
+        ach = 2.0 * M * N * K / (avg_us * 1e-6) / 1e12
+        split = gemm_mode == 1
+        r = dict(kernel=name + (' (fp32 via 3-way bf16 split, 6 bf16 MFMAs per product)' if split else ' (fp32 MFMA)'),
+                 bound='mfma', achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
+                 frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=None, avg_us=avg_us)
+        if split:
+            r['bf16_pipe_frac'] = 6.0 * ach / MFMA_BF16_PEAK_TFLOPS
+        return r
+
+    def roof_of(name):
+        k = ks[name]
+        if name in algo:
+            return hbm_roof(name, k['avg_us'])
+        if name.startswith('gemm_') or name.startswith('wgrad_'):
+            M, N, K = [int(v) for v in name.split('_')[1].split('x')]
+            return mfma_roof(name, M, N, K, k['avg_us'])
+        return dict(kernel=name, bound='hbm', achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None,
+                    traffic=None, avg_us=k['avg_us'])
+
+    out['roofline'] = roof_of(dom_name)
+    out['roofline_emb'] = roof_of('embed_fwd') if 'embed_fwd' in ks else None
+    out['roofline_emb_bwd'] = roof_of('emb_sparse_apply') if 'emb_sparse_apply' in ks else None
+    if out['roofline_emb_bwd'] and 'emb_sparse_apply' in profile:
+        # in the timed region the sparse update shares the GPU with the tower weight gradients (side
+        # stream); its launch time alone on the GPU comes from the single-stream profiling pass
+        r = out['roofline_emb_bwd']
+        alone_us = 1e3 * profile['emb_sparse_apply']['total_ms'] / max(profile['emb_sparse_apply']['calls'], 1)
+        r['shares_gpu_with'] = 'tower weight gradients (side stream)'
+        r['alone_avg_us'] = alone_us
+        r['alone_frac'] = r['bytes_per_launch'] / (alone_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+    for name in ('cross_fwd', 'cross_bwd'):
+        if name in ks:
+            out['roofline_' + name] = roof_of(name)
+    # the whole embedding path of a step (gather, dZ, pair sort, segment-reduce + row update), single-stream times
+    # of the profiling pass: algorithmic bytes of the pieces over their summed time
+    path = [n for n in ('embed_fwd', 'embed_bwd_dz', 'emb_sort', 'emb_sparse_apply') if n in profile]
+    if path:
+        us = {n: 1e3 * profile[n]['total_ms'] / PROFILE_STEPS for n in path}
+        tot_b, tot_us = sum(algo[n] for n in path), sum(us.values())
+        ach = tot_b / (tot_us * 1e-6) / 1e9
+        out['roofline_emb_path'] = dict(kernels=path, bound='hbm', bytes_per_step=tot_b, us_per_step=tot_us, achieved=ach,
+                                        peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
+                                        frac_of_measured_copy_peak=ach / HBM_COPY_GBS,
+                                        us={n: round(v, 2) for n, v in us.items()})
+    out['pmc_traffic_file'] = traffic.get('_file')
+    out['unique_rows_per_step'] = uniq
+    out['profile_steps'] = PROFILE_STEPS
+    out['kernel_ms_per_step'] = {n: round(v['total_ms'] / PROFILE_STEPS, 4) for n, v in
+                                 sorted(profile.items(), key=lambda kv: -kv[1]['total_ms'])}
     return out
 
 
@@ -144,13 +332,12 @@ def main():
                              % (args.gpus, args.gpus))
         raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
     import recommendation_amd as ra
-    from recommendation_amd import ops
-    from recommendation_amd.synthetic import CRITEO_1TB, CRITEO_KAGGLE, make_batches, scaled
 
     if args.comm == 'host-staged':
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = 'cuda:%d' % local_rank
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if args.comm == 'host-staged':
@@ -158,135 +345,33 @@ def main():
         else:
             dist.init_process_group('nccl', device_id=torch.device(dev))
     sess = ra.Session(dev, seed=11 + rank)
-    # DeepFM: BASELINE configs[1] (Criteo-Kaggle cardinalities).  DCN: configs[2] per-GPU share —
-    # Criteo-1TB cardinalities / 8 (one GPU of the 8-GPU shard), dim 64, 6 cross layers, 1024x3 tower.
-    cards = CRITEO_KAGGLE if args.model != 'DCN' else scaled(CRITEO_1TB, 8 // min(world, 8))
-    shape_name = 'Criteo-Kaggle' if args.model != 'DCN' else 'Criteo-1TB/%d' % (8 // min(world, 8))
-    if rank == 0:
-        print('[bench] building %s: %d table rows on %d rank(s)' % (args.model, sum(cards), world), file=sys.stderr, flush=True)
-    model = build_model(args, sess, cards, rank, world)
-    if rank == 0:
-        print('[bench] model built, generating batches', file=sys.stderr, flush=True)
-    B = args.batch
-    batches = make_batches(cards, 13, B, 8, args.alpha, 20240601 + rank, dev)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # distinct table rows touched per step (for the algorithmic bytes of the sparse update)
-    offs = torch.as_tensor(np.concatenate([[0], np.cumsum(cards)[:-1]]), device=dev)
-    uniq = float(np.mean([torch.unique(b[0].to(torch.int64) + offs).numel() for b in batches]))
-    if rank == 0:
-        print('[bench] warm-up', file=sys.stderr, flush=True)
-    for i in range(args.warmup):
-        model.train_step(*batches[i % len(batches)])
-    # Untimed profiling pass: every operator between HIP events, to split the step by kernel and to
-    # find the dominant one.  The timed region then keeps events only around that kernel and the two
-    # embedding kernels (a pair of events per operator costs ~10 % of a 1.5 ms step).
-    profile, timer = None, None
-    if not args.no_kernel_timers:
-        prof = ops.KernelTimer(pool=PROFILE_STEPS * 160)
-        ops.set_timer(prof)
-        sess.side_enabled = False      # one stream: every operator's time is its own, not a shared GPU's
-        for i in range(PROFILE_STEPS):
-            model.train_step(*batches[i % len(batches)])
-        sess.side_enabled = True
-        ops.set_timer(None)
-        profile = prof.summary()
-        dom_name = max(profile, key=lambda n: profile[n]['total_ms'])
-        timer = ops.KernelTimer(only={dom_name, 'embed_fwd', 'emb_sparse_apply'}, pool=args.steps * 8)
-        ops.set_timer(timer)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        model.train_step(*batches[i % len(batches)])
-    barrier()
-    dt = time.perf_counter() - t0
-    ops.set_timer(None)
-    loss = float(model._loss_dev.item())
-    model.check_overflow()      # row-sharded tables: a fixed-capacity send bucket that overflowed is an error
-    if world > 1:
-        t = torch.tensor([dt], device='cpu' if args.comm == 'host-staged' else dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    res = run_model(args.model, args, sess, rank, world, dist, args.steps, args.warmup, args.batch, args.embed, args.shard)
+    dcn = None
+    if world == 1 and args.model == 'DeepFM' and not args.no_dcn:
+        # the metric names DeepFM and DCN: the DCN step at BASELINE configs[2]'s per-GPU share rides along (its own
+        # tables, its own timed region after the headline's), reported under "dcn"
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        dcn = run_model('DCN', args, sess, rank, world, dist, max(args.steps, 20), max(args.warmup, 3), 8192, 64, 'row')
+        gc.collect()
+        torch.cuda.empty_cache()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-    value = world * B * args.steps / dt
     out = dict(metric='train samples/sec (node) DeepFM+DCN Criteo-shape; % HBM roofline on emb kernels',
-               value=value, unit='samples/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
-               ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling='weak', vs_baseline=None,
+               value=res['value'], unit='samples/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=res['ms_per_step'], higher_is_better=True, scaling='weak', vs_baseline=None,
                dtype='f32', data='synthetic',
                gemm_arithmetic='fp32 result from 6 bf16 MFMAs per product (exact 3-way split, fp32 accumulate; '
-                               '~1e-7 relative)',
-               config=dict(workload='%s %s shape: 13 dense + 26 sparse fields, sum(V)=%d rows, '
-                                    'embed dim %d, per-GPU batch %d, Zipf(%.2f) ids, fwd+bwd+Adam (sparse rows: '
-                                    'row-wise Adam on touched rows), dropout at the reference rates'
-                                    % (args.model, shape_name, int(np.sum(cards)), args.embed, B, args.alpha),
-                           global_batch=world * B, parallelism='dp%d + %s-sharded tables' % (world, args.shard) if world > 1 else 'single'),
-               final_loss=loss if np.isfinite(loss) else None)
-    if timer is not None:
-        ks = timer.summary()
-        F, E = len(cards), args.embed
-        traffic = load_traffic()
-        from recommendation_amd import _lib
-        gemm_mode = int(_lib.load().ctr_get_gemm_mode())
-
-        def hbm_roof(name, kernel, nbytes, avg_us, sym):
-            ach = nbytes / (avg_us * 1e-6) / 1e9
-            return dict(kernel=kernel, bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=ach / HBM_PEAK_GBS, traffic=traffic.get(sym), avg_us=avg_us, bytes_per_launch=nbytes)
-
-        def mfma_roof(name, M, N, K, avg_us):
-            # fp32-equivalent flops against the dense fp32 MFMA peak (the path's dtype).  In split mode the
-            # kernel issues six bf16 MFMAs per fp32 product, so what it occupies of the matrix cores is
-            # 6 * achieved / bf16 peak, reported beside it.
-            ach = 2.0 * M * N * K / (avg_us * 1e-6) / 1e12
-            split = gemm_mode == 1
-            out = dict(kernel=name + (' (fp32 via 3-way bf16 split, 6 bf16 MFMAs per product)' if split else
-                                      ' (fp32 MFMA)'),
-                       bound='mfma', achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
-                       frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=None, avg_us=avg_us)
-            if split:
-                out['bf16_pipe_frac'] = 6.0 * ach / MFMA_BF16_PEAK_TFLOPS
-            return out
-
-        def roof_of(name):
-            k = ks[name]
-            if name == 'embed_fwd':
-                # algorithmic bytes per sample: ids + row read + row write (embedding gather forward)
-                return hbm_roof(name, 'embed_fwd_kernel (gather + FM first/second order + concat)',
-                                F * (4 + E * 4 + E * 4) * B, k['avg_us'], 'embed_fwd_kernel')
-            if name == 'emb_sparse_apply':
-                # per lookup: key + src + gradient row; per unique row: read+write of W, m, v
-                return hbm_roof(name, 'sparse_apply_kernel (+tail): segment-reduce + row-wise Adam',
-                                int(F * B * (8 + E * 4) + uniq * 6 * E * 4), k['avg_us'], 'sparse_apply_kernel')
-            if name.startswith('gemm_') or name.startswith('wgrad_'):
-                M, N, K = [int(v) for v in name.split('_')[1].split('x')]
-                return mfma_roof(name, M, N, K, k['avg_us'])
-            return dict(kernel=name, bound='hbm', achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None,
-                        traffic=None, avg_us=k['avg_us'])
-
-        out['roofline'] = roof_of(dom_name)
-        out['roofline_emb'] = roof_of('embed_fwd') if 'embed_fwd' in ks else None
-        out['roofline_emb_bwd'] = roof_of('emb_sparse_apply') if 'emb_sparse_apply' in ks else None
-        if out['roofline_emb_bwd'] and 'emb_sparse_apply' in profile:
-            # in the timed region the sparse update shares the GPU with the tower weight gradients (side
-            # stream); its launch time alone on the GPU comes from the single-stream profiling pass
-            r = out['roofline_emb_bwd']
-            alone_us = 1e3 * profile['emb_sparse_apply']['total_ms'] / max(profile['emb_sparse_apply']['calls'], 1)
-            r['shares_gpu_with'] = 'tower weight gradients (side stream)'
-            r['alone_avg_us'] = alone_us
-            r['alone_frac'] = r['bytes_per_launch'] / (alone_us * 1e-6) / 1e9 / HBM_PEAK_GBS
-        out['unique_rows_per_step'] = uniq
-        out['profile_steps'] = PROFILE_STEPS
-        out['kernel_ms_per_step'] = {n: round(v['total_ms'] / PROFILE_STEPS, 4) for n, v in
-                                     sorted(profile.items(), key=lambda kv: -kv[1]['total_ms'])}
+                               '~1e-7 relative)')
+    out.update({k: v for k, v in res.items() if k not in ('value', 'unit', 'steps', 'warmup', 'ms_per_step')})
+    if dcn is not None:
+        out['dcn'] = dcn
     if not args.no_cpu_baseline and world == 1:
-        out['cpu_baseline'] = cpu_baseline(args, cards)
+        from recommendation_amd.synthetic import CRITEO_KAGGLE
+        out['cpu_baseline'] = cpu_baseline(args, CRITEO_KAGGLE)
     elif world == 1:
         out['cpu_baseline'] = None
     print(json.dumps(out))

@@ -21,3 +21,15 @@ def test_two_ranks_match_one_rank(sess, model, shard, arch):
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'DIST_OK %s %s' % (model, shard) in r.stdout
+
+
+def test_rccl_transport_one_rank(sess):
+    """distributed.TorchComm over the nccl (= RCCL) backend: one rank, both sharded layouts, against the
+    unsharded front end (a one-GPU box cannot hold two RCCL ranks; the 2-rank cases above use the host-staged
+    transport)."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1',
+           '--master-addr', '127.0.0.1', '--master-port', '29733', os.path.join(ROOT, 'tests', 'rccl_worker.py')]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'RCCL_OK backend=nccl' in r.stdout
