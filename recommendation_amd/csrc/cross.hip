@@ -11,6 +11,7 @@
 namespace ctr {
 
 constexpr int LMAX = 8;
+static inline int cross_dp_of(int D) { return (D + 3) / 4 * 4; }
 constexpr int PREP_THREADS = 1024;
 
 // Four consecutive floats row[j .. j+3] of a row of D; vec: the row may be read 16 bytes at a time.
@@ -70,8 +71,97 @@ __global__ __launch_bounds__(PREP_THREADS) void cross_prep_kernel(const float* _
   }
 }
 
-// One wave per sample; lane holds columns 256*i + 4*lane .. +3 for i < NQ.  The L dot products x0 . w_l do not
-// depend on the recursion, so they are taken in one sweep over the row in registers and reduced together.
+// Persistent form (the one used whenever the L weight rows and the bias prefix row fit the LDS): a block keeps
+// w_0 .. w_{L-1} and Bl_L in LDS for its whole life and its four waves walk the samples, the next sample's row
+// already in flight (registers) while the current one is reduced and written.  A sample costs its own bytes from
+// memory and nothing else; the weight rows, re-read per sample, come out of the LDS.
+// lds: [L][DP] weight rows (zero-padded to DP), then [DP] Bl_L.  (The staging loop is written out in both kernels:
+// as a shared helper it crashed this compiler's inliner.)
+template <int NQ>
+__global__ __launch_bounds__(256) void cross_fwd_lds_kernel(const float* __restrict__ x0, int64_t x0_ld,
+                                                           const float* __restrict__ w, int64_t wld,
+                                                           const float* __restrict__ Bl, int DP,
+                                                           const float* __restrict__ q, int B, int D, int L,
+                                                           float* __restrict__ xL, int64_t xL_ld,
+                                                           float* __restrict__ aux) {
+  extern __shared__ __attribute__((aligned(16))) float cross_lds[];
+  {  // stage w_0 .. w_{L-1} and Bl_L: 16 bytes per load, eight loads of a thread in flight before the first store
+    const int q4 = DP / 4, n4 = (L + 1) * q4;
+    const bool vw = rows16(w, wld);
+    for (int t0 = threadIdx.x; t0 < n4; t0 += 8 * 256) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u * 256;
+        const int l = t / q4, j = 4 * (t % q4);
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < n4) v[u] = l < L ? row4(w + (int64_t)l * wld, j, D, vw) : row4(Bl + (int64_t)L * DP, j, D, true);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u * 256;
+        if (t < n4) *reinterpret_cast<float4*>(cross_lds + 4 * t) = v[u];
+      }
+    }
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const bool vx = rows16(x0, x0_ld), vo = rows16(xL, xL_ld);
+  float ql[LMAX];
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l) ql[l] = l < L ? q[l] : 0.f;
+  float4 x[NQ], xn[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) xn[i] = row4(x0 + b * x0_ld, 256 * i + 4 * lane, D, vx);
+  for (; b < B; b += stride) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) x[i] = xn[i];
+    const int64_t bn = b + stride < B ? b + stride : b;            // the last sample re-reads itself (harmless)
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) xn[i] = row4(x0 + bn * x0_ld, 256 * i + 4 * lane, D, vx);
+    float p[LMAX];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      p[l] = 0.f;
+      if (l < L) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+          if (256 * i < D) p[l] += dot4(x[i], *reinterpret_cast<const float4*>(cross_lds + l * DP + 256 * i + 4 * lane));
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l)
+      if (l < L) p[l] = wave_sum(p[l]);
+    float c = 1.f;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      if (l < L) {
+        const float s = c * p[l] + ql[l];
+        c += s;
+        if (lane == 0 && aux) {
+          aux[b * 2 * L + l] = p[l];
+          aux[b * 2 * L + L + l] = c;  // c_{l+1}
+        }
+      }
+    }
+    float* orow = xL + b * xL_ld;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int j = 256 * i + 4 * lane;
+      if (j < D) {
+        const float4 bl = *reinterpret_cast<const float4*>(cross_lds + L * DP + j);
+        put4(orow, j, D, vo, make_float4(x[i].x * c + bl.x, x[i].y * c + bl.y, x[i].z * c + bl.z, x[i].w * c + bl.w));
+      }
+    }
+  }
+}
+
+// One wave per sample (rows too long for the LDS-resident form); lane holds columns 256*i + 4*lane .. +3 for
+// i < NQ.  The L dot products x0 . w_l do not depend on the recursion, so they are taken in one sweep over the row
+// in registers and reduced together.
 template <int NQ>
 __global__ __launch_bounds__(256) void cross_fwd_kernel(const float* __restrict__ x0, int64_t x0_ld,
                                                        const float* __restrict__ w, int64_t wld,
@@ -119,6 +209,100 @@ __global__ __launch_bounds__(256) void cross_fwd_kernel(const float* __restrict_
     if (j < D) {
       const float4 bl = row4(Bl + (int64_t)L * DP, j, D, true);
       put4(orow, j, D, vo, make_float4(x[i].x * c + bl.x, x[i].y * c + bl.y, x[i].z * c + bl.z, x[i].w * c + bl.w));
+    }
+  }
+}
+
+// Backward of the same shape, persistent, weights in LDS: per sample g and x0 (prefetched one sample ahead), the
+// scalar recursion backwards, dx0 = g c_L + sum_l dp_l w_l.
+template <int NQ>
+__global__ __launch_bounds__(256) void cross_bwd_lds_kernel(const float* __restrict__ x0, int64_t x0_ld,
+                                                           const float* __restrict__ w, int64_t wld, int DP,
+                                                           const float* __restrict__ aux,
+                                                           const float* __restrict__ g, int64_t g_ld, int B, int D,
+                                                           int L, float* __restrict__ dx0, int64_t dx0_ld,
+                                                           int accumulate, float* __restrict__ dpq) {
+  extern __shared__ __attribute__((aligned(16))) float cross_lds[];
+  {  // stage w_0 .. w_{L-1}: 16 bytes per load, eight loads of a thread in flight before the first store
+    const int q4 = DP / 4, n4 = L * q4;
+    const bool vw = rows16(w, wld);
+    for (int t0 = threadIdx.x; t0 < n4; t0 += 8 * 256) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u * 256;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < n4) v[u] = row4(w + (int64_t)(t / q4) * wld, 4 * (t % q4), D, vw);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u * 256;
+        if (t < n4) *reinterpret_cast<float4*>(cross_lds + 4 * t) = v[u];
+      }
+    }
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const bool vx = rows16(x0, x0_ld), vg = rows16(g, g_ld), vd = rows16(dx0, dx0_ld);
+  float4 gv[NQ], xv[NQ], gn[NQ], xn[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    gn[i] = row4(g + b * g_ld, 256 * i + 4 * lane, D, vg);
+    xn[i] = row4(x0 + b * x0_ld, 256 * i + 4 * lane, D, vx);
+  }
+  for (; b < B; b += stride) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) { gv[i] = gn[i]; xv[i] = xn[i]; }
+    const int64_t bn = b + stride < B ? b + stride : b;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      gn[i] = row4(g + bn * g_ld, 256 * i + 4 * lane, D, vg);
+      xn[i] = row4(x0 + bn * x0_ld, 256 * i + 4 * lane, D, vx);
+    }
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+      if (256 * i < D) a += dot4(gv[i], xv[i]);
+    a = wave_sum(a);
+    // scalar backward of c_{l+1} = c_l * (1 + p_l) + q_l
+    float dp[LMAX];
+    float dc = a;
+    const float cL = aux[b * 2 * L + L + (L - 1)];
+#pragma unroll
+    for (int l = LMAX - 1; l >= 0; --l) {
+      dp[l] = 0.f;
+      if (l < L) {
+        const float c_l = l == 0 ? 1.f : aux[b * 2 * L + L + (l - 1)];
+        const float p_l = aux[b * 2 * L + l];
+        dp[l] = dc * c_l;
+        if (lane == 0) {
+          dpq[b * 2 * L + l] = dp[l];
+          dpq[b * 2 * L + L + l] = dc;  // dq_l
+        }
+        dc = dc * (1.f + p_l);
+      }
+    }
+    float* drow = dx0 + b * dx0_ld;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int j = 256 * i + 4 * lane;
+      if (j < D) {
+        float4 v = make_float4(gv[i].x * cL, gv[i].y * cL, gv[i].z * cL, gv[i].w * cL);
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l)
+          if (l < L) {
+            const float4 wv = *reinterpret_cast<const float4*>(cross_lds + l * DP + j);
+            v.x += dp[l] * wv.x; v.y += dp[l] * wv.y; v.z += dp[l] * wv.z; v.w += dp[l] * wv.w;
+          }
+        if (accumulate) {
+          const float4 o = row4(drow, j, D, vd);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        put4(drow, j, D, vd, v);
+      }
     }
   }
 }
@@ -203,22 +387,43 @@ __global__ __launch_bounds__(256) void cross_bwd_partial_kernel(const float* __r
   for (int l = 0; l <= LMAX; ++l) acc[l] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int l = 0; l < LMAX; ++l) sdq[l] = 0.f;
-  for (int64_t r = r0 + ty; r < r1; r += 8) {      // two rows in flight per wave
-    const int64_t rb = r + 4 < r1 ? r + 4 : r;
-    const float wb = r + 4 < r1 ? 1.f : 0.f;
-    const float4 xa = row4(x0 + r * x0_ld, j, D, vx), xb = row4(x0 + rb * x0_ld, j, D, vx);
-    const float4 ga = row4(g + r * g_ld, j, D, vg), gb = row4(g + rb * g_ld, j, D, vg);
+  // The per-row scalars (dp_l, dq_l) of a stretch of rows are staged in LDS first (every lane of a wave needs the
+  // same 2L words of a row: read from global memory they were 2L more load instructions per row than the two
+  // loads that carry the row itself).
+  constexpr int RF = 8;                            // rows in flight per wave (rows r, r + 4, ..., r + 28)
+  constexpr int STRETCH = 128;
+  __shared__ float sdp[STRETCH * 2 * LMAX];
+  for (int64_t base = r0; base < r1; base += STRETCH) {
+    const int64_t top = base + STRETCH < r1 ? base + STRETCH : r1;
+    __syncthreads();
+    for (int t = threadIdx.x; t < (int)(top - base) * 2 * L; t += 256) sdp[t] = dpq[base * 2 * L + t];
+    __syncthreads();
+    for (int64_t r = base + ty; r < top; r += 4 * RF) {
+      float4 xs[RF], gs[RF];
+      float ws[RF];
+      int rl[RF];
 #pragma unroll
-    for (int l = 0; l < LMAX; ++l)
-      if (l < L) {
-        const float da = dpq[r * 2 * L + l], db = dpq[rb * 2 * L + l] * wb;
-        acc[l].x += da * xa.x; acc[l].y += da * xa.y; acc[l].z += da * xa.z; acc[l].w += da * xa.w;
-        acc[l].x += db * xb.x; acc[l].y += db * xb.y; acc[l].z += db * xb.z; acc[l].w += db * xb.w;
-        sdq[l] += dpq[r * 2 * L + L + l];
-        sdq[l] += dpq[rb * 2 * L + L + l] * wb;
+      for (int u = 0; u < RF; ++u) {
+        const bool ok = r + 4 * u < top;
+        const int64_t rr = ok ? r + 4 * u : r;
+        rl[u] = (int)(rr - base);
+        ws[u] = ok ? 1.f : 0.f;
+        xs[u] = row4(x0 + rr * x0_ld, j, D, vx);
+        gs[u] = row4(g + rr * g_ld, j, D, vg);
       }
-    acc[LMAX].x += ga.x; acc[LMAX].y += ga.y; acc[LMAX].z += ga.z; acc[LMAX].w += ga.w;
-    acc[LMAX].x += gb.x * wb; acc[LMAX].y += gb.y * wb; acc[LMAX].z += gb.z * wb; acc[LMAX].w += gb.w * wb;
+#pragma unroll
+      for (int u = 0; u < RF; ++u) {
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l)
+          if (l < L) {
+            const float d = sdp[rl[u] * 2 * L + l] * ws[u];
+            acc[l].x += d * xs[u].x; acc[l].y += d * xs[u].y; acc[l].z += d * xs[u].z; acc[l].w += d * xs[u].w;
+            sdq[l] += sdp[rl[u] * 2 * L + L + l] * ws[u];
+          }
+        acc[LMAX].x += gs[u].x * ws[u]; acc[LMAX].y += gs[u].y * ws[u];
+        acc[LMAX].z += gs[u].z * ws[u]; acc[LMAX].w += gs[u].w * ws[u];
+      }
+    }
   }
 #pragma unroll
   for (int l = 0; l <= LMAX; ++l) {
@@ -300,13 +505,17 @@ __global__ __launch_bounds__(64 * CF_PH) void cross_bwd_final_kernel(const float
 }
 
 static int cross_chunks(int B) {
-  int64_t n = cdiv(B, 64);
+  int64_t n = cdiv(B, 128);       // 128 rows per chunk: 4 waves x 8 rows in flight x 4 rounds
   if (n < 1) n = 1;
-  if (n > 256) n = 256;
+  if (n > 128) n = 128;
   return (int)n;
 }
 
-static int cross_dp(int D) { return (D + 3) / 4 * 4; }   // row stride of the workspace's own [.., D] arrays
+// LDS bytes of the persistent kernels ((L or L + 1) rows of DP floats); above the limit the per-sample kernels run
+static size_t cross_lds_bytes(int D, int rows) { return (size_t)rows * cross_dp_of(D) * sizeof(float); }
+constexpr size_t CROSS_LDS_LIMIT = 64 * 1024;
+
+static int cross_dp(int D) { return cross_dp_of(D); }     // row stride of the workspace's own [.., D] arrays
 static size_t cross_prep_floats(int D, int L) { return align_up((size_t)(L + 1) * cross_dp(D) + LMAX, 64); }
 
 }  // namespace ctr
@@ -332,6 +541,19 @@ extern "C" size_t ctr_cross_bwd_workspace_bytes(int B, int D, int L) {
     else hipLaunchKernelGGL(KERNEL<32>, grid, block, 0, st, __VA_ARGS__);                        \
   } while (0)
 
+// persistent launches: two blocks per CU keep 2048 waves walking the samples
+#define CROSS_DISPATCH_LDS(KERNEL, LDS_BYTES, ...)                                               \
+  do {                                                                                           \
+    const int nq = (int)cdiv(D, 256);                                                            \
+    int64_t nb = cdiv(B, 4);                                                                     \
+    if (nb > 512) nb = 512;                                                                      \
+    const dim3 grid((unsigned)nb), block(256);                                                   \
+    if (nq <= 1) hipLaunchKernelGGL(KERNEL<1>, grid, block, LDS_BYTES, st, __VA_ARGS__);         \
+    else if (nq <= 2) hipLaunchKernelGGL(KERNEL<2>, grid, block, LDS_BYTES, st, __VA_ARGS__);    \
+    else if (nq <= 4) hipLaunchKernelGGL(KERNEL<4>, grid, block, LDS_BYTES, st, __VA_ARGS__);    \
+    else hipLaunchKernelGGL(KERNEL<8>, grid, block, LDS_BYTES, st, __VA_ARGS__);                 \
+  } while (0)
+
 extern "C" int ctr_cross_fwd(const float* x0, int64_t x0_ld, const float* w, const float* b, int64_t wld,
                              int B, int D, int L, float* xL, int64_t xL_ld, float* aux_out, void* workspace,
                              size_t workspace_bytes, void* stream) {
@@ -349,7 +571,11 @@ extern "C" int ctr_cross_fwd(const float* x0, int64_t x0_ld, const float* w, con
   float* Bl = (float*)workspace;
   float* q = Bl + (size_t)(L + 1) * DP;
   hipLaunchKernelGGL(cross_prep_kernel, dim3(1), dim3(PREP_THREADS), 0, st, w, b, wld, D, DP, L, Bl, q);
-  CROSS_DISPATCH(cross_fwd_kernel, x0, x0_ld, w, wld, Bl, DP, q, B, D, L, xL, xL_ld, aux_out);
+  if (D <= 2048 && cross_lds_bytes(D, L + 1) <= CROSS_LDS_LIMIT)
+    CROSS_DISPATCH_LDS(cross_fwd_lds_kernel, cross_lds_bytes(D, L + 1), x0, x0_ld, w, wld, Bl, DP, q, B, D, L, xL, xL_ld,
+                       aux_out);
+  else
+    CROSS_DISPATCH(cross_fwd_kernel, x0, x0_ld, w, wld, Bl, DP, q, B, D, L, xL, xL_ld, aux_out);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
@@ -376,7 +602,11 @@ extern "C" int ctr_cross_bwd(const float* x0, int64_t x0_ld, const float* w, con
   float* psdq = dpq + align_up((size_t)B * 2 * L, 64);
   float* part = psdq + (size_t)nchunks * LMAX;
   hipLaunchKernelGGL(cross_prep_kernel, dim3(1), dim3(PREP_THREADS), 0, st, w, b, wld, D, DP, L, Bl, q);
-  CROSS_DISPATCH(cross_bwd_kernel, x0, x0_ld, w, wld, aux, g, g_ld, B, D, L, dx0, dx0_ld, accumulate, dpq);
+  if (D <= 2048 && cross_lds_bytes(D, L) <= CROSS_LDS_LIMIT)
+    CROSS_DISPATCH_LDS(cross_bwd_lds_kernel, cross_lds_bytes(D, L), x0, x0_ld, w, wld, DP, aux, g, g_ld, B, D, L, dx0, dx0_ld,
+                       accumulate, dpq);
+  else
+    CROSS_DISPATCH(cross_bwd_kernel, x0, x0_ld, w, wld, aux, g, g_ld, B, D, L, dx0, dx0_ld, accumulate, dpq);
   hipLaunchKernelGGL(cross_bwd_partial_kernel, dim3((unsigned)cdiv(D, 256), nchunks), dim3(256), 0, st, x0,
                      x0_ld, g, g_ld, dpq, B, D, DP, L, rows_per_chunk, part, psdq);
   hipLaunchKernelGGL(cross_bwd_final_kernel, dim3((unsigned)cdiv(D, 64)), dim3(64 * CF_PH), 0, st, part, psdq, nchunks, w,
