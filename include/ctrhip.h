@@ -78,6 +78,25 @@ int ctr_embed_fwd(const float* tables, const int64_t* row_offset, const int32_t*
                   const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second,
                   int32_t* oor_count, void* stream);
 
+/* Multi-hot fields ("gather and pool"; the sum combiner of tf.nn.embedding_lookup_sparse, which the reference's
+ * one-id-per-field models are the one-member case of: DeepFM/DeepFM.py:43-53).  idx is a flat list of nnz ids and
+ * bag_offsets a CSR array of B*F+1 int32: bag (b,f) holds idx[bag_offsets[b*F+f] .. bag_offsets[b*F+f+1]), all
+ * ids of field f.
+ *   Z[b,f,:] = sum over the bag's members j, in list order, of tables[row_offset[f] + idx[j], :]
+ * (an empty bag gives a zero row; an id outside [0, V_f) adds nothing and bumps oor_count).  Continuous rows,
+ * first / s / second, dropout and the x_cont tail are those of ctr_embed_fwd, computed over the pooled Z.
+ * z_out is required here. */
+int ctr_embed_bag_fwd(const float* tables, const int64_t* row_offset, const int32_t* idx,
+                      const int32_t* bag_offsets, int64_t nnz,
+                      const float* x_cont, const float* cont_w,
+                      int B, int F, int C, int E,
+                      float* z_out, int64_t z_ld, int cont_tail,
+                      float* first_out, int64_t first_ld,
+                      float* s_out,
+                      float* second_out, int64_t second_ld,
+                      const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second,
+                      int32_t* oor_count, void* stream);
+
 /* FM reductions over an already materialised Z (leading dimension z_ld, N rows of E per
  * sample): first / s / second exactly as in ctr_embed_fwd (DeepFM/DeepFM.py:55-63). */
 int ctr_fm_fwd(const float* z, int64_t z_ld, int B, int N, int E,
@@ -144,6 +163,14 @@ int ctr_emb_sort(const int32_t* idx, const int64_t* row_offset, int B, int F, in
                  int64_t total_rows, int rmode,
                  uint32_t* keys_out, uint32_t* src_out,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* ctr_emb_sort for multi-hot bags (same CSR arguments as ctr_embed_bag_fwd): one pair per member j of bag
+ * (b,f), key = row_offset[f] + idx[j] (total_rows when out of range), src = b*N + f, sorted by key with the same
+ * stable sort, so ctr_emb_sparse_apply(n_items = nnz) adds dZ[b,f,:] to every member row: the gradient of the
+ * sum pooling.  keys_out / src_out: [nnz] uint32; workspace: ctr_emb_sort_workspace_bytes(nnz). */
+int ctr_emb_bag_sort(const int32_t* idx, const int32_t* bag_offsets, int64_t nnz,
+                     const int64_t* row_offset, int B, int F, int N, int64_t total_rows,
+                     uint32_t* keys_out, uint32_t* src_out,
+                     void* workspace, size_t workspace_bytes, void* stream);
 /* ctr_emb_sort for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and the same result,
  * bit for bit, as ctr_emb_sort, but the scratch is a 24 MiB array built into the library's device image (one copy

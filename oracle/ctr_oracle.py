@@ -103,9 +103,39 @@ def embed_block_rmode(tables, X_cate):
     return torch.cat(outs, dim=1)
 
 
+class BagIds:
+    """Multi-hot input in CSR form: bag (b,f) = ids[offsets[b*F+f] : offsets[b*F+f+1]].  Not a reference input:
+    the reference feeds one id per field (DeepFM/DeepFM.py:43-53), which is the one-member case; the pooling is
+    the published sum combiner of tf.nn.embedding_lookup_sparse."""
+
+    def __init__(self, ids, offsets, F):
+        self.ids = torch.as_tensor(np.asarray(ids).astype(np.int32).astype(np.int64)).reshape(-1)
+        self.offsets = torch.as_tensor(np.asarray(offsets).astype(np.int64)).reshape(-1)
+        self.F = int(F)
+        self.B = (self.offsets.numel() - 1) // self.F
+        counts = self.offsets[1:] - self.offsets[:-1]
+        self.bag = torch.repeat_interleave(torch.arange(self.B * self.F), counts)     # bag of every member
+
+    def __len__(self):
+        return self.B
+
+
+def embed_bags_smode(tables, bags):
+    """Z[b,f,:] = sum over the members of bag (b,f) of W_f[id,:]; out-of-range members add nothing."""
+    outs = []
+    for f, W in enumerate(tables):
+        V = W.shape[0]
+        sel = (bags.bag % bags.F == f) & (bags.ids >= 0) & (bags.ids < V)
+        z = torch.zeros(bags.B, W.shape[1], dtype=W.dtype)
+        outs.append(z.index_add(0, bags.bag[sel] // bags.F, W[bags.ids[sel]]))
+    return torch.stack(outs, dim=1)
+
+
 def embed_block_smode(tables, X_cate):
     """Standard per-field lookup Z[b,f,:] = W_f[x[b,f],:] (Wide_Deep/Wide_Deep.py:51,
     DIN/DIN.py:26); an out-of-range id gives a zero row (the tf.one_hot convention)."""
+    if isinstance(X_cate, BagIds):
+        return embed_bags_smode(tables, X_cate)
     outs = []
     for f, W in enumerate(tables):
         V = W.shape[0]
@@ -840,23 +870,33 @@ class OracleModel:
 
     def touched_rows(self, X_cate):
         """name -> bool[V_f]: the rows of every table the batch looks up with an in-range id."""
-        xc = np.asarray(X_cate).astype(np.int32).astype(np.int64)
+        bags = self._bags(X_cate)
+        xc = None if bags is not None else np.asarray(X_cate).astype(np.int32).astype(np.int64)
         rows = {}
         for f, v in enumerate(self.cfg.cate_list):
             m = torch.zeros(int(v), dtype=torch.bool)
-            col = xc[:, f]
+            col = bags.ids[bags.bag % bags.F == f].numpy() if bags is not None else xc[:, f]
             m[torch.as_tensor(col[(col >= 0) & (col < v)])] = True
             rows['embedding/embed_cate_w_%d' % f] = m
         return rows
 
+    def _bags(self, X_cate):
+        if isinstance(X_cate, BagIds):
+            return X_cate
+        if isinstance(X_cate, tuple) and len(X_cate) == 2:
+            return BagIds(X_cate[0], X_cate[1], len(self.cfg.cate_list))
+        return None
+
     def _inputs(self, X_cate, X_cont, y):
-        xc = torch.as_tensor(np.asarray(X_cate).astype(np.int32).astype(np.int64))   # feed narrows to int32
+        xc = self._bags(X_cate)
+        if xc is None:
+            xc = torch.as_tensor(np.asarray(X_cate).astype(np.int32).astype(np.int64))   # feed narrows to int32
         xf = torch.as_tensor(np.asarray(X_cont).astype(np.float32)).to(self.dtype)
         yy = torch.as_tensor(np.asarray(y).astype(np.float32)).to(self.dtype)
         return xc, xf, yy
 
     def forward(self, X_cate, X_cont, masks=None, P=None):
-        xc, xf, _ = self._inputs(X_cate, X_cont, np.zeros(len(X_cate)))
+        xc, xf, _ = self._inputs(X_cate, X_cont, np.zeros(len(X_cont)))
         with torch.no_grad():
             return FORWARD[self.model](P or self.P, self.cfg, xc, xf, masks, self.literal)
 

@@ -283,6 +283,53 @@ __global__ __launch_bounds__(256) void embed_bwd_dz_kernel(
   }
 }
 
+// Multi-hot front end, first step: every bag (b, f) of a CSR list is summed into Z[b, f, :] in member order (a
+// fixed order, so the result is bitwise reproducible); G = E/4 lanes cover a row, a bag's members go four at a
+// time (ids first, then the four row loads they address).  Continuous rows and the x_cont tail are written as in
+// embed_fwd_kernel, so the reductions can run over the finished Z.
+template <int G>
+__global__ __launch_bounds__(256) void embed_bag_pool_kernel(
+    const float* __restrict__ tables, const int64_t* __restrict__ row_offset, const int32_t* __restrict__ idx,
+    const int32_t* __restrict__ bag_offsets, const float* __restrict__ x_cont, const float* __restrict__ cont_w,
+    int B, int F, int C, int E, float* __restrict__ z_out, int64_t z_ld, int cont_tail,
+    int32_t* __restrict__ oor_count) {
+  constexpr int ROWS = 256 / G;                        // rows of Z a block writes per step
+  const int g = threadIdx.x % G;
+  const int N = F + (cont_w ? C : 0);
+  const int64_t total = (int64_t)B * N;
+  for (int64_t r = (int64_t)blockIdx.x * ROWS + threadIdx.x / G; r < total; r += (int64_t)gridDim.x * ROWS) {
+    const int64_t b = r / N;
+    const int n = (int)(r % N);
+    float4 acc = f4_zero();
+    if (n < F) {
+      const int64_t off = row_offset[n];
+      const int64_t V = row_offset[n + 1] - off;
+      const int lo = bag_offsets[b * F + n], hi = bag_offsets[b * F + n + 1];
+      for (int j = lo; j < hi; j += 4) {
+        int x[4];
+        float4 z[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = j + u < hi ? idx[j + u] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          z[u] = f4_zero();
+          if (x[u] >= 0 && x[u] < V) z[u] = *reinterpret_cast<const float4*>(tables + (off + x[u]) * E + g * 4);
+          else if (j + u < hi && oor_count && g == 0) atomicAdd(oor_count, 1);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc.x += z[u].x; acc.y += z[u].y; acc.z += z[u].z; acc.w += z[u].w; }
+      }
+    } else {
+      const float v = x_cont[b * C + (n - F)];
+      const float4 w = *reinterpret_cast<const float4*>(cont_w + (int64_t)(n - F) * E + g * 4);
+      acc = make_float4(w.x * v, w.y * v, w.z * v, w.w * v);
+    }
+    *reinterpret_cast<float4*>(z_out + b * z_ld + (int64_t)n * E + g * 4) = acc;
+    if (cont_tail && n == 0)
+      for (int c = g; c < C; c += G) z_out[b * z_ld + (int64_t)N * E + c] = x_cont[b * C + c];
+  }
+}
+
 static bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
 }  // namespace ctr
@@ -387,6 +434,45 @@ extern "C" int ctr_fm_fwd(const float* z, int64_t z_ld, int B, int N, int E, flo
 #undef LAUNCH
   CTR_LAUNCH_CHECK();
   return CTR_OK;
+}
+
+extern "C" int ctr_embed_bag_fwd(const float* tables, const int64_t* row_offset, const int32_t* idx,
+                                 const int32_t* bag_offsets, int64_t nnz, const float* x_cont, const float* cont_w,
+                                 int B, int F, int C, int E, float* z_out, int64_t z_ld, int cont_tail,
+                                 float* first_out, int64_t first_ld, float* s_out, float* second_out,
+                                 int64_t second_ld, const ctr_dropout_t* drop_first,
+                                 const ctr_dropout_t* drop_second, int32_t* oor_count, void* stream) {
+  CTR_REQUIRE(B >= 0 && F >= 0 && C >= 0 && nnz >= 0 && nnz <= 0x7FFFFFFFll, "ctr_embed_bag_fwd: bad size");
+  CTR_REQUIRE(pow2(E) && E >= 4 && E <= 256, "ctr_embed_bag_fwd: E=%d must be a power of two in [4,256]", E);
+  CTR_REQUIRE(F == 0 || (tables && row_offset && bag_offsets && (idx || nnz == 0)), "ctr_embed_bag_fwd: null pointer");
+  CTR_REQUIRE(z_out && z_ld % 4 == 0 && ((uintptr_t)z_out % 16) == 0,
+              "ctr_embed_bag_fwd: z_out is required, 16-byte aligned with z_ld %% 4 == 0");
+  CTR_REQUIRE(!(cont_w || cont_tail) || x_cont || C == 0, "ctr_embed_bag_fwd: x_cont missing");
+  const int N = F + (cont_w ? C : 0);
+  CTR_REQUIRE(z_ld >= (int64_t)N * E + (cont_tail ? C : 0), "ctr_embed_bag_fwd: z_ld too small");
+  CTR_REQUIRE(!cont_tail || N > 0, "ctr_embed_bag_fwd: cont_tail needs at least one row of Z");
+  if (B == 0 || N == 0) return CTR_OK;
+  const int G = E / 4;
+  const int64_t steps = cdiv((int64_t)B * N, 256 / G);
+  const dim3 grid((unsigned)(steps < 8192 ? steps : 8192)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(GG)                                                                                          \
+  hipLaunchKernelGGL((embed_bag_pool_kernel<GG>), grid, block, 0, st, tables, row_offset, idx, bag_offsets, \
+                     x_cont, cont_w, B, F, C, E, z_out, z_ld, cont_tail, oor_count)
+  switch (G) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 4: LAUNCH(4); break;
+    case 8: LAUNCH(8); break;
+    case 16: LAUNCH(16); break;
+    case 32: LAUNCH(32); break;
+    case 64: LAUNCH(64); break;
+  }
+#undef LAUNCH
+  CTR_LAUNCH_CHECK();
+  if (!first_out && !s_out && !second_out) return CTR_OK;
+  return ctr_fm_fwd(z_out, z_ld, B, N, E, first_out, first_ld, s_out, second_out, second_ld, drop_first, drop_second,
+                    stream);
 }
 
 extern "C" int ctr_embed_onehot_fwd(const float* tables, const int64_t* row_offset,

@@ -41,6 +41,26 @@ __global__ __launch_bounds__(256) void build_pairs_kernel(
   }
 }
 
+// Pair builder for multi-hot bags (CSR): one pair per member j of bag (b, f), key = the member's table row,
+// src = the bag's row of dZ.  A thread walks one bag, so the pairs come out in member order.
+__global__ __launch_bounds__(256) void build_bag_pairs_kernel(
+    const int32_t* __restrict__ idx, const int32_t* __restrict__ bag_offsets, const int64_t* __restrict__ row_offset,
+    int B, int F, int N, int64_t total_rows, uint32_t* __restrict__ keys, uint32_t* __restrict__ src) {
+  const int64_t nbags = (int64_t)B * F;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbags; i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % F);
+    const int64_t b = i / F;
+    const int64_t off = row_offset[f];
+    const int64_t V = row_offset[f + 1] - off;
+    const int lo = bag_offsets[i], hi = bag_offsets[i + 1];
+    for (int j = lo; j < hi; ++j) {
+      const int x = idx[j];
+      keys[j] = (x >= 0 && x < V) ? (uint32_t)(off + x) : (uint32_t)total_rows;
+      src[j] = (uint32_t)(b * N + f);
+    }
+  }
+}
+
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(
     const uint32_t* __restrict__ keys, int64_t n, int shift, int nblocks, uint32_t* __restrict__ counts) {
   __shared__ uint32_t hist[RBINS];
@@ -363,6 +383,35 @@ extern "C" int ctr_emb_sort(const int32_t* idx, const int64_t* row_offset, int B
   hipLaunchKernelGGL(build_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, idx, row_offset, B, F,
                      N, total_rows, rmode, ka, va);
   run_passes(ka, va, kb, vb, n, passes, w, st);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_emb_bag_sort(const int32_t* idx, const int32_t* bag_offsets, int64_t nnz,
+                                const int64_t* row_offset, int B, int F, int N, int64_t total_rows,
+                                uint32_t* keys_out, uint32_t* src_out, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  CTR_REQUIRE(B >= 0 && F >= 0 && N > 0 && nnz >= 0 && nnz <= 0x7FFFFFFFll, "ctr_emb_bag_sort: bad size");
+  CTR_REQUIRE(total_rows > 0 && total_rows < 0xFFFFFFFFll, "ctr_emb_bag_sort: total_rows must fit 32 bits");
+  CTR_REQUIRE((int64_t)B * N < 0xFFFFFFFFll, "ctr_emb_bag_sort: B*N must fit 32 bits");
+  if (nnz == 0 || (int64_t)B * F == 0) return CTR_OK;
+  CTR_REQUIRE(idx && bag_offsets && row_offset && keys_out && src_out && workspace, "ctr_emb_bag_sort: null pointer");
+  if (workspace_bytes < sort_ws_bytes(nnz)) {
+    set_error("ctr_emb_bag_sort: workspace %zu < %zu", workspace_bytes, sort_ws_bytes(nnz));
+    return CTR_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const SortWs w = carve(workspace, nnz);
+  const int passes = (bits_for((uint64_t)total_rows) + RBITS - 1) / RBITS;
+  uint32_t* ka = (passes % 2 == 0) ? keys_out : w.keys_tmp;
+  uint32_t* va = (passes % 2 == 0) ? src_out : w.vals_tmp;
+  uint32_t* kb = (passes % 2 == 0) ? w.keys_tmp : keys_out;
+  uint32_t* vb = (passes % 2 == 0) ? w.vals_tmp : src_out;
+  const int64_t nbags = (int64_t)B * F;
+  const int64_t blocks = cdiv(nbags, 256) < 2048 ? cdiv(nbags, 256) : 2048;
+  hipLaunchKernelGGL(build_bag_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, idx, bag_offsets, row_offset,
+                     B, F, N, total_rows, ka, va);
+  run_passes(ka, va, kb, vb, nnz, passes, w, st);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }

@@ -145,6 +145,35 @@ class EmbeddingTables:
             self.slot1 = torch.zeros_like(self.weight)
 
 
+class Bags:
+    """Multi-hot categorical input: bag (b, f) holds ids[offsets[b*F+f] : offsets[b*F+f+1]], all of field f, and is
+    sum-pooled into one row of Z (the single id per field of DeepFM/DeepFM.py:43-53 is the one-member case).
+    ids: int32 [nnz]; offsets: int32 [B*F+1], non-decreasing from 0 to nnz.  Both on the device."""
+
+    def __init__(self, ids, offsets, B, F):
+        if ids.dtype != torch.int32 or offsets.dtype != torch.int32 or ids.dim() != 1 or offsets.dim() != 1:
+            raise TypeError('Bags: ids and offsets must be 1-D int32 tensors')
+        if offsets.numel() != B * F + 1:
+            raise ValueError('Bags: offsets must have B*F+1 = %d entries, got %d' % (B * F + 1, offsets.numel()))
+        self.ids, self.offsets, self.shape = ids.contiguous(), offsets.contiguous(), (int(B), int(F))
+
+    @classmethod
+    def from_host(cls, ids, offsets, F, device):
+        """Validates a host CSR (monotone, starting at 0, ending at len(ids)) and uploads it."""
+        ids = np.ascontiguousarray(np.asarray(ids)).astype(np.int32).reshape(-1)
+        off = np.ascontiguousarray(np.asarray(offsets)).astype(np.int64).reshape(-1)
+        if off.size < 1 or (off.size - 1) % F or off[0] != 0 or off[-1] != ids.size or np.any(np.diff(off) < 0):
+            raise ValueError('bag offsets must be non-decreasing, start at 0, end at len(ids) and hold B*F+1 entries')
+        if ids.size > 2 ** 31 - 1:
+            raise ValueError('too many bag members')
+        return cls(torch.as_tensor(ids, device=device), torch.as_tensor(off.astype(np.int32), device=device),
+                   (off.size - 1) // F, F)
+
+    @property
+    def nnz(self):
+        return self.ids.numel()
+
+
 class EmbedFront:
     """Embedding block + FM reductions in either semantics.
 
@@ -167,6 +196,17 @@ class EmbedFront:
                 second_out=None, drop_first=None, drop_second=None, oor_count=None):
         t, E = self.t, self.E
         want_fm = first_out is not None or s_out is not None or second_out is not None
+        if isinstance(idx, Bags):
+            if self.mode != 'S':
+                raise ValueError('multi-hot bags are defined for the standard lookup (mode S)')
+            if z_out is None:
+                raise ValueError('multi-hot bags need the Z buffer')
+            ops.embed_bag_fwd(t.weight, t.row_offset, idx.ids, idx.offsets, x_cont,
+                              cont_w if self.cont_embed else None, B=idx.shape[0], F=idx.shape[1], E=E, z_out=z_out,
+                              cont_tail=cont_tail, first_out=first_out, s_out=s_out, second_out=second_out,
+                              drop_first=drop_first, drop_second=drop_second,
+                              oor_count=oor_count if oor_count is not None else self.oor_count)
+            return
         if self.mode == 'S':
             ops.embed_fwd(t.weight, t.row_offset, idx, x_cont, cont_w if self.cont_embed else None, E=E,
                           z_out=z_out, cont_tail=cont_tail, first_out=first_out, s_out=s_out,
@@ -189,6 +229,10 @@ class EmbedFront:
         """The (key, src) pair sort of the table backward; it reads only the ids, so a caller may run it early, on
         another stream, and pass presorted=True to backward_tables."""
         t = self.t
+        if isinstance(idx, Bags):
+            ops.emb_bag_sort(idx.ids, idx.offsets, t.row_offset, B=idx.shape[0], F=idx.shape[1], N=self.N,
+                             total_rows=t.total_rows, keys_out=keys, src_out=src, ws=ws)
+            return
         ops.emb_sort(idx, t.row_offset, N=self.N, total_rows=t.total_rows, rmode=(self.mode == 'R'),
                      keys_out=keys, src_out=src, ws=ws)
 
@@ -196,15 +240,18 @@ class EmbedFront:
         """dz: [B, >= N*E] gradient with respect to Z.  Sort (key, src), segment-reduce, update."""
         t = self.t
         B, F = idx.shape
+        n_items = idx.nnz if isinstance(idx, Bags) else B * F     # one pair per bag member
+        if n_items == 0:
+            return
         if not presorted:
             self.sort_pairs(idx, keys, src, ws)
         if opt.kind == OPT_ADAM and not lazy:
             t.grad.zero_()
-            ops.emb_sparse_apply(keys, src, B * F, N=self.N, E=self.E, total_rows=t.total_rows, dz=dz,
+            ops.emb_sparse_apply(keys, src, n_items, N=self.N, E=self.E, total_rows=t.total_rows, dz=dz,
                                  opt=ops.make_opt(OPT_GRAD_ONLY), slot0=t.grad, ws=ws)
             ops.dense_update(t.weight, t.grad, opt, t.slot0, t.slot1)
         else:
-            ops.emb_sparse_apply(keys, src, B * F, N=self.N, E=self.E, total_rows=t.total_rows, dz=dz,
+            ops.emb_sparse_apply(keys, src, n_items, N=self.N, E=self.E, total_rows=t.total_rows, dz=dz,
                                  opt=opt, tables=t.weight, slot0=t.slot0, slot1=t.slot1, ws=ws)
 
     def backward_cont_w(self, dz, x_cont, g_cont_w, ws):

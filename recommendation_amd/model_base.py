@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .engine import OPT_KIND, DenseParams, EmbedFront, EmbeddingTables, adam_lr_t, round_up, truncated_normal
+from .engine import OPT_KIND, Bags, DenseParams, EmbedFront, EmbeddingTables, adam_lr_t, round_up, truncated_normal
 from ._lib import OPT_ADAM
 
 
@@ -223,6 +223,7 @@ class CTRModel:
         self._built = False
         self._ready = False
         self._bufs = OrderedDict()       # per-batch-size buffers, least recently used first
+        self._bag_pairs = None           # (keys, src) of the multi-hot backward, grown to the largest member count
         self._graphs = {}
         self._train_graphs = {}
         self._stage = OrderedDict()      # pinned staging buffers of _upload, by (feed, shape), LRU
@@ -443,10 +444,19 @@ class CTRModel:
 
     def _upload(self, X_cate, X_cont, y):
         """Feed conversion of the reference placeholders: int64 -> int32, float64 -> float32."""
-        idx = self._to_device(X_cate, torch.int32, 'cate')
         xc = self._to_device(X_cont, torch.float32, 'cont')
         yy = self._to_device(y, torch.float32, 'y')
-        if idx.dim() != 2 or idx.shape[1] != self.cate_num:
+        if isinstance(X_cate, Bags):
+            idx = X_cate
+        elif isinstance(X_cate, tuple) and len(X_cate) == 2:
+            # multi-hot feed (not a reference input): (ids [nnz], offsets [B*F+1]) in CSR form, sum-pooled per field
+            idx = Bags.from_host(X_cate[0], X_cate[1], self.cate_num, self.session.device)
+        else:
+            idx = self._to_device(X_cate, torch.int32, 'cate')
+        if isinstance(idx, Bags):
+            if self.mode != 'S' or self.world > 1:
+                raise ValueError('multi-hot bags need the standard lookup (mode S) in one process')
+        if len(idx.shape) != 2 or idx.shape[1] != self.cate_num:
             raise ValueError('X_cate must be [B, %d]' % self.cate_num)
         if xc.dim() != 2 or xc.shape[1] != self.cont_num or xc.shape[0] != idx.shape[0]:
             raise ValueError('X_cont must be [B, %d]' % self.cont_num)
@@ -578,14 +588,17 @@ class CTRModel:
             raise ValueError('empty batch')
         if is_train:
             # the reference's loop feeds small mini-batches (128 by default): launch-bound, so replay a graph
-            step = self.train_step_graphed if idx.shape[0] <= GRAPH_MAX_BATCH else self.train_step
+            # (bags change their member count from batch to batch and run eagerly)
+            graphed = idx.shape[0] <= GRAPH_MAX_BATCH and not isinstance(idx, Bags)
+            step = self.train_step_graphed if graphed else self.train_step
             step(idx, xc, yy)
             host = self._scalars.cpu()                  # loss + out-of-range counter in one copy
             self.check_overflow()
             if self.strict_ids:
                 self._raise_on_bad_ids(int(host[1:].view(torch.int32)[0]))
             return np.float32(host[0].item())
-        y_out = self.predict_step_graphed(idx, xc)      # evaluation batches are small: graph replay, not ~15 launches
+        # evaluation batches are small: graph replay, not ~15 launches
+        y_out = self.predict_step(idx, xc) if isinstance(idx, Bags) else self.predict_step_graphed(idx, xc)
         # tf.round is round-half-to-even; torch.round too
         pred = torch.round(y_out).cpu().numpy()
         if self.strict_ids:
@@ -613,8 +626,9 @@ class CTRModel:
 
     def predict_proba(self, session, X_cate, X_cont):
         self._ensure_initialized(session)
-        idx, xc, _ = self._upload(X_cate, X_cont, np.zeros(len(X_cate), dtype=np.float32))
-        return self.predict_step_graphed(idx, xc).cpu().numpy()
+        idx, xc, _ = self._upload(X_cate, X_cont, np.zeros(len(X_cont), dtype=np.float32))
+        step = self.predict_step if isinstance(idx, Bags) else self.predict_step_graphed
+        return step(idx, xc).cpu().numpy()
 
     # hooks
     LOSS_KIND = 0
@@ -639,5 +653,12 @@ class CTRModel:
 
     def _tables_backward(self, idx, dz, bufs, routed=False):
         kw = dict(dz_in_blocks=True) if routed and hasattr(self.front, 'dz_route') else {}
-        self.front.backward_tables(idx, dz, bufs['keys'], bufs['src'], self.session.ws, self._optimizer(),
+        keys, src = bufs['keys'], bufs['src']
+        if isinstance(idx, Bags) and idx.nnz > keys.numel():
+            # one pair per bag member: a pair of buffers that only grows, shared by every batch size
+            if self._bag_pairs is None or self._bag_pairs[0].numel() < idx.nnz:
+                n = max(idx.nnz, 2 * (self._bag_pairs[0].numel() if self._bag_pairs else 0))
+                self._bag_pairs = tuple(torch.zeros(n, dtype=torch.int32, device=self.session.device) for _ in range(2))
+            keys, src = self._bag_pairs
+        self.front.backward_tables(idx, dz, keys, src, self.session.ws, self._optimizer(),
                                    lazy=(self.adam_mode == 'lazy'), **kw)

@@ -182,6 +182,45 @@ def embed_fwd(tables, row_offset, idx, x_cont=None, cont_w=None, *, E, z_out=Non
 
 
 @_timed
+def embed_bag_fwd(tables, row_offset, idx, bag_offsets, x_cont=None, cont_w=None, *, B, F, E, z_out, cont_tail=False,
+                  first_out=None, s_out=None, second_out=None, drop_first=None, drop_second=None, oor_count=None):
+    """Multi-hot front end: bag (b,f) = idx[bag_offsets[b*F+f] : bag_offsets[b*F+f+1]], sum-pooled into Z[b,f,:];
+    everything else as embed_fwd.  The CSR must be well formed (non-decreasing, ending at idx.numel())."""
+    nnz = idx.numel()
+    C_ = 0 if x_cont is None else x_cont.shape[1]
+    if idx.dtype != torch.int32 or idx.dim() != 1 or not idx.is_contiguous():
+        raise TypeError('idx must be contiguous int32 [nnz]')
+    if bag_offsets.dtype != torch.int32 or bag_offsets.numel() != B * F + 1 or not bag_offsets.is_contiguous():
+        raise ValueError('bag_offsets must be contiguous int32 [B*F+1]')
+    if row_offset.dtype != torch.int64 or row_offset.numel() != F + 1:
+        raise ValueError('row_offset must be int64 [F+1]')
+    if tables.dim() != 2 or tables.shape[1] != E or not tables.is_contiguous():
+        raise ValueError('tables must be contiguous [rows, E]')
+    if x_cont is not None and (not x_cont.is_contiguous() or x_cont.shape[0] != B):
+        raise ValueError('x_cont must be contiguous [B,C]')
+    if cont_w is not None and (tuple(cont_w.shape) != (C_, E) or not cont_w.is_contiguous()):
+        raise ValueError('cont_w must be contiguous [C,E]')
+    N = F + (C_ if cont_w is not None else 0)
+    zp, zld = _rows(z_out, 'z_out')
+    if z_out.shape[0] != B or z_out.shape[1] < N * E + (C_ if cont_tail else 0):
+        raise ValueError('z_out too small')
+    fp, fld = (None, 0) if first_out is None else _rows(first_out, 'first_out')
+    sp, sld = (None, 0) if second_out is None else _rows(second_out, 'second_out')
+    if first_out is not None and (first_out.shape[0] != B or first_out.shape[1] < N):
+        raise ValueError('first_out too small')
+    if second_out is not None and (second_out.shape[0] != B or second_out.shape[1] < E):
+        raise ValueError('second_out too small')
+    if s_out is not None and (tuple(s_out.shape) != (B, E) or not s_out.is_contiguous()):
+        raise ValueError('s_out must be contiguous [B,E]')
+    check(lib().ctr_embed_bag_fwd(_ptr(tables, torch.float32, 'tables'), _ptr(row_offset), _ptr(idx),
+                                  _ptr(bag_offsets), nnz, _ptr(x_cont, torch.float32, 'x_cont'),
+                                  _ptr(cont_w, torch.float32, 'cont_w'), B, F, C_, E, zp, zld, int(bool(cont_tail)),
+                                  fp, fld, _ptr(s_out, torch.float32, 's_out'), sp, sld, _dp(drop_first),
+                                  _dp(drop_second), _ptr(oor_count, torch.int32, 'oor_count'), _stream()),
+          'ctr_embed_bag_fwd')
+
+
+@_timed
 def embed_assemble_fwd(blocks, fbase, fstride, x_cont=None, cont_w=None, *, F, E, z_out, cont_tail=False,
                        first_out=None, s_out=None, second_out=None, drop_first=None, drop_second=None):
     """Z from per-owner row blocks (sharded tables) + continuous rows + FM sums, one pass (see embed_fwd)."""
@@ -280,6 +319,20 @@ def emb_sort(idx, row_offset, *, N, total_rows, rmode, keys_out, src_out, ws):
     wp, wn = ws.get(lib().ctr_emb_sort_workspace_bytes(n))
     check(lib().ctr_emb_sort(_ptr(idx, torch.int32), _ptr(row_offset, torch.int64), B, F, N, int(total_rows),
                              int(bool(rmode)), _ptr(keys_out), _ptr(src_out), wp, wn, _stream()), 'ctr_emb_sort')
+
+
+@_timed
+def emb_bag_sort(idx, bag_offsets, row_offset, *, B, F, N, total_rows, keys_out, src_out, ws):
+    """(key, src) pairs of multi-hot bags, sorted by key: one pair per member, src = the bag's row of dZ."""
+    nnz = idx.numel()
+    if bag_offsets.dtype != torch.int32 or bag_offsets.numel() != B * F + 1:
+        raise ValueError('bag_offsets must be int32 [B*F+1]')
+    if keys_out.numel() < nnz or src_out.numel() < nnz:
+        raise ValueError('sort outputs too small')
+    wp, wn = ws.get(lib().ctr_emb_sort_workspace_bytes(max(nnz, 1)))
+    check(lib().ctr_emb_bag_sort(_ptr(idx, torch.int32), _ptr(bag_offsets, torch.int32), nnz,
+                                 _ptr(row_offset, torch.int64), B, F, N, int(total_rows), _ptr(keys_out),
+                                 _ptr(src_out), wp, wn, _stream()), 'ctr_emb_bag_sort')
 
 
 @_timed

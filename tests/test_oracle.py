@@ -271,3 +271,22 @@ def test_lazy_adam_freezes_unseen_rows_and_equals_dense_adam_on_rows_seen_every_
         v = 0.999 * v + 0.001 * g * g
         w = w - 0.01 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (torch.sqrt(v) + 1e-8)
     assert torch.allclose(P1['t'][2], w, rtol=1e-14, atol=0)
+
+
+def test_bag_pooling_reduces_to_the_single_id_lookup_and_sums_members():
+    """The multi-hot oracle (sum pooling, not a reference input): one-member bags equal embed_block_smode; a bag
+    with repeats, an empty bag and an out-of-range member are checked by hand; gradients flow to every member."""
+    rng = np.random.default_rng(0)
+    tabs = [torch.as_tensor(rng.standard_normal((v, 4))) for v in (3, 5)]
+    X = np.array([[0, 4], [2, 1], [1, 3]])
+    one = O.BagIds(X.reshape(-1), np.arange(7), 2)
+    assert torch.equal(O.embed_block_smode(tabs, one), O.embed_block_smode(tabs, torch.as_tensor(X)))
+    # B = 2, F = 2: (0,0) = [0, 2, 2], (0,1) = [], (1,0) = [1, 7 (out of range)], (1,1) = [4]
+    bags = O.BagIds([0, 2, 2, 1, 7, 4], [0, 3, 3, 5, 6], 2)
+    W = [t.clone().requires_grad_(True) for t in tabs]
+    Z = O.embed_block_smode(W, bags)
+    assert torch.allclose(Z[0, 0], tabs[0][0] + 2 * tabs[0][2]) and torch.all(Z[0, 1] == 0)
+    assert torch.equal(Z[1, 0], tabs[0][1]) and torch.equal(Z[1, 1], tabs[1][4])
+    Z.sum().backward()
+    assert torch.equal(W[0].grad[:, 0], torch.tensor([1.0, 1.0, 2.0], dtype=torch.float64))
+    assert torch.equal(W[1].grad[:, 0], torch.tensor([0.0, 0.0, 0.0, 0.0, 1.0], dtype=torch.float64))
