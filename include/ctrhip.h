@@ -501,6 +501,28 @@ int ctr_din_build_idx(const int32_t* ids, const int32_t* cate_list, int64_t n, i
 int ctr_din_concat_fwd(const float* q, const float* k, int B, int T, int H, float* out, void* stream);
 int ctr_din_concat_bwd(const float* d_all, const float* q, const float* k, int B, int T, int H,
                        float* dq, int accumulate_q, float* dk, int accumulate_k, void* stream);
+/* The attention scoring network of DIN/DIN.py:169-185 in one launch, [B*T, 4H] never formed:
+ *   din_all = [q, k, q - k, q*k];  d1 = sigmoid(din_all W1 + b1);  d2 = sigmoid(d1 W2 + b2);  score = d2 w3 + b3
+ * q: [B,H] (the candidate item), k: [B,T,H] (the behaviour sequence), W1: [4H,80], W2: [80,40], w3: [40].
+ * d1_out [B*T,80] / d2_out [B*T,40] (optional, kept for the backward), score_out [B*T] (unmasked, unscaled: feed
+ * ctr_din_attn_pool_fwd).  H in {16, 32, 64}; ctr_din_attn_mlp_supported says whether all three calls below take
+ * a shape (the weight-gradient call holds H <= 32).
+ * _bwd: from dscore (gradient of score) and the stored d1, d2: g1_out [B*T,80] and g2_out [B*T,40] (gradients at
+ * the two pre-activations), dq_out [B,H] (overwritten) and dk [B,T,H] (added to its content when accumulate_dk).
+ * _wgrad: every parameter gradient of the network (the tf.layers.dense kernels and biases f1_att, f2_att, f3_att),
+ * summed over rows in a fixed order; workspace from ctr_din_attn_mlp_wgrad_workspace_bytes(B, H). */
+int ctr_din_attn_mlp_supported(int H, int n1, int n2);
+int ctr_din_attn_mlp_fwd(const float* q, const float* k, int B, int T, int H, const float* W1, const float* b1,
+                         const float* W2, const float* b2, const float* w3, const float* b3,
+                         float* d1_out, float* d2_out, float* score_out, void* stream);
+int ctr_din_attn_mlp_bwd(const float* q, const float* k, int B, int T, int H, const float* W1, const float* W2,
+                         const float* w3, const float* d1, const float* d2, const float* dscore,
+                         float* g1_out, float* g2_out, float* dq_out, float* dk, int accumulate_dk, void* stream);
+size_t ctr_din_attn_mlp_wgrad_workspace_bytes(int B, int H);
+int ctr_din_attn_mlp_wgrad(const float* q, const float* k, int B, int T, int H, const float* d1, const float* d2,
+                           const float* dscore, const float* g1, const float* g2,
+                           float* dW1, float* db1, float* dW2, float* db2, float* dw3, float* db3,
+                           void* workspace, size_t workspace_bytes, void* stream);
 int ctr_din_attn_pool_fwd(const float* score, const int32_t* sl, const float* K, int B, int T, int H,
                           float* att_out, float* out, void* stream);
 int ctr_din_attn_pool_bwd(const float* dout, const float* att, const int32_t* sl, const float* K,

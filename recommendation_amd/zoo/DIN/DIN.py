@@ -50,6 +50,9 @@ class DIN(object):
         self.global_step = 0
         self.global_epoch_step = 0
         self.strict_ids = bool(getattr(args, 'strict_ids', True))
+        # the attention scoring network as three fused launches (H = 16 or 32, the reference's default); any other
+        # width, or fused_attention=False, goes layer by layer through the materialised [B*T, 4H]
+        self.fused_attention = bool(getattr(args, 'fused_attention', True)) and ops.din_attn_mlp_supported(H)
         self._ready = False
         self._bufs = BufferCache()
 
@@ -154,7 +157,7 @@ class DIN(object):
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         n = B + B * T
         b = dict(pair=torch.zeros(n, 2, dtype=torch.int32, device=dev), emb=z(n, H), demb=z(n, H),
-                 ib4=z(B, 4), dib4=z(B, 4), din_all=z(B * T, 4 * H), d1=z(B * T, 80), d2=z(B * T, 40),
+                 ib4=z(B, 4), dib4=z(B, 4), din_all=z(0 if self.fused_attention else B * T, 4 * H), d1=z(B * T, 80), d2=z(B * T, 40),
                  g1=z(B * T, 80), g2=z(B * T, 40), score=z(B * T), dscore=z(B * T), att=z(B * T),
                  pooled=z(B, H), dpooled=z(B, H), xhat1=z(B, H), hist_bn=z(B, H), dhist_bn=z(B, H),
                  u_emb=z(B, H), din=z(B, 2 * H), ddin=z(B, 2 * H), xhat2=z(B, 2 * H), din_bn=z(B, 2 * H),
@@ -183,12 +186,20 @@ class DIN(object):
         """attention() + batch_normalization + dense (DIN/DIN.py:44-49); returns u_emb."""
         d, H, ws = self.dense, self.H, self.session.ws
         i_emb, h_emb = b['emb'][:B], b['emb'][B:B + B * T]
-        ops.din_concat_fwd(i_emb, h_emb, b['din_all'], B=B, T=T, H=H)
-        ops.gemm(b['din_all'], d.p('embedding/f1_att/kernel'), b['d1'], bias=d.p('embedding/f1_att/bias'),
-                 sigmoid=True, ws=ws)
-        ops.gemm(b['d1'], d.p('embedding/f2_att/kernel'), b['d2'], bias=d.p('embedding/f2_att/bias'),
-                 sigmoid=True, ws=ws)
-        ops.rowdot_fwd(b['d2'], d.p('embedding/f3_att/kernel').reshape(-1), d.p('embedding/f3_att/bias'), b['score'])
+        if self.fused_attention:
+            # the scoring network in one launch; [B*T, 4H] is never formed
+            ops.din_attn_mlp_fwd(i_emb, h_emb, d.p('embedding/f1_att/kernel'), d.p('embedding/f1_att/bias'),
+                                 d.p('embedding/f2_att/kernel'), d.p('embedding/f2_att/bias'),
+                                 d.p('embedding/f3_att/kernel').reshape(-1), d.p('embedding/f3_att/bias'), b['score'],
+                                 B=B, T=T, H=H, d1=b['d1'], d2=b['d2'])
+        else:
+            ops.din_concat_fwd(i_emb, h_emb, b['din_all'], B=B, T=T, H=H)
+            ops.gemm(b['din_all'], d.p('embedding/f1_att/kernel'), b['d1'], bias=d.p('embedding/f1_att/bias'),
+                     sigmoid=True, ws=ws)
+            ops.gemm(b['d1'], d.p('embedding/f2_att/kernel'), b['d2'], bias=d.p('embedding/f2_att/bias'),
+                     sigmoid=True, ws=ws)
+            ops.rowdot_fwd(b['d2'], d.p('embedding/f3_att/kernel').reshape(-1), d.p('embedding/f3_att/bias'),
+                           b['score'])
         ops.din_attn_pool_fwd(b['score'], sl, h_emb, b['att'], b['pooled'], B=B, T=T, H=H)
         p = 'embedding/batch_normalization/'
         ops.bn_infer(b['pooled'], b['hist_bn'], gamma=d.p(p + 'gamma'), beta=d.p(p + 'beta'),
@@ -211,6 +222,19 @@ class DIN(object):
 
     def _item_bias(self, ids, out4):
         ops.embed_fwd(self.bias_table.weight, self.bias_table.row_offset, ids.view(-1, 1), E=4, z_out=out4)
+
+    def _attention_mlp_backward_unfused(self, b, ds, i_emb, h_emb, dq, dk, B, T):
+        """The scoring network's backward layer by layer over the materialised [B*T, 4H] (any H)."""
+        d, H, ws = self.dense, self.H, self.session.ws
+        ops.rowdot_bwd_x(ds, d.p('embedding/f3_att/kernel').reshape(-1), b['g2'])
+        ops.dense_wgrad(b['d2'], ds.view(B * T, 1), d.g('embedding/f3_att/kernel'), d.g('embedding/f3_att/bias'), ws=ws)
+        ops.dsigmoid_apply(b['g2'], b['d2'])
+        ops.dense_wgrad(b['d1'], b['g2'], d.g('embedding/f2_att/kernel'), d.g('embedding/f2_att/bias'), ws=ws)
+        ops.gemm(b['g2'], d.p('embedding/f2_att/kernel'), b['g1'], trans_b=True, ws=ws)
+        ops.dsigmoid_apply(b['g1'], b['d1'])
+        ops.dense_wgrad(b['din_all'], b['g1'], d.g('embedding/f1_att/kernel'), d.g('embedding/f1_att/bias'), ws=ws)
+        ops.gemm(b['g1'], d.p('embedding/f1_att/kernel'), b['din_all'], trans_b=True, ws=ws)   # d(din_all), in place
+        ops.din_concat_bwd(b['din_all'], i_emb, h_emb, dq, dk, B=B, T=T, H=H, acc_q=False, acc_k=True)
 
     # ---- public API ------------------------------------------------------------------------
     def train(self, sess, uij, l):
@@ -278,15 +302,18 @@ class DIN(object):
         ops.din_attn_pool_bwd(b['dpooled'], b['att'], sl, h_emb, b['dscore'], dk, B=B, T=T, H=H)
         # backward: attention MLP
         ds = b['dscore']
-        ops.rowdot_bwd_x(ds, d.p('embedding/f3_att/kernel').reshape(-1), b['g2'])
-        ops.dense_wgrad(b['d2'], ds.view(B * T, 1), d.g('embedding/f3_att/kernel'), d.g('embedding/f3_att/bias'), ws=ws)
-        ops.dsigmoid_apply(b['g2'], b['d2'])
-        ops.dense_wgrad(b['d1'], b['g2'], d.g('embedding/f2_att/kernel'), d.g('embedding/f2_att/bias'), ws=ws)
-        ops.gemm(b['g2'], d.p('embedding/f2_att/kernel'), b['g1'], trans_b=True, ws=ws)
-        ops.dsigmoid_apply(b['g1'], b['d1'])
-        ops.dense_wgrad(b['din_all'], b['g1'], d.g('embedding/f1_att/kernel'), d.g('embedding/f1_att/bias'), ws=ws)
-        ops.gemm(b['g1'], d.p('embedding/f1_att/kernel'), b['din_all'], trans_b=True, ws=ws)   # d(din_all), in place
-        ops.din_concat_bwd(b['din_all'], i_emb, h_emb, dq, dk, B=B, T=T, H=H, acc_q=False, acc_k=True)
+        if self.fused_attention:
+            W1, W2 = d.p('embedding/f1_att/kernel'), d.p('embedding/f2_att/kernel')
+            w3 = d.p('embedding/f3_att/kernel').reshape(-1)
+            ops.din_attn_mlp_bwd(i_emb, h_emb, W1, W2, w3, b['d1'], b['d2'], ds, b['g1'], b['g2'], dq, dk, B=B, T=T, H=H,
+                                 acc_k=True)
+            ops.din_attn_mlp_wgrad(i_emb, h_emb, b['d1'], b['d2'], ds, b['g1'], b['g2'],
+                                   d.g('embedding/f1_att/kernel'), d.g('embedding/f1_att/bias'),
+                                   d.g('embedding/f2_att/kernel'), d.g('embedding/f2_att/bias'),
+                                   d.g('embedding/f3_att/kernel').reshape(-1), d.g('embedding/f3_att/bias'),
+                                   B=B, T=T, H=H, ws=ws)
+        else:
+            self._attention_mlp_backward_unfused(b, ds, i_emb, h_emb, dq, dk, B, T)
         ops.copy2d(b['ddin'][:, H:], dq, accumulate=True)                                # i_emb also feeds the FCN
         # sparse updates (SGD) on item/category tables and on item_b
         sgd = ops.make_opt(OPT_SGD, lr=float(l))
