@@ -302,16 +302,43 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
         us = {n: 1e3 * profile[n]['total_ms'] / PROFILE_STEPS for n in path}
         tot_b, tot_us = sum(algo[n] for n in path), sum(us.values())
         ach = tot_b / (tot_us * 1e-6) / 1e9
+        # the same bytes as cold streaming copies, one per kernel: the time a launch of that size needs at the least
+        # when it starts with the caches full of the rest of the step
+        cold = {n: cold_copy_us(algo[n], dev) for n in path}
         out['roofline_emb_path'] = dict(kernels=path, bound='hbm', bytes_per_step=tot_b, us_per_step=tot_us, achieved=ach,
                                         peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
                                         frac_of_measured_copy_peak=ach / HBM_COPY_GBS,
-                                        us={n: round(v, 2) for n, v in us.items()})
+                                        us={n: round(v, 2) for n, v in us.items()},
+                                        cold_copy_us={n: round(v, 2) for n, v in cold.items()},
+                                        frac_of_cold_copy=sum(cold.values()) / tot_us)
     out['pmc_traffic_file'] = traffic.get('_file')
     out['unique_rows_per_step'] = uniq
     out['profile_steps'] = PROFILE_STEPS
     out['kernel_ms_per_step'] = {n: round(v['total_ms'] / PROFILE_STEPS, 4) for n, v in
                                  sorted(profile.items(), key=lambda kv: -kv[1]['total_ms'])}
     return out
+
+
+def cold_copy_us(nbytes, dev, reps=5):
+    """Time of a streaming device copy that moves `nbytes` in total (half read, half written) when it starts the way
+    a kernel inside a training step does: caches holding other data (a 1 GiB fill runs before every repetition).
+    The yardstick for what a launch of this size can reach at all; mean of `reps` event-timed runs."""
+    n = max(int(nbytes) // 8, 1)
+    src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    flush = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    ts = []
+    for r in range(reps + 1):
+        flush.fill_(float(r))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        if r:
+            ts.append(e0.elapsed_time(e1) * 1e3)
+    del src, dst, flush
+    return float(np.mean(ts))
 
 
 def main():

@@ -128,8 +128,9 @@ __global__ __launch_bounds__(256) void cross_fwd_lds_kernel(const float* __restr
       p[l] = 0.f;
       if (l < L) {
 #pragma unroll
-        for (int i = 0; i < NQ; ++i)
-          if (256 * i < D) p[l] += dot4(x[i], *reinterpret_cast<const float4*>(cross_lds + l * DP + 256 * i + 4 * lane));
+        for (int i = 0; i < NQ; ++i)      // lanes past the row hold zeros and must not touch the LDS behind it
+          if (256 * i + 4 * lane < DP)
+            p[l] += dot4(x[i], *reinterpret_cast<const float4*>(cross_lds + l * DP + 256 * i + 4 * lane));
       }
     }
 #pragma unroll

@@ -21,7 +21,9 @@ constexpr int DT2 = 3;                   // layer 2 padded to 48 columns (the la
 constexpr int DS1 = DN1 + 4;             // LDS row strides: 4 rows apart = 16 banks apart
 constexpr int DS2 = 16 * DT2 + 4;
 
-__device__ static inline float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+// 1 / (1 + e^-x) on the hardware exp2 and reciprocal (about 1 ulp each, relative error ~2e-7): 128 sigmoids per
+// row would otherwise cost more vector-instruction time than the row's matrix products
+__device__ static inline float sigm(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -199,19 +201,39 @@ __global__ __launch_bounds__(256, 2) void din_mlp_bwd_kernel(const float* __rest
       qf[j] = *reinterpret_cast<const f32x4*>(q + b * H + 16 * j + 4 * kq);
       dqa[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // a strip's operands (k, d1, d2, ds of its rows) are fetched one strip ahead
+    struct In { f32x4 k[HT], y1[DT1], y2[DT2]; float ds; };
+    auto fetch = [&](int s, In& o) {
+      const int row = 16 * s + l16;
+      const bool live = row < T;
+      const int64_t m = b * T + (live ? row : T - 1);
+#pragma unroll
+      for (int j = 0; j < HT; ++j) o.k[j] = *reinterpret_cast<const f32x4*>(k + m * H + 16 * j + 4 * kq);
+#pragma unroll
+      for (int t = 0; t < DT1; ++t) o.y1[t] = *reinterpret_cast<const f32x4*>(d1 + m * DN1 + 16 * t + 4 * kq);
+#pragma unroll
+      for (int t = 0; t < DT2; ++t)
+        o.y2[t] = 16 * t + 4 * kq < DN2 ? *reinterpret_cast<const f32x4*>(d2 + m * DN2 + 16 * t + 4 * kq)
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+      o.ds = live ? ds[m] : 0.f;
+    };
+    In nxt;
+    fetch(0, nxt);
     for (int s = 0; s < strips; ++s) {
       const int row = 16 * s + l16;
       const bool live = row < T;
       const int64_t m = b * T + (live ? row : T - 1);
-      const float dsv = live ? ds[m] : 0.f;
+      const In cur = nxt;
+      if (s + 1 < strips) fetch(s + 1, nxt);
+      const float dsv = cur.ds;
       f32x4 kf[HT];
 #pragma unroll
-      for (int j = 0; j < HT; ++j) kf[j] = *reinterpret_cast<const f32x4*>(k + m * H + 16 * j + 4 * kq);
+      for (int j = 0; j < HT; ++j) kf[j] = cur.k[j];
       f32x4 gg2[DT2];
 #pragma unroll
       for (int t = 0; t < DT2; ++t) {
         const bool in = 16 * t + 4 * kq < DN2;
-        const f32x4 y = in ? *reinterpret_cast<const f32x4*>(d2 + m * DN2 + 16 * t + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 y = cur.y2[t];
         const f32x4 w = *reinterpret_cast<const f32x4*>(w3s + 16 * t + 4 * kq);
 #pragma unroll
         for (int r = 0; r < 4; ++r) gg2[t][r] = dsv * w[r] * (y[r] * (1.f - y[r]));
@@ -231,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void din_mlp_bwd_kernel(const float* __rest
         }
 #pragma unroll
       for (int t = 0; t < DT1; ++t) {
-        const f32x4 y = *reinterpret_cast<const f32x4*>(d1 + m * DN1 + 16 * t + 4 * kq);
+        const f32x4 y = cur.y1[t];
 #pragma unroll
         for (int r = 0; r < 4; ++r) gg1[t][r] *= y[r] * (1.f - y[r]);
         if (live) *reinterpret_cast<f32x4*>(g1 + m * DN1 + 16 * t + 4 * kq) = gg1[t];

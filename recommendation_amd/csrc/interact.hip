@@ -729,8 +729,9 @@ __global__ __launch_bounds__(256, 2) void afm_attn_kernel(const float* __restric
               const float zv = (j < N && eok) ? Zs[j * ES + e] : 0.f;
               Tc = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? ck[k] : 0.f, zv, Tc, 0, 0, 0);
 #pragma unroll
-              for (int a = 0; a < 16; ++a)  // mask bits at and beyond A are zero
-                T[a] = __builtin_amdgcn_mfma_f32_16x16x4f32((bits >> a & 1u) ? dek : 0.f, zv, T[a], 0, 0, 0);
+              for (int a = 0; a < 16; ++a)  // units at and beyond A have no mask bits and no weights: skipped
+                if (a0 + a < A)
+                  T[a] = __builtin_amdgcn_mfma_f32_16x16x4f32((bits >> a & 1u) ? dek : 0.f, zv, T[a], 0, 0, 0);
             }
             // element r of lane (g4, l16): row i0 + 4 g4 + r, column e
             if (eok) {

@@ -195,8 +195,7 @@ def test_training_steps_are_reproducible_at_full_size(sess):
     batches = make_batches(list(CRITEO_KAGGLE), 13, B, 3, 1.05, 9, DEV)
     runs = []
     for _ in range(2):
-        args = SimpleNamespace(model='DeepFM', embed=16, shard='table', comm='rccl')
-        model = bench.build_model(args, sess, list(CRITEO_KAGGLE), 0, 1)
+        model = bench.build_model('DeepFM', 16, 'table', 'rccl', sess, list(CRITEO_KAGGLE), 0, 1)
         losses = [float(model.train_step(*b).item()) for b in batches]
         runs.append(losses)
         del model

@@ -412,6 +412,33 @@ def test_cross_network_fwd_bwd(ops_ws, D, L, B):
     assert rel_err(db.cpu().numpy(), np.stack([t.grad.numpy().reshape(-1) for t in tb])) < 1e-5
 
 
+def test_cross_network_short_rows_ignore_stale_lds(ops_ws):
+    """Rows much shorter than a wave's 256-column reach (D = 43): the lanes past the row must not read the LDS
+    behind the staged weights.  A GEMM over NaN operands first leaves NaN bit patterns in every CU's LDS."""
+    ops, ws = ops_ws
+    rng = np.random.default_rng(43)
+    B, D, L = 300, 43, 3
+    x0 = (rng.standard_normal((B, D)) * 0.5).astype(np.float32)
+    w = (rng.standard_normal((L, D)) * 0.05).astype(np.float32)
+    b = (rng.standard_normal((L, D)) * 0.05).astype(np.float32)
+    x0p = np.zeros((B, 44), dtype=np.float32); x0p[:, :D] = x0
+    d_x0, d_w, d_b = dev(x0p), dev(w), dev(b)
+    tx = torch.tensor(x0, dtype=torch.float64)
+    ref = O.dcn_cross(tx, [torch.tensor(w[l].reshape(D, 1), dtype=torch.float64) for l in range(L)],
+                      [torch.tensor(b[l].reshape(D, 1), dtype=torch.float64) for l in range(L)]).numpy()
+    nan_a = torch.full((4096, 256), float('nan'), device=DEV)
+    nan_b = torch.full((256, 256), float('nan'), device=DEV)
+    nan_c = torch.zeros(4096, 256, device=DEV)
+    for _ in range(5):
+        ops.gemm(nan_a, nan_b, nan_c, ws=ws)
+        xL = torch.zeros(B, D, device=DEV)
+        aux = torch.zeros(B, 2 * L, device=DEV)
+        ops.cross_fwd(d_x0, d_w, d_b, xL, aux, ws)
+        out = xL.cpu().numpy()
+        assert np.isfinite(out).all() and np.isfinite(aux.cpu().numpy()).all()
+        assert rel_err(out, ref) < 1e-5
+
+
 @pytest.mark.parametrize('B,N,E,A,keep', [(5, 2, 4, 1, 1.0), (70, 7, 8, 10, 1.0), (33, 39, 16, 16, 0.7),
                                           (9, 20, 64, 32, 1.0), (1100, 12, 16, 5, 0.5)])
 def test_afm_attention_over_pairs_fwd_bwd(ops_ws, B, N, E, A, keep):
