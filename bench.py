@@ -147,11 +147,18 @@ def load_traffic(model):
         return out
     paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_%s_*pmc_traffic.json' % tag)))
     if paths:
+        # operator -> the kernel symbols one call of it launches (the cross operators have an LDS-resident form and,
+        # backward, the two kernels of the dw/db reduction; the sparse update its tail)
+        parts = {'embed_fwd_kernel': ('embed_fwd_kernel', 'embed_fwd_wide_kernel'),
+                 'sparse_apply_kernel': ('sparse_apply_kernel', 'sparse_apply_tail_kernel'),
+                 'embed_bwd_dz_kernel': ('embed_bwd_dz_kernel',),
+                 'cross_fwd_kernel': ('cross_fwd_kernel', 'cross_fwd_lds_kernel'),
+                 'cross_bwd_kernel': ('cross_bwd_kernel', 'cross_bwd_lds_kernel', 'cross_bwd_partial_kernel',
+                                      'cross_bwd_final_kernel')}
         for k, v in json.load(open(paths[-1])).items():
-            for sym in ('embed_fwd_kernel', 'sparse_apply_kernel', 'embed_bwd_dz_kernel', 'cross_fwd_kernel',
-                        'cross_bwd_kernel'):
-                if sym + '<' in k or sym + '(' in k:
-                    out[sym] = out.get(sym, 0) + v['hbm_bytes_per_launch']
+            for op, syms in parts.items():
+                if any(sym + '<' in k or sym + '(' in k for sym in syms):
+                    out[op] = out.get(op, 0) + v['hbm_bytes_per_launch']
         out['_file'] = os.path.basename(paths[-1])
     return out
 
@@ -294,7 +301,13 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
         r['alone_frac'] = r['bytes_per_launch'] / (alone_us * 1e-6) / 1e9 / HBM_PEAK_GBS
     for name in ('cross_fwd', 'cross_bwd'):
         if name in ks:
-            out['roofline_' + name] = roof_of(name)
+            r = out['roofline_' + name] = roof_of(name)
+            if name == 'cross_bwd' and name in profile:
+                # like the sparse update, the cross backward runs beside the tower weight gradients of the side stream
+                alone_us = 1e3 * profile[name]['total_ms'] / max(profile[name]['calls'], 1)
+                r['shares_gpu_with'] = 'tower weight gradients (side stream)'
+                r['alone_avg_us'] = alone_us
+                r['alone_frac'] = r['bytes_per_launch'] / (alone_us * 1e-6) / 1e9 / HBM_PEAK_GBS
     # the whole embedding path of a step (gather, dZ, pair sort, segment-reduce + row update), single-stream times
     # of the profiling pass: algorithmic bytes of the pieces over their summed time
     path = [n for n in ('embed_fwd', 'embed_bwd_dz', 'emb_sort', 'emb_sparse_apply') if n in profile]

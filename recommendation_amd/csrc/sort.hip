@@ -16,29 +16,46 @@ constexpr int RBITS = 9;                             // digit width: 26-bit row 
 constexpr int RBINS = 1 << RBITS;
 constexpr int BINS_PER_THREAD = RBINS / SORT_THREADS;
 
-__global__ __launch_bounds__(256) void build_pairs_kernel(
+// One block per sort tile: builds the tile's pairs and, while the keys are in registers, the tile's digit
+// histogram of the first radix pass (counts[digit][tile], what radix_hist_kernel would write for shift 0), so the
+// first pass starts at its scan.  32-bit index arithmetic: B*F < 2^32 is required by the callers.
+__global__ __launch_bounds__(SORT_THREADS) void build_pairs_kernel(
     const int32_t* __restrict__ idx, const int64_t* __restrict__ row_offset, int B, int F, int N,
-    int64_t total_rows, int rmode, uint32_t* __restrict__ keys, uint32_t* __restrict__ src) {
-  const int64_t n = (int64_t)B * F;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int f = (int)(i % F);
-    const int64_t b = i / F;
-    const int x = idx[i];
+    int64_t total_rows, int rmode, uint32_t* __restrict__ keys, uint32_t* __restrict__ src, int nblocks,
+    uint32_t* __restrict__ counts) {
+  __shared__ uint32_t hist[RBINS];
+  for (int d = threadIdx.x; d < RBINS; d += SORT_THREADS) hist[d] = 0;
+  __syncthreads();
+  const uint32_t n = (uint32_t)B * (uint32_t)F;
+  const uint32_t base = blockIdx.x * (uint32_t)SORT_TILE;
+  int x[SORT_CHUNKS];
+#pragma unroll
+  for (int c = 0; c < SORT_CHUNKS; ++c) {
+    const uint32_t i = base + c * SORT_THREADS + threadIdx.x;
+    x[c] = i < n ? idx[i] : 0;
+  }
+#pragma unroll
+  for (int c = 0; c < SORT_CHUNKS; ++c) {
+    const uint32_t i = base + c * SORT_THREADS + threadIdx.x;
+    if (i >= n) continue;
+    const uint32_t b = i / (uint32_t)F, f = i - b * (uint32_t)F;
     const int64_t off = row_offset[f];
     const int64_t V = row_offset[f + 1] - off;
-    const bool ok = x >= 0 && x < V;
+    const bool ok = x[c] >= 0 && x[c] < V;
     uint32_t k, s;
     if (rmode) {
       k = ok ? (uint32_t)(off + 1) : (uint32_t)total_rows;
-      s = ok ? (uint32_t)(b * N + off + x) : 0u;
+      s = ok ? (uint32_t)((int64_t)b * N + off + x[c]) : 0u;
     } else {
-      k = ok ? (uint32_t)(off + x) : (uint32_t)total_rows;
-      s = (uint32_t)(b * N + f);
+      k = ok ? (uint32_t)(off + x[c]) : (uint32_t)total_rows;
+      s = b * (uint32_t)N + f;
     }
     keys[i] = k;
     src[i] = s;
+    atomicAdd(&hist[k & (RBINS - 1)], 1u);
   }
+  __syncthreads();
+  for (int d = threadIdx.x; d < RBINS; d += SORT_THREADS) counts[(int64_t)d * nblocks + blockIdx.x] = hist[d];
 }
 
 // Pair builder for multi-hot bags (CSR): one pair per member j of bag (b, f), key = the member's table row,
@@ -243,11 +260,12 @@ static SortWs carve(void* ws, int64_t n) {
 // Sorts the pairs currently in (ka, va); the result lands in (keys_out, vals_out).
 // (ka, va) must be (keys_out, vals_out) when the pass count is even, else the tmp pair.
 static int run_passes(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, int64_t n, int passes,
-                      const SortWs& w, hipStream_t st) {
+                      const SortWs& w, hipStream_t st, bool first_hist_done = false) {
   for (int p = 0; p < passes; ++p) {
     const int shift = RBITS * p;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, n, shift,
-                       w.nblocks, w.counts);
+    if (p > 0 || !first_hist_done)
+      hipLaunchKernelGGL(radix_hist_kernel, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, n, shift,
+                         w.nblocks, w.counts);
     hipLaunchKernelGGL(radix_scan_kernel, dim3(RBINS), dim3(256), 0, st, w.counts, w.nblocks, w.totals);
     hipLaunchKernelGGL(radix_scatter_kernel, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, va, n,
                        shift, w.nblocks, w.counts, w.totals, kb, vb);
@@ -366,6 +384,7 @@ extern "C" int ctr_emb_sort(const int32_t* idx, const int64_t* row_offset, int B
   CTR_REQUIRE(B >= 0 && F >= 0 && N > 0, "ctr_emb_sort: bad size");
   CTR_REQUIRE(total_rows > 0 && total_rows < 0xFFFFFFFFll, "ctr_emb_sort: total_rows must fit 32 bits");
   CTR_REQUIRE((int64_t)B * N < 0xFFFFFFFFll, "ctr_emb_sort: B*N must fit 32 bits");
+  CTR_REQUIRE(n < 0xFFFFF000ll, "ctr_emb_sort: B*F must stay below 2^32 - 4096");
   if (n == 0) return CTR_OK;
   CTR_REQUIRE(idx && row_offset && keys_out && src_out && workspace, "ctr_emb_sort: null pointer");
   if (workspace_bytes < sort_ws_bytes(n)) {
@@ -379,10 +398,9 @@ extern "C" int ctr_emb_sort(const int32_t* idx, const int64_t* row_offset, int B
   uint32_t* va = (passes % 2 == 0) ? src_out : w.vals_tmp;
   uint32_t* kb = (passes % 2 == 0) ? w.keys_tmp : keys_out;
   uint32_t* vb = (passes % 2 == 0) ? w.vals_tmp : src_out;
-  const int64_t blocks = cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048;
-  hipLaunchKernelGGL(build_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, idx, row_offset, B, F,
-                     N, total_rows, rmode, ka, va);
-  run_passes(ka, va, kb, vb, n, passes, w, st);
+  hipLaunchKernelGGL(build_pairs_kernel, dim3((unsigned)w.nblocks), dim3(SORT_THREADS), 0, st, idx, row_offset, B, F,
+                     N, total_rows, rmode, ka, va, w.nblocks, w.counts);
+  run_passes(ka, va, kb, vb, n, passes, w, st, true);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
