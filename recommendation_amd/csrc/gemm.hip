@@ -980,12 +980,14 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
   }
   hipStream_t st = (hipStream_t)stream;
   // narrow tower layers: the whole B chunk in LDS, A streamed (see skinny_gemm_kernel)
-  if (!trans_a && M >= 4096 && K <= 256 && K % 16 == 0 && N <= 256 && lda % 4 == 0 && ((uintptr_t)A % 16) == 0) {
+  if (!trans_a && M >= 1024 && K <= 256 && K % 16 == 0 && N <= 256 && lda % 4 == 0 && ((uintptr_t)A % 16) == 0) {
     int nc = N <= 32 ? 32 : N <= 64 ? 64 : 128;
     if ((size_t)K * (nc + 4) * sizeof(float) > 72 * 1024 && nc == 128) nc = 64;
     const size_t lds = (size_t)K * (nc + 4) * sizeof(float);
     const int chunks = (int)cdiv(N, nc);
-    if (lds <= 72 * 1024 && chunks == 1 && !trans_b && N <= 64) {
+    // large M: only the narrow (N <= 64) untransposed layers win over the tile kernels (measured); a few thousand
+    // rows leave the 128 x 128 tiles a handful of blocks, so every shape that fits goes the strip way there
+    if (lds <= 72 * 1024 && chunks == 1 && ((!trans_b && N <= 64) || M < 8192)) {
       const int strips = (int)cdiv(M, 32);
       int blocks = (int)cdiv(strips, 4);
       const int cap = 256 * (lds > 40 * 1024 ? 2 : 4) / chunks;  // resident blocks the LDS allows
