@@ -12,17 +12,22 @@ constexpr int SORT_THREADS = 256;
 constexpr int SORT_WAVES = SORT_THREADS / 64;
 constexpr int SORT_CHUNKS = 8;                       // 64-key chunks per wave
 constexpr int SORT_TILE = SORT_THREADS * SORT_CHUNKS;  // 2048 keys per block
-constexpr int RBITS = 9;                             // digit width: 26-bit row keys sort in 3 passes
-constexpr int RBINS = 1 << RBITS;
-constexpr int BINS_PER_THREAD = RBINS / SORT_THREADS;
+// digit width RB: 9 bits (26-bit row keys sort in 3 passes), or 10 where that saves a pass (19-20, 28-30 bits)
+constexpr int RBITS_MAX = 10;
+constexpr int RBINS_MAX = 1 << RBITS_MAX;
+static inline int digit_bits(int key_bits) {
+  return (key_bits + 9) / 10 < (key_bits + 8) / 9 ? 10 : 9;
+}
 
 // One block per sort tile: builds the tile's pairs and, while the keys are in registers, the tile's digit
 // histogram of the first radix pass (counts[digit][tile], what radix_hist_kernel would write for shift 0), so the
 // first pass starts at its scan.  32-bit index arithmetic: B*F < 2^32 is required by the callers.
+template <int RB>
 __global__ __launch_bounds__(SORT_THREADS) void build_pairs_kernel(
     const int32_t* __restrict__ idx, const int64_t* __restrict__ row_offset, int B, int F, int N,
     int64_t total_rows, int rmode, uint32_t* __restrict__ keys, uint32_t* __restrict__ src, int nblocks,
-    uint32_t* __restrict__ counts) {
+    uint32_t* __restrict__ counts) {  constexpr int RBITS = RB, RBINS = 1 << RB, BINS_PER_THREAD = RBINS / SORT_THREADS;
+
   __shared__ uint32_t hist[RBINS];
   for (int d = threadIdx.x; d < RBINS; d += SORT_THREADS) hist[d] = 0;
   __syncthreads();
@@ -78,8 +83,10 @@ __global__ __launch_bounds__(256) void build_bag_pairs_kernel(
   }
 }
 
+template <int RB>
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(
-    const uint32_t* __restrict__ keys, int64_t n, int shift, int nblocks, uint32_t* __restrict__ counts) {
+    const uint32_t* __restrict__ keys, int64_t n, int shift, int nblocks, uint32_t* __restrict__ counts) {  constexpr int RBITS = RB, RBINS = 1 << RB, BINS_PER_THREAD = RBINS / SORT_THREADS;
+
   __shared__ uint32_t hist[RBINS];
   for (int d = threadIdx.x; d < RBINS; d += SORT_THREADS) hist[d] = 0;
   __syncthreads();
@@ -143,10 +150,12 @@ __global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ 
   if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+template <int RB>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t n, int shift,
     int nblocks, const uint32_t* __restrict__ scanned, const uint32_t* __restrict__ totals,
-    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {  constexpr int RBITS = RB, RBINS = 1 << RB, BINS_PER_THREAD = RBINS / SORT_THREADS;
+
   __shared__ uint32_t whist[SORT_WAVES][RBINS];
   __shared__ uint32_t dbase[RBINS];
   __shared__ uint32_t wtot[SORT_WAVES];
@@ -243,7 +252,7 @@ struct SortWs {
 
 static size_t sort_ws_bytes(int64_t n) {
   const int64_t nblocks = cdiv(n > 0 ? n : 1, SORT_TILE);
-  return align_up((size_t)n * 4, 256) * 2 + align_up((size_t)nblocks * RBINS * 4, 256) + RBINS * 4;
+  return align_up((size_t)n * 4, 256) * 2 + align_up((size_t)nblocks * RBINS_MAX * 4, 256) + RBINS_MAX * 4;
 }
 
 static SortWs carve(void* ws, int64_t n) {
@@ -252,23 +261,32 @@ static SortWs carve(void* ws, int64_t n) {
   w.nblocks = (int)cdiv(n > 0 ? n : 1, SORT_TILE);
   w.keys_tmp = (uint32_t*)p; p += align_up((size_t)n * 4, 256);
   w.vals_tmp = (uint32_t*)p; p += align_up((size_t)n * 4, 256);
-  w.counts = (uint32_t*)p; p += align_up((size_t)w.nblocks * RBINS * 4, 256);
+  w.counts = (uint32_t*)p; p += align_up((size_t)w.nblocks * RBINS_MAX * 4, 256);
   w.totals = (uint32_t*)p;
   return w;
 }
 
 // Sorts the pairs currently in (ka, va); the result lands in (keys_out, vals_out).
 // (ka, va) must be (keys_out, vals_out) when the pass count is even, else the tmp pair.
-static int run_passes(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, int64_t n, int passes,
+static int run_passes(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, int64_t n, int passes, int rb,
                       const SortWs& w, hipStream_t st, bool first_hist_done = false) {
   for (int p = 0; p < passes; ++p) {
-    const int shift = RBITS * p;
-    if (p > 0 || !first_hist_done)
-      hipLaunchKernelGGL(radix_hist_kernel, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, n, shift,
-                         w.nblocks, w.counts);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(RBINS), dim3(256), 0, st, w.counts, w.nblocks, w.totals);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, va, n,
-                       shift, w.nblocks, w.counts, w.totals, kb, vb);
+    const int shift = rb * p;
+    if (p > 0 || !first_hist_done) {
+      if (rb == 10)
+        hipLaunchKernelGGL(radix_hist_kernel<10>, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, n, shift, w.nblocks,
+                           w.counts);
+      else
+        hipLaunchKernelGGL(radix_hist_kernel<9>, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, n, shift, w.nblocks,
+                           w.counts);
+    }
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(1 << rb), dim3(256), 0, st, w.counts, w.nblocks, w.totals);
+    if (rb == 10)
+      hipLaunchKernelGGL(radix_scatter_kernel<10>, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, va, n, shift,
+                         w.nblocks, w.counts, w.totals, kb, vb);
+    else
+      hipLaunchKernelGGL(radix_scatter_kernel<9>, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, va, n, shift,
+                         w.nblocks, w.counts, w.totals, kb, vb);
     uint32_t* t;
     t = ka; ka = kb; kb = t;
     t = va; va = vb; vb = t;
@@ -360,14 +378,14 @@ extern "C" int ctr_auc(const float* score, const float* label, int64_t n, float*
   double* part = (double*)p; p += AUC_BLOCKS * 3 * sizeof(double);
   const SortWs w = carve(p, n);
   const int64_t blocks = cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048;
-  const int passes = (32 + RBITS - 1) / RBITS;
+  const int rb = digit_bits(32), passes = (32 + rb - 1) / rb;
   // the pass count decides which buffer pair the sort starts from so that it ends in (keys, vals)
   uint32_t* ka = (passes % 2 == 0) ? keys : w.keys_tmp;
   uint32_t* va = (passes % 2 == 0) ? vals : w.vals_tmp;
   uint32_t* kb = (passes % 2 == 0) ? w.keys_tmp : keys;
   uint32_t* vb = (passes % 2 == 0) ? w.vals_tmp : vals;
   hipLaunchKernelGGL(auc_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, st, score, label, n, ka, va);
-  run_passes(ka, va, kb, vb, n, passes, w, st);
+  run_passes(ka, va, kb, vb, n, passes, rb, w, st);
   const int nb = (int)(cdiv(n, 256) < AUC_BLOCKS ? cdiv(n, 256) : AUC_BLOCKS);
   hipLaunchKernelGGL(auc_partial_kernel, dim3(nb), dim3(256), 0, st, keys, vals, n, score, label, part);
   hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(1), 0, st, part, nb, n, auc_out, logloss_out);
@@ -393,14 +411,18 @@ extern "C" int ctr_emb_sort(const int32_t* idx, const int64_t* row_offset, int B
   }
   hipStream_t st = (hipStream_t)stream;
   const SortWs w = carve(workspace, n);
-  const int passes = (bits_for((uint64_t)total_rows) + RBITS - 1) / RBITS;
+  const int kbits = bits_for((uint64_t)total_rows), rb = digit_bits(kbits), passes = (kbits + rb - 1) / rb;
   uint32_t* ka = (passes % 2 == 0) ? keys_out : w.keys_tmp;
   uint32_t* va = (passes % 2 == 0) ? src_out : w.vals_tmp;
   uint32_t* kb = (passes % 2 == 0) ? w.keys_tmp : keys_out;
   uint32_t* vb = (passes % 2 == 0) ? w.vals_tmp : src_out;
-  hipLaunchKernelGGL(build_pairs_kernel, dim3((unsigned)w.nblocks), dim3(SORT_THREADS), 0, st, idx, row_offset, B, F,
-                     N, total_rows, rmode, ka, va, w.nblocks, w.counts);
-  run_passes(ka, va, kb, vb, n, passes, w, st, true);
+  if (rb == 10)
+    hipLaunchKernelGGL(build_pairs_kernel<10>, dim3((unsigned)w.nblocks), dim3(SORT_THREADS), 0, st, idx, row_offset, B,
+                       F, N, total_rows, rmode, ka, va, w.nblocks, w.counts);
+  else
+    hipLaunchKernelGGL(build_pairs_kernel<9>, dim3((unsigned)w.nblocks), dim3(SORT_THREADS), 0, st, idx, row_offset, B,
+                       F, N, total_rows, rmode, ka, va, w.nblocks, w.counts);
+  run_passes(ka, va, kb, vb, n, passes, rb, w, st, true);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
@@ -420,7 +442,7 @@ extern "C" int ctr_emb_bag_sort(const int32_t* idx, const int32_t* bag_offsets, 
   }
   hipStream_t st = (hipStream_t)stream;
   const SortWs w = carve(workspace, nnz);
-  const int passes = (bits_for((uint64_t)total_rows) + RBITS - 1) / RBITS;
+  const int kbits = bits_for((uint64_t)total_rows), rb = digit_bits(kbits), passes = (kbits + rb - 1) / rb;
   uint32_t* ka = (passes % 2 == 0) ? keys_out : w.keys_tmp;
   uint32_t* va = (passes % 2 == 0) ? src_out : w.vals_tmp;
   uint32_t* kb = (passes % 2 == 0) ? w.keys_tmp : keys_out;
@@ -429,7 +451,7 @@ extern "C" int ctr_emb_bag_sort(const int32_t* idx, const int32_t* bag_offsets, 
   const int64_t blocks = cdiv(nbags, 256) < 2048 ? cdiv(nbags, 256) : 2048;
   hipLaunchKernelGGL(build_bag_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, idx, bag_offsets, row_offset,
                      B, F, N, total_rows, ka, va);
-  run_passes(ka, va, kb, vb, nnz, passes, w, st);
+  run_passes(ka, va, kb, vb, nnz, passes, rb, w, st);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
@@ -493,7 +515,7 @@ extern "C" int ctr_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, 
   }
   hipStream_t st = (hipStream_t)stream;
   const SortWs w = carve(workspace, n);
-  const int passes = (key_bits + RBITS - 1) / RBITS;
+  const int rb = digit_bits(key_bits), passes = (key_bits + rb - 1) / rb;
   uint32_t* ka = (passes % 2 == 0) ? keys_out : w.keys_tmp;
   uint32_t* va = (passes % 2 == 0) ? vals_out : w.vals_tmp;
   uint32_t* kb = (passes % 2 == 0) ? w.keys_tmp : keys_out;
@@ -501,7 +523,7 @@ extern "C" int ctr_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, 
   hipError_t e = hipMemcpyAsync(ka, keys_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(va, vals_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
   if (e != hipSuccess) { set_error("ctr_sort_pairs: copy failed: %s", hipGetErrorString(e)); return (int)e; }
-  run_passes(ka, va, kb, vb, n, passes, w, st);
+  run_passes(ka, va, kb, vb, n, passes, rb, w, st);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }

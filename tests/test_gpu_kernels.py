@@ -26,7 +26,8 @@ def ops_ws(sess):
 
 
 @pytest.mark.parametrize('n,bits', [(1, 3), (63, 8), (64, 9), (4097, 17), (200000, 26), (70001, 32), (300000, 2),
-                                    (5000, 2), (8192, 26), (8193, 26), (777, 32)])
+                                    (5000, 2), (8192, 26), (8193, 26), (777, 32),
+                                    (50000, 19), (100000, 20), (4097, 10), (30000, 30), (6000, 28)])   # 10-bit digits
 def test_sort_pairs_stable_exact(ops_ws, n, bits):
     ops, ws = ops_ws
     rng = np.random.default_rng(n + bits)
