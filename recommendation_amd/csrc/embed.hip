@@ -283,6 +283,46 @@ __global__ __launch_bounds__(256) void embed_bwd_dz_kernel(
   }
 }
 
+// Plain lookup, no reductions, for inputs with very few fields (DIN's item / category pair, a bias column): the
+// sample-per-16-lanes layout above would leave most lanes without a row.  G lanes per (sample, field) row,
+// 256 / G rows per block step, four steps in flight (ids first, then the rows they address).
+template <int G>
+__global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restrict__ tables,
+                                                          const int64_t* __restrict__ row_offset,
+                                                          const int32_t* __restrict__ idx, int B, int F, int E,
+                                                          float* __restrict__ z_out, int64_t z_ld,
+                                                          int32_t* __restrict__ oor_count) {
+  constexpr int ROWS = 256 / G, UNR = 4;
+  const int g = threadIdx.x % G;
+  const uint32_t total = (uint32_t)B * (uint32_t)F;
+  for (uint32_t base = blockIdx.x * (uint32_t)(ROWS * UNR); base < total; base += gridDim.x * (uint32_t)(ROWS * UNR)) {
+    int x[UNR];
+    uint32_t r[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      r[u] = base + u * ROWS + threadIdx.x / G;
+      x[u] = r[u] < total ? idx[r[u]] : -1;
+    }
+    float4 z[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      z[u] = f4_zero();
+      if (r[u] >= total) continue;
+      const uint32_t f = r[u] % (uint32_t)F;
+      const int64_t off = row_offset[f];
+      const int64_t V = row_offset[f + 1] - off;
+      if (x[u] >= 0 && x[u] < V) z[u] = *reinterpret_cast<const float4*>(tables + (off + x[u]) * E + g * 4);
+      else if (oor_count && g == 0) atomicAdd(oor_count, 1);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (r[u] >= total) continue;
+      const uint32_t b = r[u] / (uint32_t)F, f = r[u] - b * (uint32_t)F;
+      *reinterpret_cast<float4*>(z_out + (int64_t)b * z_ld + (int64_t)f * E + g * 4) = z[u];
+    }
+  }
+}
+
 // Multi-hot front end, first step: every bag (b, f) of a CSR list is summed into Z[b, f, :] in member order (a
 // fixed order, so the result is bitwise reproducible); G = E/4 lanes cover a row, a bag's members go four at a
 // time (ids first, then the four row loads they address).  Continuous rows and the x_cont tail are written as in
@@ -358,6 +398,26 @@ static int embed_fwd_impl(const float* tables, const int64_t* row_offset, const 
   const dim3 grid((unsigned)cdiv(B, 16)), wgrid((unsigned)cdiv(B, 4)), block(256);
   const size_t lds = (size_t)(F + 1) * sizeof(int64_t);
   hipStream_t st = (hipStream_t)stream;
+  if (F > 0 && F <= 4 && !blk && z_out && !first_out && !s_out && !second_out && N == F && !cont_tail &&
+      (int64_t)B * F < 0xFFFF0000ll) {
+    const int G = E / 4;
+    const int64_t steps = cdiv((int64_t)B * F, (256 / G) * 4);
+    const dim3 ggrid((unsigned)(steps < 16384 ? steps : 16384));
+#define GATHER(GG) hipLaunchKernelGGL((embed_gather_kernel<GG>), ggrid, block, 0, st, tables, row_offset, idx, B, F, E, \
+                                      z_out, z_ld, oor_count)
+    switch (G) {
+      case 1: GATHER(1); break;
+      case 2: GATHER(2); break;
+      case 4: GATHER(4); break;
+      case 8: GATHER(8); break;
+      case 16: GATHER(16); break;
+      case 32: GATHER(32); break;
+      case 64: GATHER(64); break;
+    }
+#undef GATHER
+    CTR_LAUNCH_CHECK();
+    return CTR_OK;
+  }
 #define LAUNCH(GG)                                                                                  \
   hipLaunchKernelGGL((embed_fwd_kernel<GG, false>), grid, block, lds, st, tables, row_offset, idx, x_cont, \
                      cont_w, B, F, C, E, z_out, z_ld, cont_tail, first_out, first_ld, s_out,       \
