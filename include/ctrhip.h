@@ -249,9 +249,13 @@ typedef struct {
  *   CTR_GEMM_FP32_MFMA   v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain.
  *   CTR_GEMM_SPLIT_BF16  every fp32 operand split exactly into three bf16 terms and the product
  *                        accumulated in fp32 from six bf16 MFMAs: fp32-level accuracy (~1e-7
- *                        relative, different rounding order) at 2.7x the matrix-core rate. */
+ *                        relative, different rounding order) at 2.7x the matrix-core rate.
+ *   CTR_GEMM_BF16        operands rounded to bf16 (nearest even), one bf16 MFMA per product, fp32
+ *                        accumulate: a reduced-precision mode for the tile kernel (~4e-3 relative per
+ *                        operand), opt-in only; the narrow-layer, chained and streamed kernels stay fp32. */
 #define CTR_GEMM_FP32_MFMA 0
 #define CTR_GEMM_SPLIT_BF16 1
+#define CTR_GEMM_BF16 2
 int ctr_set_gemm_mode(int mode);
 int ctr_get_gemm_mode(void);
 /* Diagnostic: resident blocks per CU the runtime grants the 128x128 split tile kernel (designed for 2); < 0 on error. */

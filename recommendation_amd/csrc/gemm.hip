@@ -330,21 +330,28 @@ __device__ static inline void split_load8(const float* __restrict__ P, int64_t l
     if (k0 + j < kend) v[j] = KCONTIG ? p[j] : p[(int64_t)j * ld];
 }
 
-// S: three planes [3][R][SROW] of bf16; writes the hi / mid / lo terms of v at (row, 8*kg .. 8*kg+7)
+// S: PL planes [PL][R][SROW] of bf16; writes the hi / mid / lo terms of v at (row, 8*kg .. 8*kg+7).  PL = 1 keeps
+// only the leading term: v rounded to bf16 (round to nearest even), the plain bf16-in / fp32-accumulate product.
+template <int PL>
 __device__ static inline void split_store8(__bf16* __restrict__ S, int R, int row, int kg, const float (&v)[8]) {
   bf16x8 hi, mid, lo;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const __bf16 h = (__bf16)v[j];
-    const float r1 = v[j] - (float)h;
-    const __bf16 m = (__bf16)r1;
-    const float r2 = r1 - (float)m;
-    hi[j] = h; mid[j] = m; lo[j] = (__bf16)r2;
+    hi[j] = h;
+    if (PL == 3) {
+      const float r1 = v[j] - (float)h;
+      const __bf16 m = (__bf16)r1;
+      const float r2 = r1 - (float)m;
+      mid[j] = m; lo[j] = (__bf16)r2;
+    }
   }
   __bf16* p = S + row * SROW + kg * 8;
   *reinterpret_cast<bf16x8*>(p) = hi;
-  *reinterpret_cast<bf16x8*>(p + R * SROW) = mid;
-  *reinterpret_cast<bf16x8*>(p + 2 * R * SROW) = lo;
+  if (PL == 3) {
+    *reinterpret_cast<bf16x8*>(p + R * SROW) = mid;
+    *reinterpret_cast<bf16x8*>(p + 2 * R * SROW) = lo;
+  }
 }
 
 // Pipeline: LDS holds two stages.  In iteration s a wave (1) issues the global loads of stage s+2 into one
@@ -352,7 +359,7 @@ __device__ static inline void split_store8(__bf16* __restrict__ S, int R, int ro
 // writes them to buffer (s+1)%2 - the split's VALU and LDS writes fill the issue slots between MFMAs - and
 // (3) meets the block at ONE barrier.  The loop is unrolled by two so the register sets alternate without
 // moves.
-template <bool A_K, bool B_K, int TBM, int TBN, int WGM, int NW = 4>
+template <bool A_K, bool B_K, int TBM, int TBN, int WGM, int NW = 4, int PL = 3>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_split_kernel(int M, int N, int K, const float* __restrict__ A,
                                                            int64_t lda, bool vecA, const float* __restrict__ Bm,
                                                            int64_t ldb, bool vecB, float* __restrict__ C,
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_split_kernel(int M, int N, in
   constexpr int TM = TBM / WGM / 32, TN = TBN / WGN / 32;
   constexpr int GA = TBM * SKG, GB = TBN * SKG;          // groups of 8 k per operand tile
   constexpr int NA = (GA + NT - 1) / NT, NB = (GB + NT - 1) / NT;
-  constexpr int STAGE = 3 * (TBM + TBN) * SROW;          // bf16 elements of one stage (A planes, then B planes)
+  constexpr int STAGE = PL * (TBM + TBN) * SROW;         // bf16 elements of one stage (A planes, then B planes)
   constexpr int OPER = 2 * STAGE * 2;                    // bytes
   constexpr int SMEM = OPER > NW * 32 * 36 * 4 ? OPER : NW * 32 * 36 * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -431,13 +438,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_split_kernel(int M, int N, in
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
       const int g = t + NT * q;
-      if (GA % NT == 0 || g < GA) split_store8(S, TBM, A_K ? g / SKG : g % TBM, A_K ? g % SKG : g / TBM, va[q]);
+      if (GA % NT == 0 || g < GA) split_store8<PL>(S, TBM, A_K ? g / SKG : g % TBM, A_K ? g % SKG : g / TBM, va[q]);
     }
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
       const int g = t + NT * q;
       if (GB % NT == 0 || g < GB)
-        split_store8(S + 3 * TBM * SROW, TBN, B_K ? g / SKG : g % TBN, B_K ? g % SKG : g / TBN, vb[q]);
+        split_store8<PL>(S + PL * TBM * SROW, TBN, B_K ? g / SKG : g % TBN, B_K ? g % SKG : g / TBN, vb[q]);
     }
   };
   const int lr = lane & 31, lk = lane >> 5;
@@ -447,41 +454,45 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_split_kernel(int M, int N, in
                       const float (&vb)[NB][8]) {
     constexpr bool STORE = decltype(store_tag)::value;
     const __bf16* As = S;
-    const __bf16* Bs = S + 3 * TBM * SROW;
+    const __bf16* Bs = S + PL * TBM * SROW;
     // fragments: lane (row lr, k half lk) holds 8 consecutive k of its row, one 16-byte read per plane
-    bf16x8 a[TM][3], b[TN][3];
+    bf16x8 a[TM][PL], b[TN][PL];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < PL; ++p)
         a[i][p] = *reinterpret_cast<const bf16x8*>(As + (p * TBM + wm * (32 * TM) + i * 32 + lr) * SROW + lk * 8);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < PL; ++p)
         b[j][p] = *reinterpret_cast<const bf16x8*>(Bs + (p * TBN + wn * (32 * TN) + j * 32 + lr) * SROW + lk * 8);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        f32x16 c = acc[i][j];                       // small terms first
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+        f32x16 c = acc[i][j];
+        if (PL == 3) {                              // small terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PL - 1], b[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][PL - 1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PL / 2], b[j][PL / 2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PL / 2], b[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][PL / 2], c, 0, 0, 0);
+        }
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
         acc[i][j] = c;
       }
     if (STORE) {
       store_stage(Snext, va, vb);
-      constexpr int NMFMA = TM * TN * 6;
-      __builtin_amdgcn_sched_group_barrier(0x100, 3 * (TM + TN), 0);   // the fragment reads first
+      if (PL == 3) {
+        constexpr int NMFMA = TM * TN * 6;
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * (TM + TN), 0);   // the fragment reads first
 #pragma unroll
-      for (int q = 0; q < NMFMA; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);             // five VALU of the split
-        if (q % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // an LDS write now and then
+        for (int q = 0; q < NMFMA; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);             // five VALU of the split
+          if (q % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // an LDS write now and then
+        }
       }
     }
   };
@@ -899,14 +910,15 @@ static Plan make_plan(int M, int N, int K, bool wide_ok) {
 using namespace ctr;
 
 
-static size_t split_lds_bytes(int tbm, int tbn) {
-  const size_t oper = (size_t)2 * 3 * (tbm + tbn) * ctr::SROW * 2;
+static size_t split_lds_bytes(int tbm, int tbn, int planes = 3) {
+  const size_t oper = (size_t)2 * planes * (tbm + tbn) * ctr::SROW * 2;
   const size_t epi = (size_t)8 * 32 * 36 * 4;
   return oper > epi ? oper : epi;
 }
 
 extern "C" int ctr_set_gemm_mode(int mode) {
-  CTR_REQUIRE(mode == CTR_GEMM_FP32_MFMA || mode == CTR_GEMM_SPLIT_BF16, "ctr_set_gemm_mode: unknown mode %d", mode);
+  CTR_REQUIRE(mode == CTR_GEMM_FP32_MFMA || mode == CTR_GEMM_SPLIT_BF16 || mode == CTR_GEMM_BF16,
+              "ctr_set_gemm_mode: unknown mode %d", mode);
   g_gemm_mode = mode;
   return CTR_OK;
 }
@@ -1008,7 +1020,7 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
       return CTR_OK;
     }
   }
-  const Plan p = make_plan(M, N, K, g_gemm_mode == CTR_GEMM_SPLIT_BF16 && !trans_a);   // wide tiles lose on A^T B (measured)
+  const Plan p = make_plan(M, N, K, g_gemm_mode != CTR_GEMM_FP32_MFMA && !trans_a);   // wide tiles lose on A^T B (measured)
   float* partial = nullptr;
   if (p.splits > 1) {
     const size_t need = (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float);
@@ -1018,7 +1030,7 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
     }
     partial = (float*)workspace;
   }
-  if (trans_b && !trans_a && g_gemm_mode == CTR_GEMM_SPLIT_BF16 && pretranspose_b(M, N, K) && workspace) {
+  if (trans_b && !trans_a && g_gemm_mode != CTR_GEMM_FP32_MFMA && pretranspose_b(M, N, K) && workspace) {
     const size_t off = align_up(partial ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0, 256);
     if (workspace_bytes >= off + bt_floats(N, K) * sizeof(float)) {   // else: the direct path below
       float* Bt = reinterpret_cast<float*>(static_cast<char*>(workspace) + off);
@@ -1033,27 +1045,27 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
   const bool vecA = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0);
   const bool vecB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
   const dim3 grid(p.tiles_n, p.tiles_m, p.splits), block(256);
+#define LAUNCH_SPLIT(AK, BK_, TBM, TBN, WGM, NW_, PL_)                                                      \
+  do {                                                                                                      \
+    const size_t lds_ = split_lds_bytes(TBM, TBN, PL_);                                                     \
+    if (lds_ > 64 * 1024)                                                                                   \
+      CTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<AK, BK_, TBM, TBN, WGM, NW_, PL_>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));                  \
+    hipLaunchKernelGGL((gemm_split_kernel<AK, BK_, TBM, TBN, WGM, NW_, PL_>), grid, dim3(64 * NW_), lds_, st, M, N, K, \
+                       A, lda, vecA, B, ldb, vecB, C, ldc, e, p.k_chunk, partial);                          \
+  } while (0)
 #define LAUNCH3(AK, BK_, TBM, TBN, WGM)                                                                     \
   do {                                                                                                      \
-    if (g_gemm_mode == CTR_GEMM_SPLIT_BF16) {                                                               \
-      const size_t lds_ = split_lds_bytes(TBM, TBN);                                                        \
-      if (lds_ > 64 * 1024)                                                                                 \
-        CTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<AK, BK_, TBM, TBN, WGM>), \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));                \
-      hipLaunchKernelGGL((gemm_split_kernel<AK, BK_, TBM, TBN, WGM>), grid, block, lds_, st, M, N, K, A, lda, vecA, \
-                         B, ldb, vecB, C, ldc, e, p.k_chunk, partial);                                      \
-    }                                                                                                       \
+    if (g_gemm_mode == CTR_GEMM_SPLIT_BF16) LAUNCH_SPLIT(AK, BK_, TBM, TBN, WGM, 4, 3);                     \
+    else if (g_gemm_mode == CTR_GEMM_BF16) LAUNCH_SPLIT(AK, BK_, TBM, TBN, WGM, 4, 1);                      \
     else                                                                                                    \
       hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, TBM, TBN, WGM>), grid, block, 0, st, M, N, K, A, lda, vecA, B,  \
                          ldb, vecB, C, ldc, e, p.k_chunk, partial);                                         \
   } while (0)
 #define LAUNCH_WIDE(AK, BK_)                                                                                 \
   do {                                                                                                      \
-    const size_t lds_ = split_lds_bytes(128, 256);                                                          \
-    CTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<AK, BK_, 128, 256, 2, 8>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));                    \
-    hipLaunchKernelGGL((gemm_split_kernel<AK, BK_, 128, 256, 2, 8>), grid, dim3(512), lds_, st, M, N, K, A, lda, vecA, \
-                       B, ldb, vecB, C, ldc, e, p.k_chunk, partial);                                        \
+    if (g_gemm_mode == CTR_GEMM_BF16) LAUNCH_SPLIT(AK, BK_, 128, 256, 2, 8, 1);                             \
+    else LAUNCH_SPLIT(AK, BK_, 128, 256, 2, 8, 3);                                                          \
   } while (0)
 #define LAUNCH(AK, BK_)                                    \
   do {                                                     \
@@ -1069,6 +1081,7 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
 #undef LAUNCH
 #undef LAUNCH_WIDE
 #undef LAUNCH3
+#undef LAUNCH_SPLIT
   if (partial) {
     const int64_t total = (int64_t)M * N;
     const int64_t blocks = cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048;

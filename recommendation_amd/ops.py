@@ -505,6 +505,23 @@ def emb_sparse_apply(keys, src, n_items, *, N, E, total_rows, dz, opt, ws, table
 
 
 # ------------------------------------------------------------------ dense pieces
+GEMM_MODES = {'fp32': 0, 'split': 1, 'bf16': 2}
+
+
+def set_gemm_mode(name):
+    """Arithmetic of the tiled GEMM, process-wide: 'split' (default: fp32 result from six bf16 MFMAs per product),
+    'fp32' (the fp32 MFMA) or 'bf16' (operands rounded to bf16, one MFMA per product, fp32 accumulate - reduced
+    precision, opt-in).  Returns the previous mode's name."""
+    prev = get_gemm_mode()
+    check(lib().ctr_set_gemm_mode(GEMM_MODES[name]), 'ctr_set_gemm_mode')
+    return prev
+
+
+def get_gemm_mode():
+    m = int(lib().ctr_get_gemm_mode())
+    return [k for k, v in GEMM_MODES.items() if v == m][0]
+
+
 @_timed
 def gemm(A, B_, Cout, *, trans_a=False, trans_b=False, bias=None, relu=False, sigmoid=False, accumulate=False,
          dropout=None, mask_src=None, mask_scale=1.0, ws=None):

@@ -6,6 +6,8 @@ import recommendation_amd as ra
 from recommendation_amd import ops
 
 sess = ra.Session('cuda:0')
+if os.environ.get('GEMM_MODE'):          # fp32 | split | bf16
+    ops.set_gemm_mode(os.environ['GEMM_MODE'])
 ws = sess.ws
 B = 65536
 if len(sys.argv) > 1 and sys.argv[1] == 'ksweep':   # time = a + b*K: fixed cost (prologue + C store) vs per-k-step cost
