@@ -441,6 +441,15 @@ int ctr_mlp_chain_fwd(int M, int K0, const float* X, int64_t ldx,
  *   Gout = (Gmid Wa^T) * [Hout > 0] * scale_out, Wa [out, mid] = weights of the layer out -> mid
  * Gin is the gradient of the last layer's output with its own relu/dropout mask already applied.
  * Rows of Hmid, Hout, Gmid, Gout must be 16-byte aligned; Gin may be any column range of a wider buffer. */
+/* Weight and bias gradients of the last two narrow tower layers in one launch (gradient of
+ * DeepFM/DeepFM.py:71,78 for those layers):  dWa = Xa^T Ga [ka,na], dba = column sums of Ga, dWb = Xb^T Gb [kb,nb],
+ * dbb = column sums of Gb; all operands have M rows; dW* / db* are contiguous and overwritten.  Covered widths:
+ * ctr_tail_wgrad2_supported.  Xa, Ga, Xb need 16-byte aligned rows; Gb may sit at any column of a wider buffer. */
+int ctr_tail_wgrad2_supported(int ka, int na, int kb, int nb);
+size_t ctr_tail_wgrad2_workspace_bytes(int M, int ka, int na, int kb, int nb);
+int ctr_tail_wgrad2(int M, int ka, const float* Xa, int64_t ldxa, int na, const float* Ga, int64_t ldga,
+                    float* dWa, float* dba, int kb, const float* Xb, int64_t ldxb, int nb, const float* Gb, int64_t ldgb,
+                    float* dWb, float* dbb, void* workspace, size_t workspace_bytes, void* stream);
 int ctr_mlp_chain_bwd_supported(int in, int mid, int out);
 int ctr_mlp_chain_bwd(int M, int in, const float* Gin, int64_t ldgi, int mid, const float* Wb,
                       const float* Hmid, int64_t ldhm, float scale_mid, float* Gmid, int64_t ldgm, int out,

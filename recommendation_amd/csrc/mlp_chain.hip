@@ -218,6 +218,214 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(int M, const float* 
   }
 }
 
+
+// Weight and bias gradients of the last two (narrow) tower layers in one launch:
+//   dWa = Xa^T Ga [KA x NA],  dba = sum_rows Ga,   dWb = Xb^T Gb [KB x NB],  dbb = sum_rows Gb
+// (Xa, Xb the layers' inputs, Ga, Gb the gradients at their outputs, all M rows).  Launched per layer these
+// products are two passes over M-row operands with a few tiles of output each, latency-bound; here a wave
+// walks 16-row strips, stages a strip of all four operands in its own LDS area with whole-row 16-byte loads
+// (the next strip's loads in flight meanwhile) and feeds rows^T x rows 16x16x4 fp32 MFMAs whose accumulator
+// tiles (KA/16 * NA/16 + KB/16 * NB/16 of them) stay in registers for the whole launch.  The four waves of a
+// block add their tiles in wave order through LDS; tail_wgrad2_reduce_kernel adds the block partials in a
+// fixed order.
+template <int KAT, int NAT, int KBT, int NBT>
+struct TailWgradLayout {
+  static constexpr int KA = 16 * KAT, NA = 16 * NAT, KB = 16 * KBT, NB = 16 * NBT;
+  static constexpr int SXA = KA + 4, SGA = NA + 4, SXB = KB + 4, SGB = NB + 4;       // LDS strides of a strip
+  static constexpr int XA = 0, GA = 16 * SXA, XB = GA + 16 * SGA, GB = XB + 16 * SXB, WAVE = GB + 16 * SGB;
+  static constexpr int WA = 0, WB = KA * NA, BA = WB + KB * NB, BB = BA + NA, PART = BB + NB;   // a partial's layout
+};
+
+template <int KAT, int NAT, int KBT, int NBT>
+__global__ __launch_bounds__(256, 1) void tail_wgrad2_kernel(int M, const float* __restrict__ Xa, int64_t ldxa,
+                                                            const float* __restrict__ Ga, int64_t ldga,
+                                                            const float* __restrict__ Xb, int64_t ldxb,
+                                                            const float* __restrict__ Gb, int64_t ldgb, int gb_scalar,
+                                                            float* __restrict__ part) {
+  using L = TailWgradLayout<KAT, NAT, KBT, NBT>;
+  constexpr int KA = L::KA, NA = L::NA, KB = L::KB, NB = L::NB;
+  constexpr int FXA = 16 * KA / 4, FGA = 16 * NA / 4, FXB = 16 * KB / 4, FGB = 16 * NB / 4;   // float4s per strip
+  constexpr int NXA = (FXA + 63) / 64, NGA = (FGA + 63) / 64, NXB = (FXB + 63) / 64, NGB = (FGB + 63) / 64;
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l16 = lane & 15, kq = lane >> 4;
+  float* my = lds + wave * L::WAVE;
+  f32x4 accA[KAT][NAT], accB[KBT][NBT];
+#pragma unroll
+  for (int i = 0; i < KAT; ++i)
+#pragma unroll
+    for (int t = 0; t < NAT; ++t) accA[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < KBT; ++i)
+#pragma unroll
+    for (int t = 0; t < NBT; ++t) accB[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float sba[NAT], sbb[NBT];
+#pragma unroll
+  for (int t = 0; t < NAT; ++t) sba[t] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NBT; ++t) sbb[t] = 0.f;
+  struct Regs { f32x4 xa[NXA], ga[NGA], xb[NXB], gb[NGB]; };
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  // piece f of a strip of C-column rows: row f / (C/4), columns 4 (f % (C/4)) .. +3; rows past M are zeros
+  auto load_strip = [&](int64_t strip, Regs& r) {
+    const int64_t m0 = strip * 16;
+    const int nrows = M - m0 < 16 ? (int)(M - m0) : 16;
+#pragma unroll
+    for (int i = 0; i < NXA; ++i) {
+      const int f = lane + 64 * i, row = f / (KA / 4), c = 4 * (f % (KA / 4));
+      r.xa[i] = (f < FXA && row < nrows) ? *reinterpret_cast<const f32x4*>(Xa + (m0 + row) * ldxa + c) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < NGA; ++i) {
+      const int f = lane + 64 * i, row = f / (NA / 4), c = 4 * (f % (NA / 4));
+      r.ga[i] = (f < FGA && row < nrows) ? *reinterpret_cast<const f32x4*>(Ga + (m0 + row) * ldga + c) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < NXB; ++i) {
+      const int f = lane + 64 * i, row = f / (KB / 4), c = 4 * (f % (KB / 4));
+      r.xb[i] = (f < FXB && row < nrows) ? *reinterpret_cast<const f32x4*>(Xb + (m0 + row) * ldxb + c) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < NGB; ++i) {
+      const int f = lane + 64 * i, row = f / (NB / 4), c = 4 * (f % (NB / 4));
+      f32x4 v = zero4;
+      if (f < FGB && row < nrows) {
+        const float* p = Gb + (m0 + row) * ldgb + c;
+        if (gb_scalar) v = f32x4{p[0], p[1], p[2], p[3]};
+        else v = *reinterpret_cast<const f32x4*>(p);
+      }
+      r.gb[i] = v;
+    }
+  };
+  auto store_strip = [&](const Regs& r) {
+#pragma unroll
+    for (int i = 0; i < NXA; ++i) {
+      const int f = lane + 64 * i;
+      if (FXA % 64 == 0 || f < FXA) *reinterpret_cast<f32x4*>(my + L::XA + (f / (KA / 4)) * L::SXA + 4 * (f % (KA / 4))) = r.xa[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NGA; ++i) {
+      const int f = lane + 64 * i;
+      if (FGA % 64 == 0 || f < FGA) *reinterpret_cast<f32x4*>(my + L::GA + (f / (NA / 4)) * L::SGA + 4 * (f % (NA / 4))) = r.ga[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NXB; ++i) {
+      const int f = lane + 64 * i;
+      if (FXB % 64 == 0 || f < FXB) *reinterpret_cast<f32x4*>(my + L::XB + (f / (KB / 4)) * L::SXB + 4 * (f % (KB / 4))) = r.xb[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NGB; ++i) {
+      const int f = lane + 64 * i;
+      if (FGB % 64 == 0 || f < FGB) *reinterpret_cast<f32x4*>(my + L::GB + (f / (NB / 4)) * L::SGB + 4 * (f % (NB / 4))) = r.gb[i];
+    }
+  };
+  const int64_t strips = ((int64_t)M + 15) / 16;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
+  Regs regs;
+  if (gw < strips) load_strip(gw, regs);
+  for (int64_t strip = gw; strip < strips; strip += nw) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the last strip's reads are done before it is overwritten
+    __builtin_amdgcn_wave_barrier();
+    store_strip(regs);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (strip + nw < strips) load_strip(strip + nw, regs);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = 4 * kq + u;                              // a product step takes rows u, 4+u, 8+u, 12+u
+      float xa[KAT], ga[NAT], xb[KBT], gb[NBT];
+#pragma unroll
+      for (int i = 0; i < KAT; ++i) xa[i] = my[L::XA + row * L::SXA + 16 * i + l16];
+#pragma unroll
+      for (int t = 0; t < NAT; ++t) ga[t] = my[L::GA + row * L::SGA + 16 * t + l16];
+#pragma unroll
+      for (int i = 0; i < KBT; ++i) xb[i] = my[L::XB + row * L::SXB + 16 * i + l16];
+#pragma unroll
+      for (int t = 0; t < NBT; ++t) gb[t] = my[L::GB + row * L::SGB + 16 * t + l16];
+#pragma unroll
+      for (int i = 0; i < KAT; ++i)
+#pragma unroll
+        for (int t = 0; t < NAT; ++t) accA[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], ga[t], accA[i][t], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < KBT; ++i)
+#pragma unroll
+        for (int t = 0; t < NBT; ++t) accB[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[i], gb[t], accB[i][t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NAT; ++t) sba[t] += ga[t];
+#pragma unroll
+      for (int t = 0; t < NBT; ++t) sbb[t] += gb[t];
+    }
+  }
+  // column sums: lanes kq = 0..3 hold different rows of the same column
+#pragma unroll
+  for (int t = 0; t < NAT; ++t) { sba[t] += __shfl_xor(sba[t], 16); sba[t] += __shfl_xor(sba[t], 32); }
+#pragma unroll
+  for (int t = 0; t < NBT; ++t) { sbb[t] += __shfl_xor(sbb[t], 16); sbb[t] += __shfl_xor(sbb[t], 32); }
+  // the block's four waves add their tiles in wave order in LDS (the staging areas are free now)
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      // tile (i, t): lane (l16, kq) holds D[16 i + 4 kq + r][16 t + l16]
+#pragma unroll
+      for (int i = 0; i < KAT; ++i)
+#pragma unroll
+        for (int t = 0; t < NAT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* q = lds + L::WA + (16 * i + 4 * kq + r) * NA + 16 * t + l16;
+            *q = w == 0 ? accA[i][t][r] : *q + accA[i][t][r];
+          }
+#pragma unroll
+      for (int i = 0; i < KBT; ++i)
+#pragma unroll
+        for (int t = 0; t < NBT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* q = lds + L::WB + (16 * i + 4 * kq + r) * NB + 16 * t + l16;
+            *q = w == 0 ? accB[i][t][r] : *q + accB[i][t][r];
+          }
+      if (kq == 0) {
+#pragma unroll
+        for (int t = 0; t < NAT; ++t) {
+          float* q = lds + L::BA + 16 * t + l16;
+          *q = w == 0 ? sba[t] : *q + sba[t];
+        }
+#pragma unroll
+        for (int t = 0; t < NBT; ++t) {
+          float* q = lds + L::BB + 16 * t + l16;
+          *q = w == 0 ? sbb[t] : *q + sbb[t];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* P = part + (int64_t)blockIdx.x * L::PART;
+  for (int i = threadIdx.x; i < L::PART; i += 256) P[i] = lds[i];
+}
+
+// Block partials -> the four gradients, in a fixed order: thread (group pg, element e) adds partials pg, pg + 8, ...
+__global__ __launch_bounds__(256) void tail_wgrad2_reduce_kernel(const float* __restrict__ part, int nparts, int PART,
+                                                                int nwa, int nwb, int nba, float* __restrict__ dWa,
+                                                                float* __restrict__ dWb, float* __restrict__ dba,
+                                                                float* __restrict__ dbb) {
+  __shared__ float sm[8][32];
+  const int pg = threadIdx.x >> 5, e = blockIdx.x * 32 + (threadIdx.x & 31);
+  float s = 0.f;
+  if (e < PART)
+    for (int p = pg; p < nparts; p += 8) s += part[(int64_t)p * PART + e];
+  sm[pg][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (pg == 0 && e < PART) {
+    float t = sm[0][threadIdx.x];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += sm[g][threadIdx.x];
+    if (e < nwa) dWa[e] = t;
+    else if (e < nwa + nwb) dWb[e - nwa] = t;
+    else if (e < nwa + nwb + nba) dba[e - nwa - nwb] = t;
+    else dbb[e - nwa - nwb - nba] = t;
+  }
+}
+
 }  // namespace ctr
 
 using namespace ctr;
@@ -298,6 +506,62 @@ extern "C" int ctr_mlp_chain_bwd(int M, int in, const float* Gin, int64_t ldgi, 
   if (in == 32) CB(2, 4, 8);
   else CB(1, 2, 4);
 #undef CB
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+// Widths the fused two-layer weight gradient covers: (KA, NA) = the earlier layer, (KB, NB) = the later one.
+extern "C" int ctr_tail_wgrad2_supported(int ka, int na, int kb, int nb) {
+  return (ka == 128 && na == 64 && kb == 64 && nb == 32) || (ka == 64 && na == 32 && kb == 32 && nb == 16);
+}
+
+static int tail_wgrad2_blocks(int M) {
+  const int64_t need = cdiv(cdiv(M, 16), 4);
+  return (int)(need < 256 ? (need > 0 ? need : 1) : 256);
+}
+
+extern "C" size_t ctr_tail_wgrad2_workspace_bytes(int M, int ka, int na, int kb, int nb) {
+  if (M <= 0 || !ctr_tail_wgrad2_supported(ka, na, kb, nb)) return 0;
+  return (size_t)tail_wgrad2_blocks(M) * ((size_t)ka * na + (size_t)kb * nb + na + nb) * sizeof(float);
+}
+
+extern "C" int ctr_tail_wgrad2(int M, int ka, const float* Xa, int64_t ldxa, int na, const float* Ga, int64_t ldga,
+                               float* dWa, float* dba, int kb, const float* Xb, int64_t ldxb, int nb, const float* Gb,
+                               int64_t ldgb, float* dWb, float* dbb, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  CTR_REQUIRE(M > 0, "ctr_tail_wgrad2: M must be positive");
+  CTR_REQUIRE(ctr_tail_wgrad2_supported(ka, na, kb, nb), "ctr_tail_wgrad2: widths %d x %d, %d x %d not covered", ka, na,
+              kb, nb);
+  CTR_REQUIRE(Xa && Ga && dWa && dba && Xb && Gb && dWb && dbb && workspace, "ctr_tail_wgrad2: null pointer");
+  CTR_REQUIRE(ldxa >= ka && ldga >= na && ldxb >= kb && ldgb >= nb, "ctr_tail_wgrad2: leading dimension");
+  const auto rows16 = [](const void* p, int64_t ld) { return ld % 4 == 0 && ((uintptr_t)p % 16) == 0; };
+  CTR_REQUIRE(rows16(Xa, ldxa) && rows16(Ga, ldga) && rows16(Xb, ldxb),
+              "ctr_tail_wgrad2: Xa, Ga and Xb must be 16-byte aligned rows");
+  const size_t need = ctr_tail_wgrad2_workspace_bytes(M, ka, na, kb, nb);
+  if (workspace_bytes < need) {
+    set_error("ctr_tail_wgrad2: workspace %zu < %zu", workspace_bytes, need);
+    return CTR_EWORKSPACE;
+  }
+  const int gb_scalar = rows16(Gb, ldgb) ? 0 : 1;
+  const int blocks = tail_wgrad2_blocks(M);
+  float* part = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+#define TW(A_, B_, C_, D_)                                                                                          \
+  do {                                                                                                              \
+    using L = TailWgradLayout<A_, B_, C_, D_>;                                                                      \
+    const size_t a = (size_t)4 * L::WAVE, b = (size_t)L::PART;                                                      \
+    const size_t shm = (a > b ? a : b) * sizeof(float);                                                             \
+    if (shm > 48 * 1024)                                                                                            \
+      CTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_wgrad2_kernel<A_, B_, C_, D_>),               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                           \
+    hipLaunchKernelGGL((tail_wgrad2_kernel<A_, B_, C_, D_>), dim3(blocks), dim3(256), shm, st, M, Xa, ldxa, Ga, ldga, \
+                       Xb, ldxb, Gb, ldgb, gb_scalar, part);                                                        \
+    hipLaunchKernelGGL(tail_wgrad2_reduce_kernel, dim3((unsigned)cdiv(L::PART, 32)), dim3(256), 0, st, part, blocks, \
+                       (int)L::PART, ka * na, kb * nb, na, dWa, dWb, dba, dbb);                                     \
+  } while (0)
+  if (ka == 128) TW(8, 4, 4, 2);
+  else TW(4, 2, 2, 1);
+#undef TW
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }

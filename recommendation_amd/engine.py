@@ -271,6 +271,7 @@ class Tower:
         self.d_in = dense.shapes[self.names[0][0]][0]
         self._chain = None
         self._bwd_chain = None
+        self._tail_wgrad = None
 
     def forward(self, x, acts, drops, ws):
         """x: [B, >= d_in]; acts[i]: output buffer of layer i ([B, L_i] views)."""
@@ -334,10 +335,26 @@ class Tower:
         ctx = side.side_stream() if side is not None else contextlib.nullcontext()
         wws = side.ws_side if side is not None else ws
         with ctx:
-            for i in range(n - 1, -1, -1):
+            first = n - 1
+            if n >= 3 and self._tail_wgrad_ok(acts, gs):
+                # the last two (narrow) layers' weight and bias gradients in one pass over their operands
+                (wa, ba), (wb, bb) = self.names[n - 2], self.names[n - 1]
+                ops.tail_wgrad2(acts[n - 3], gs[n - 2], self.dense.g(wa), self.dense.g(ba).reshape(-1),
+                                acts[n - 2], gs[n - 1], self.dense.g(wb), self.dense.g(bb).reshape(-1), ws=wws)
+                first = n - 3
+            for i in range(first, -1, -1):
                 wn, bn = self.names[i]
                 h_in = x[:, :self.d_in] if i == 0 else acts[i - 1]
                 ops.dense_wgrad(h_in, gs[i], self.dense.g(wn), self.dense.g(bn).reshape(-1), ws=wws)
+
+    def _tail_wgrad_ok(self, acts, gs):
+        if self._tail_wgrad is None:
+            n = len(self.names)
+            ok = ops.tail_wgrad2_supported(self.widths[n - 3], self.widths[n - 2], self.widths[n - 2], self.widths[n - 1])
+            for t in (acts[n - 3], gs[n - 2], acts[n - 2]):
+                ok = ok and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+            self._tail_wgrad = bool(ok)
+        return self._tail_wgrad
 
     def _bwd_chain_ok(self, acts, gbufs):
         if self._bwd_chain is None:

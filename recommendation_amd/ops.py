@@ -568,6 +568,29 @@ def dense_wgrad(x, g, dW, db=None, *, ws):
                                 _stream()), 'ctr_dense_wgrad')
 
 
+def tail_wgrad2_supported(ka, na, kb, nb):
+    return bool(lib().ctr_tail_wgrad2_supported(int(ka), int(na), int(kb), int(nb)))
+
+
+@_timed
+def tail_wgrad2(xa, ga, dWa, dba, xb, gb, dWb, dbb, *, ws):
+    """Weight / bias gradients of two narrow layers in one launch: dWa = xa^T ga, dba = colsum(ga), dWb = xb^T gb,
+    dbb = colsum(gb).  xa, ga, xb: 16-byte aligned row views; gb may be any column slice."""
+    M, ka = xa.shape
+    na, kb, nb = ga.shape[1], xb.shape[1], gb.shape[1]
+    if ga.shape[0] != M or xb.shape[0] != M or gb.shape[0] != M or dWa.numel() != ka * na or dWb.numel() != kb * nb \
+            or dba.numel() != na or dbb.numel() != nb or not dWa.is_contiguous() or not dWb.is_contiguous():
+        raise ValueError('tail_wgrad2 shape mismatch')
+    xap, lxa = _rows(xa, 'xa')
+    gap, lga = _rows(ga, 'ga')
+    xbp, lxb = _rows(xb, 'xb')
+    gbp, lgb = _rows(gb, 'gb')
+    wp, wn = ws.get(lib().ctr_tail_wgrad2_workspace_bytes(M, ka, na, kb, nb))
+    check(lib().ctr_tail_wgrad2(M, ka, xap, lxa, na, gap, lga, _ptr(dWa, torch.float32), _ptr(dba, torch.float32), kb, xbp,
+                                lxb, nb, gbp, lgb, _ptr(dWb, torch.float32), _ptr(dbb, torch.float32), wp, wn, _stream()),
+          'ctr_tail_wgrad2')
+
+
 @_timed
 def colsum(X, out, *, w=None, w_group=1, accumulate=False, ws):
     B, K = X.shape

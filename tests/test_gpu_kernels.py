@@ -705,3 +705,28 @@ def test_afm_pair_layer_forward_and_backward(ops_ws, B, N, E, rate):
     ops.afm_pair_bwd(zd[:, :N * E], dev(dx), dzd[:, :N * E], N=N, E=E, pair_drop=drop)
     assert rel_err(dzd[:, :N * E].cpu().numpy().reshape(B, N, E), dx[:, None, :] * y) < 1e-5
     assert (dzd[:, N * E:] == 2.0).all()
+
+
+@pytest.mark.parametrize('M,ka,na,kb,nb,off', [(65536, 128, 64, 64, 32, 3), (1000, 128, 64, 64, 32, 0),
+                                               (37, 64, 32, 32, 16, 1), (5000, 64, 32, 32, 16, 0)])
+def test_tail_wgrad2_matches_two_float64_products(ops_ws, M, ka, na, kb, nb, off):
+    """Both weight gradients and both bias gradients of the last two tower layers from one launch; gb sits at a
+    column offset of a wider buffer (the output unit's concat gradient), rows not 16-byte aligned when off % 4."""
+    ops, ws = ops_ws
+    assert ops.tail_wgrad2_supported(ka, na, kb, nb) and not ops.tail_wgrad2_supported(256, 128, 128, 64)
+    g = torch.Generator().manual_seed(M + ka)
+    xa, ga, xb = (torch.randn(M, c, generator=g).to(DEV) for c in (ka, na, kb))
+    wide = torch.randn(M, nb + off + 2, generator=g).to(DEV)
+    gb = wide[:, off:off + nb]
+    outs = []
+    for rep in range(2):
+        dWa, dba = torch.full((ka, na), 7.0, device=DEV), torch.full((na,), 7.0, device=DEV)
+        dWb, dbb = torch.full((kb, nb), 7.0, device=DEV), torch.full((nb,), 7.0, device=DEV)
+        ops.tail_wgrad2(xa, ga, dWa, dba, xb, gb, dWb, dbb, ws=ws)
+        outs.append((dWa, dba, dWb, dbb))
+    d = lambda t: t.double().cpu()
+    refs = (d(xa).t() @ d(ga), d(ga).sum(0), d(xb).t() @ d(gb), d(gb).sum(0))
+    for got, ref, name in zip(outs[0], refs, ('dWa', 'dba', 'dWb', 'dbb')):
+        assert_close(got.cpu().numpy(), ref.numpy(), 1e-5, name)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)                                   # overwrites, fixed summation order
