@@ -411,8 +411,17 @@ __global__ __launch_bounds__(256) void tail_wgrad2_reduce_kernel(const float* __
   __shared__ float sm[8][32];
   const int pg = threadIdx.x >> 5, e = blockIdx.x * 32 + (threadIdx.x & 31);
   float s = 0.f;
-  if (e < PART)
-    for (int p = pg; p < nparts; p += 8) s += part[(int64_t)p * PART + e];
+  if (e < PART) {
+    int p = pg;
+    for (; p + 56 < nparts; p += 64) {               // eight independent loads in flight
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(p + 8 * u) * PART + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; p < nparts; p += 8) s += part[(int64_t)p * PART + e];
+  }
   sm[pg][threadIdx.x & 31] = s;
   __syncthreads();
   if (pg == 0 && e < PART) {
