@@ -95,6 +95,16 @@ class DenseParams:
                 raise ValueError('variables are not stacked: %s' % (names,))
         return b[off0:off0 + len(names) * stride].view(len(names), stride)[:, :n]
 
+    def g_with_bias_row(self, wn, bn):
+        """[K+1, N] view of the gradient buffer covering dW (K rows) and, as its last row, db - or None when the
+        two variables are not adjacent in the flat buffer.  A weight-gradient product whose input carries a column
+        of ones after its K features writes both at once."""
+        K, N = self.shapes[wn]
+        if int(np.prod(self.shapes[bn])) != N or self.offsets[bn] != self.offsets[wn] + K * N:
+            return None
+        o = self.offsets[wn]
+        return self.grad[o:o + (K + 1) * N].view(K + 1, N)
+
     def init_slots(self, kind):
         if kind == 'adam':
             self.slot0 = torch.zeros_like(self.flat)
@@ -260,6 +270,16 @@ class EmbedFront:
         ops.colsum(dz[:, self.Ncat * E:(self.Ncat + self.C) * E], g_cont_w.reshape(-1), w=x_cont, w_group=E, ws=ws)
 
 
+def ones_padded(B, L, device):
+    """A [B, L] activation buffer inside [B, round_up(L + 1, 4)] storage whose column L holds ones: returns
+    (view [B, L], view [B, L + 1]).  Kernels write the first L columns only (they take the row pitch), so the ones
+    stay; the weight-gradient product of the layer this buffer feeds uses the wider view and gets the bias gradient
+    as one more output row instead of a separate pass over the gradient."""
+    buf = torch.zeros(B, round_up(L + 1, 4), dtype=torch.float32, device=device)
+    buf[:, L] = 1.0
+    return buf[:, :L], buf[:, :L + 1]
+
+
 class Tower:
     """relu(x W_i + b_i) -> dropout chain on the fp32 MFMA GEMM, with the relu/dropout backward
     fused into the next GEMM's epilogue (DeepFM/DeepFM.py:65-80)."""
@@ -300,11 +320,13 @@ class Tower:
                     break
         return self._chain
 
-    def backward(self, x, acts, g_last, gbufs, rates, dx, ws, accumulate_dx=False, g_last_masked=False, side=None):
+    def backward(self, x, acts, g_last, gbufs, rates, dx, ws, accumulate_dx=False, g_last_masked=False, side=None,
+                 ext=None):
         """g_last: gradient w.r.t. acts[-1] (post relu+dropout); it is masked in place unless the caller
         already did (g_last_masked).
         gbufs[i]: scratch [B, L_i] for i < n-1.  dx (optional): [B, >= d_in] receives dL/dx
-        (added to its content when accumulate_dx)."""
+        (added to its content when accumulate_dx).  ext (optional): per layer, the layer's input as a [B, K+1] view
+        whose last column is ones (ones_padded), or None."""
         n = len(self.names)
         scale = [1.0 / (1.0 - r) if r else 1.0 for r in rates]
         if not g_last_masked:
@@ -344,6 +366,12 @@ class Tower:
                 first = n - 3
             for i in range(first, -1, -1):
                 wn, bn = self.names[i]
+                gext = self.dense.g_with_bias_row(wn, bn) if ext is not None and ext[i] is not None else None
+                K = self.dense.shapes[wn][0]
+                if gext is not None and (K + 128) // 128 == (K + 127) // 128:
+                    # db falls out of the product as its last row (only where that row fits the last 128-row tile)
+                    ops.dense_wgrad(ext[i], gs[i], gext, None, ws=wws)
+                    continue
                 h_in = x[:, :self.d_in] if i == 0 else acts[i - 1]
                 ops.dense_wgrad(h_in, gs[i], self.dense.g(wn), self.dense.g(bn).reshape(-1), ws=wws)
 

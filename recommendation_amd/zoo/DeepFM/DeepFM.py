@@ -2,7 +2,7 @@
 import torch
 
 from recommendation_amd import ops
-from recommendation_amd.engine import Tower, round_up, unit_backward
+from recommendation_amd.engine import Tower, ones_padded, round_up, unit_backward
 from recommendation_amd.model_base import CTRModel
 from recommendation_amd._lib import LOSS_SIGMOID_LOGLOSS
 
@@ -36,12 +36,16 @@ class DeepFM(CTRModel):
     def _alloc(self, B, bufs, dev):
         N, E, Ls = self.N, self.embed_size, self.deep_layers
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
-        bufs['x0'] = z(B, round_up(self.total_size, 4))
-        bufs['dx0'] = z(B, round_up(self.total_size, 4))
+        D = self.total_size
+        bufs['x0'] = z(B, round_up(D + 1, 4))          # one spare column of ones: the bias gradient rides the wgrad
+        bufs['x0'][:, D] = 1.0
+        bufs['dx0'] = z(B, round_up(D, 4))
         bufs['concat'] = z(B, self.concat_width)
         bufs['dconcat'] = z(B, self.concat_width)
         bufs['s'] = z(B, E)
-        bufs['acts'] = [z(B, L) for L in Ls[:-1]] + [bufs['concat'][:, N + E:]]
+        padded = [ones_padded(B, L, dev) for L in Ls[:-1]]
+        bufs['acts'] = [a for a, _ in padded] + [bufs['concat'][:, N + E:]]
+        bufs['ext'] = [bufs['x0'][:, :D + 1]] + [e for _, e in padded]      # layer i's input with its ones column
         bufs['gbufs'] = [z(B, L) for L in Ls[:-1]]
 
     def _forward(self, idx, xc, bufs, train):
@@ -64,7 +68,8 @@ class DeepFM(CTRModel):
         # output unit backward + the last tower layer's relu/dropout mask in one pass over concat
         fused = unit_backward(self.dense, wn, bn, concat, dconcat, dl, ws, mask_from=N + E, rate=self.dropout_deep)
         self.tower.backward(bufs['x0'], bufs['acts'], dconcat[:, N + E:], bufs['gbufs'],
-                            [self.dropout_deep] * n, bufs['dx0'], ws, g_last_masked=fused, side=self.session)
+                            [self.dropout_deep] * n, bufs['dx0'], ws, g_last_masked=fused, side=self.session,
+                            ext=bufs['ext'])
         ops.embed_bwd_dz(bufs['dx0'], B=B, N=N, E=E, gz=bufs['dx0'], g_first=dconcat[:, :N],
                          g_second=dconcat[:, N:N + E], s=bufs['s'], z=bufs['x0'],
                          drop_first=self._drop(self.dropout_fm, 1, True),
