@@ -441,6 +441,17 @@ int ctr_mlp_chain_fwd(int M, int K0, const float* X, int64_t ldx,
  *   Gout = (Gmid Wa^T) * [Hout > 0] * scale_out, Wa [out, mid] = weights of the layer out -> mid
  * Gin is the gradient of the last layer's output with its own relu/dropout mask already applied.
  * Rows of Hmid, Hout, Gmid, Gout must be 16-byte aligned; Gin may be any column range of a wider buffer. */
+/* ctr_mlp_chain_bwd and the two layers' weight / bias gradients in one pass over the activations (same widths):
+ * Gout as there (the mid gradient is not written); dWa [out,mid] / dba [mid] = gradients of the layer out -> mid
+ * (Hout^T g_mid, column sums of g_mid), dWb [mid,in] / dbb [in] those of the layer mid -> in (Hmid^T Gin, column sums
+ * of Gin).  Contiguous outputs, overwritten; fixed summation order. */
+int ctr_tail_bwd_fused_supported(int in, int mid, int out);
+size_t ctr_tail_bwd_fused_workspace_bytes(int M, int in, int mid, int out);
+int ctr_tail_bwd_fused(int M, int in, const float* Gin, int64_t ldgi, int mid, const float* Wb,
+                       const float* Hmid, int64_t ldhm, float scale_mid, int out, const float* Wa,
+                       const float* Hout, int64_t ldho, float scale_out, float* Gout, int64_t ldgo,
+                       float* dWa, float* dba, float* dWb, float* dbb,
+                       void* workspace, size_t workspace_bytes, void* stream);
 /* Weight and bias gradients of the last two narrow tower layers in one launch (gradient of
  * DeepFM/DeepFM.py:71,78 for those layers):  dWa = Xa^T Ga [ka,na], dba = column sums of Ga, dWb = Xb^T Gb [kb,nb],
  * dbb = column sums of Gb; all operands have M rows; dW* / db* are contiguous and overwritten.  Covered widths:

@@ -98,6 +98,9 @@ SIGNATURES = {
     'ctr_mlp_chain_fwd': (i, [i, i, vp, i64, i, vp, vp, DP, vp, i64, i, vp, vp, DP, vp, i64, i, vp, vp, DP, vp, i64, vp]),
     'ctr_mlp_chain_bwd_supported': (i, [i, i, i]),
     'ctr_tail_wgrad2_supported': (i, [i, i, i, i]),
+    'ctr_tail_bwd_fused_supported': (i, [i, i, i]),
+    'ctr_tail_bwd_fused_workspace_bytes': (sz, [i, i, i, i]),
+    'ctr_tail_bwd_fused': (i, [i, i, vp, i64, i, vp, vp, i64, f, i, vp, vp, i64, f, vp, i64, vp, vp, vp, vp, vp, sz, vp]),
     'ctr_tail_wgrad2_workspace_bytes': (sz, [i, i, i, i, i]),
     'ctr_tail_wgrad2': (i, [i, i, vp, i64, i, vp, i64, vp, vp, i, vp, i64, i, vp, i64, vp, vp, vp, sz, vp]),
     'ctr_mlp_chain_bwd': (i, [i, i, vp, i64, i, vp, vp, i64, f, vp, i64, i, vp, vp, i64, f, vp, i64, vp]),

@@ -403,6 +403,225 @@ __global__ __launch_bounds__(256, 1) void tail_wgrad2_kernel(int M, const float*
   for (int i = threadIdx.x; i < L::PART; i += 256) P[i] = lds[i];
 }
 
+// The two-layer backward chain and the two layers' weight / bias gradients in ONE pass over the activations:
+//   g_mid = (g_in W_b^T) * [h_mid > 0] * scale_mid,   g_out = (g_mid W_a^T) * [h_out > 0] * scale_out   (written)
+//   dW_b = h_mid^T g_in,  db_b = sum g_in,   dW_a = h_out^T g_mid,  db_a = sum g_mid
+// with (OUT, MID, IN) = 16 * (KAT, NAT = KBT, NBT).  A wave stages a 16-row strip of h_out, h_mid and g_in in its LDS
+// area (whole-row 16-byte loads, the next strip in flight), runs the chain on row-layout fragments read back from
+// there (transposed weights in LDS, as mlp_chain_bwd_kernel), parks g_mid beside them and then reads all four
+// column-wise for the rows^T x rows products, whose accumulator tiles stay in registers for the whole launch.
+// g_mid never goes to memory; h_out, h_mid and g_in are read once.  Partials as tail_wgrad2_kernel.
+template <int KAT, int NAT, int NBT>
+__global__ __launch_bounds__(256, 1) void tail_bwd_fused_kernel(int M, const float* __restrict__ Gin, int64_t ldgi,
+                                                               int in_scalar, const float* __restrict__ Wb,
+                                                               const float* __restrict__ Hm, int64_t ldhm, float scale_m,
+                                                               const float* __restrict__ Wa, const float* __restrict__ Ho,
+                                                               int64_t ldho, float scale_o, float* __restrict__ Go,
+                                                               int64_t ldgo, float* __restrict__ part) {
+  using L = TailWgradLayout<KAT, NAT, NAT, NBT>;
+  constexpr int OUT = 16 * KAT, MID = 16 * NAT, IN = 16 * NBT, SB = MID + 4, SA = OUT + 4;
+  constexpr int FHO = 16 * OUT / 4, FHM = 16 * MID / 4, FGI = 16 * IN / 4;
+  constexpr int NHO = (FHO + 63) / 64, NHM = (FHM + 63) / 64, NGI = (FGI + 63) / 64;
+  extern __shared__ float lds[];
+  float* Wbt = lds;                          // [IN][SB]:  Wbt[k][n] = Wb[n][k]
+  float* Wat = Wbt + IN * SB;                // [MID][SA]: Wat[k][n] = Wa[n][k]
+  float* stage = Wat + MID * SA;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l16 = lane & 15, kq = lane >> 4;
+  float* my = stage + wave * L::WAVE;
+  for (int q = threadIdx.x; q < MID * IN; q += 256) Wbt[(q % IN) * SB + q / IN] = Wb[q];
+  for (int q = threadIdx.x; q < OUT * MID; q += 256) Wat[(q % MID) * SA + q / MID] = Wa[q];
+  __syncthreads();
+  f32x4 accA[KAT][NAT], accB[NAT][NBT];
+#pragma unroll
+  for (int i = 0; i < KAT; ++i)
+#pragma unroll
+    for (int t = 0; t < NAT; ++t) accA[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NAT; ++i)
+#pragma unroll
+    for (int t = 0; t < NBT; ++t) accB[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float sba[NAT], sbb[NBT];
+#pragma unroll
+  for (int t = 0; t < NAT; ++t) sba[t] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NBT; ++t) sbb[t] = 0.f;
+  struct Regs { f32x4 ho[NHO], hm[NHM], gi[NGI]; };
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load_strip = [&](int64_t strip, Regs& r) {
+    const int64_t m0 = strip * 16;
+    const int nrows = M - m0 < 16 ? (int)(M - m0) : 16;
+#pragma unroll
+    for (int i = 0; i < NHO; ++i) {
+      const int f = lane + 64 * i, row = f / (OUT / 4), c = 4 * (f % (OUT / 4));
+      r.ho[i] = (f < FHO && row < nrows) ? *reinterpret_cast<const f32x4*>(Ho + (m0 + row) * ldho + c) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < NHM; ++i) {
+      const int f = lane + 64 * i, row = f / (MID / 4), c = 4 * (f % (MID / 4));
+      r.hm[i] = (f < FHM && row < nrows) ? *reinterpret_cast<const f32x4*>(Hm + (m0 + row) * ldhm + c) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < NGI; ++i) {
+      const int f = lane + 64 * i, row = f / (IN / 4), c = 4 * (f % (IN / 4));
+      f32x4 v = zero4;
+      if (f < FGI && row < nrows) {
+        const float* p = Gin + (m0 + row) * ldgi + c;
+        if (in_scalar) v = f32x4{p[0], p[1], p[2], p[3]};
+        else v = *reinterpret_cast<const f32x4*>(p);
+      }
+      r.gi[i] = v;
+    }
+  };
+  auto store_strip = [&](const Regs& r) {
+#pragma unroll
+    for (int i = 0; i < NHO; ++i) {
+      const int f = lane + 64 * i;
+      if (FHO % 64 == 0 || f < FHO) *reinterpret_cast<f32x4*>(my + L::XA + (f / (OUT / 4)) * L::SXA + 4 * (f % (OUT / 4))) = r.ho[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NHM; ++i) {
+      const int f = lane + 64 * i;
+      if (FHM % 64 == 0 || f < FHM) *reinterpret_cast<f32x4*>(my + L::XB + (f / (MID / 4)) * L::SXB + 4 * (f % (MID / 4))) = r.hm[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NGI; ++i) {
+      const int f = lane + 64 * i;
+      if (FGI % 64 == 0 || f < FGI) *reinterpret_cast<f32x4*>(my + L::GB + (f / (IN / 4)) * L::SGB + 4 * (f % (IN / 4))) = r.gi[i];
+    }
+  };
+  const int64_t strips = ((int64_t)M + 15) / 16;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
+  Regs regs;
+  if (gw < strips) load_strip(gw, regs);
+  for (int64_t strip = gw; strip < strips; strip += nw) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the last strip's reads are done before it is overwritten
+    __builtin_amdgcn_wave_barrier();
+    store_strip(regs);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (strip + nw < strips) load_strip(strip + nw, regs);
+    const int64_t m = strip * 16 + l16;
+    const bool live = m < M;
+    // ---- the chain, on row-layout fragments: lane (row l16, quad kq) holds columns 16 t + 4 kq .. +3
+    f32x4 gi[NBT], hm[NAT], gm[NAT];
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) gi[j] = *reinterpret_cast<const f32x4*>(my + L::GB + l16 * L::SGB + 16 * j + 4 * kq);
+#pragma unroll
+    for (int t = 0; t < NAT; ++t) {
+      hm[t] = *reinterpret_cast<const f32x4*>(my + L::XB + l16 * L::SXB + 16 * t + 4 * kq);
+      gm[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < NBT; ++j)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* wrow = Wbt + (16 * j + 4 * kq + u) * SB + l16;
+#pragma unroll
+        for (int t = 0; t < NAT; ++t) gm[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[16 * t], gi[j][u], gm[t], 0, 0, 0);
+        asm volatile("" ::: "memory");
+      }
+#pragma unroll
+    for (int t = 0; t < NAT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gm[t][r] = hm[t][r] > 0.f ? gm[t][r] * scale_m : 0.f;
+      *reinterpret_cast<f32x4*>(my + L::GA + l16 * L::SGA + 16 * t + 4 * kq) = gm[t];     // parked for dW_a
+    }
+    {
+      f32x4 go[KAT];
+#pragma unroll
+      for (int t = 0; t < KAT; ++t) go[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NAT; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* wrow = Wat + (16 * j + 4 * kq + u) * SA + l16;
+#pragma unroll
+          for (int t = 0; t < KAT; ++t) go[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[16 * t], gm[j][u], go[t], 0, 0, 0);
+          asm volatile("" ::: "memory");
+        }
+#pragma unroll
+      for (int t = 0; t < KAT; ++t) {
+        const f32x4 ho = *reinterpret_cast<const f32x4*>(my + L::XA + l16 * L::SXA + 16 * t + 4 * kq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) go[t][r] = ho[r] > 0.f ? go[t][r] * scale_o : 0.f;
+        if (live) *reinterpret_cast<f32x4*>(Go + m * ldgo + 16 * t + 4 * kq) = go[t];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // g_mid is in LDS before it is read column-wise
+    __builtin_amdgcn_wave_barrier();
+    // ---- the weight gradients: rows^T x rows, a product step takes rows u, 4+u, 8+u, 12+u
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = 4 * kq + u;
+      float xa[KAT], ga[NAT], xb[NAT], gb[NBT];
+#pragma unroll
+      for (int i = 0; i < KAT; ++i) xa[i] = my[L::XA + row * L::SXA + 16 * i + l16];
+#pragma unroll
+      for (int t = 0; t < NAT; ++t) ga[t] = my[L::GA + row * L::SGA + 16 * t + l16];
+#pragma unroll
+      for (int i = 0; i < NAT; ++i) xb[i] = my[L::XB + row * L::SXB + 16 * i + l16];
+#pragma unroll
+      for (int t = 0; t < NBT; ++t) gb[t] = my[L::GB + row * L::SGB + 16 * t + l16];
+#pragma unroll
+      for (int i = 0; i < KAT; ++i)
+#pragma unroll
+        for (int t = 0; t < NAT; ++t) accA[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], ga[t], accA[i][t], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NAT; ++i)
+#pragma unroll
+        for (int t = 0; t < NBT; ++t) accB[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[i], gb[t], accB[i][t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NAT; ++t) sba[t] += ga[t];
+#pragma unroll
+      for (int t = 0; t < NBT; ++t) sbb[t] += gb[t];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NAT; ++t) { sba[t] += __shfl_xor(sba[t], 16); sba[t] += __shfl_xor(sba[t], 32); }
+#pragma unroll
+  for (int t = 0; t < NBT; ++t) { sbb[t] += __shfl_xor(sbb[t], 16); sbb[t] += __shfl_xor(sbb[t], 32); }
+  __syncthreads();
+  float* red = stage;                        // the staging areas are free now
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < KAT; ++i)
+#pragma unroll
+        for (int t = 0; t < NAT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* q = red + L::WA + (16 * i + 4 * kq + r) * MID + 16 * t + l16;
+            *q = w == 0 ? accA[i][t][r] : *q + accA[i][t][r];
+          }
+#pragma unroll
+      for (int i = 0; i < NAT; ++i)
+#pragma unroll
+        for (int t = 0; t < NBT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* q = red + L::WB + (16 * i + 4 * kq + r) * IN + 16 * t + l16;
+            *q = w == 0 ? accB[i][t][r] : *q + accB[i][t][r];
+          }
+      if (kq == 0) {
+#pragma unroll
+        for (int t = 0; t < NAT; ++t) {
+          float* q = red + L::BA + 16 * t + l16;
+          *q = w == 0 ? sba[t] : *q + sba[t];
+        }
+#pragma unroll
+        for (int t = 0; t < NBT; ++t) {
+          float* q = red + L::BB + 16 * t + l16;
+          *q = w == 0 ? sbb[t] : *q + sbb[t];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* P = part + (int64_t)blockIdx.x * L::PART;
+  for (int i = threadIdx.x; i < L::PART; i += 256) P[i] = red[i];
+}
+
 // Block partials -> the four gradients, in a fixed order: thread (group pg, element e) adds partials pg, pg + 8, ...
 __global__ __launch_bounds__(256) void tail_wgrad2_reduce_kernel(const float* __restrict__ part, int nparts, int PART,
                                                                 int nwa, int nwb, int nba, float* __restrict__ dWa,
@@ -571,6 +790,56 @@ extern "C" int ctr_tail_wgrad2(int M, int ka, const float* Xa, int64_t ldxa, int
   if (ka == 128) TW(8, 4, 4, 2);
   else TW(4, 2, 2, 1);
 #undef TW
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+// The chain backward fused with the two layers' weight gradients (same widths as ctr_mlp_chain_bwd).
+extern "C" int ctr_tail_bwd_fused_supported(int in, int mid, int out) { return ctr_mlp_chain_bwd_supported(in, mid, out); }
+
+extern "C" size_t ctr_tail_bwd_fused_workspace_bytes(int M, int in, int mid, int out) {
+  return ctr_tail_wgrad2_workspace_bytes(M, out, mid, mid, in);
+}
+
+extern "C" int ctr_tail_bwd_fused(int M, int in, const float* Gin, int64_t ldgi, int mid, const float* Wb,
+                                  const float* Hmid, int64_t ldhm, float scale_mid, int out, const float* Wa,
+                                  const float* Hout, int64_t ldho, float scale_out, float* Gout, int64_t ldgo,
+                                  float* dWa, float* dba, float* dWb, float* dbb, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  CTR_REQUIRE(M > 0, "ctr_tail_bwd_fused: M must be positive");
+  CTR_REQUIRE(ctr_tail_bwd_fused_supported(in, mid, out), "ctr_tail_bwd_fused: widths %d -> %d -> %d not covered", in,
+              mid, out);
+  CTR_REQUIRE(Gin && Wb && Hmid && Wa && Hout && Gout && dWa && dba && dWb && dbb && workspace,
+              "ctr_tail_bwd_fused: null pointer");
+  CTR_REQUIRE(ldgi >= in && ldhm >= mid && ldho >= out && ldgo >= out, "ctr_tail_bwd_fused: leading dimension");
+  const auto rows16 = [](const void* p, int64_t ld) { return ld % 4 == 0 && ((uintptr_t)p % 16) == 0; };
+  CTR_REQUIRE(rows16(Hmid, ldhm) && rows16(Hout, ldho) && rows16(Gout, ldgo),
+              "ctr_tail_bwd_fused: activations and the output gradient must be 16-byte aligned rows");
+  const size_t need = ctr_tail_bwd_fused_workspace_bytes(M, in, mid, out);
+  if (workspace_bytes < need) {
+    set_error("ctr_tail_bwd_fused: workspace %zu < %zu", workspace_bytes, need);
+    return CTR_EWORKSPACE;
+  }
+  const int in_scalar = rows16(Gin, ldgi) ? 0 : 1;
+  const int blocks = tail_wgrad2_blocks(M);
+  float* part = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+#define TF(A_, B_, C_)                                                                                              \
+  do {                                                                                                              \
+    using L = TailWgradLayout<A_, B_, B_, C_>;                                                                      \
+    const size_t wts = (size_t)in * (mid + 4) + (size_t)mid * (out + 4);                                            \
+    const size_t a = (size_t)4 * L::WAVE, b = (size_t)L::PART;                                                      \
+    const size_t shm = (wts + (a > b ? a : b)) * sizeof(float);                                                     \
+    CTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_bwd_fused_kernel<A_, B_, C_>),                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                             \
+    hipLaunchKernelGGL((tail_bwd_fused_kernel<A_, B_, C_>), dim3(blocks), dim3(256), shm, st, M, Gin, ldgi, in_scalar, \
+                       Wb, Hmid, ldhm, scale_mid, Wa, Hout, ldho, scale_out, Gout, ldgo, part);                     \
+    hipLaunchKernelGGL(tail_wgrad2_reduce_kernel, dim3((unsigned)cdiv(L::PART, 32)), dim3(256), 0, st, part, blocks, \
+                       (int)L::PART, out * mid, mid * in, mid, dWa, dWb, dba, dbb);                                 \
+  } while (0)
+  if (in == 32) TF(8, 4, 2);
+  else TF(4, 2, 1);
+#undef TF
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }

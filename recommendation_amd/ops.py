@@ -415,6 +415,31 @@ def mlp_chain_bwd(g_in, Wb, h_mid, scale_mid, g_mid, Wa, h_out, scale_out, g_out
 
 
 @_timed
+def tail_bwd_fused(g_in, Wb, h_mid, scale_mid, Wa, h_out, scale_out, g_out, dWa, dba, dWb, dbb, *, ws):
+    """mlp_chain_bwd (without writing the mid gradient) plus both layers' weight / bias gradients in one pass:
+    dWb = h_mid^T g_in, dbb = colsum(g_in), dWa = h_out^T g_mid, dba = colsum(g_mid)."""
+    M, n_in = g_in.shape
+    mid, out = Wb.shape[0], Wa.shape[0]
+    if Wb.shape[1] != n_in or Wa.shape[1] != mid or not Wb.is_contiguous() or not Wa.is_contiguous():
+        raise ValueError('tail_bwd_fused: weight shapes disagree')
+    for t, wdt in ((h_mid, mid), (h_out, out), (g_out, out)):
+        if tuple(t.shape) != (M, wdt):
+            raise ValueError('tail_bwd_fused: activation shapes disagree')
+    if dWa.numel() != out * mid or dWb.numel() != mid * n_in or dba.numel() != mid or dbb.numel() != n_in \
+            or not dWa.is_contiguous() or not dWb.is_contiguous():
+        raise ValueError('tail_bwd_fused: gradient shapes disagree')
+    gp, ldgi = _rows(g_in, 'g_in')
+    hm, ldhm = _rows(h_mid, 'h_mid')
+    ho, ldho = _rows(h_out, 'h_out')
+    go, ldgo = _rows(g_out, 'g_out')
+    wp, wn = ws.get(lib().ctr_tail_bwd_fused_workspace_bytes(M, n_in, mid, out))
+    check(lib().ctr_tail_bwd_fused(M, n_in, gp, ldgi, mid, _ptr(Wb, torch.float32), hm, ldhm, float(scale_mid), out,
+                                   _ptr(Wa, torch.float32), ho, ldho, float(scale_out), go, ldgo,
+                                   _ptr(dWa, torch.float32), _ptr(dba, torch.float32), _ptr(dWb, torch.float32),
+                                   _ptr(dbb, torch.float32), wp, wn, _stream()), 'ctr_tail_bwd_fused')
+
+
+@_timed
 def auc_logloss(score, label, ws):
     """(auc, logloss) device scalars of float32 scores / labels (AUC with average ranks for ties)."""
     n = score.numel()

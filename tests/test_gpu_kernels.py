@@ -730,3 +730,38 @@ def test_tail_wgrad2_matches_two_float64_products(ops_ws, M, ka, na, kb, nb, off
         assert_close(got.cpu().numpy(), ref.numpy(), 1e-5, name)
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)                                   # overwrites, fixed summation order
+
+
+@pytest.mark.parametrize('M,n_in,mid,out,off', [(65536, 32, 64, 128, 55), (1000, 32, 64, 128, 0), (37, 16, 32, 64, 1),
+                                                (5000, 16, 32, 64, 0)])
+def test_tail_bwd_fused_matches_chain_backward_and_float64_weight_gradients(ops_ws, M, n_in, mid, out, off):
+    """One launch = mlp_chain_bwd's output gradient (bit for bit: same products in the same order) + the two
+    layers' weight and bias gradients against float64; g_in sits at a column offset of a wider buffer."""
+    ops, ws = ops_ws
+    g = torch.Generator().manual_seed(M + out)
+    Wb = (torch.randn(mid, n_in, generator=g) * 0.2).to(DEV)
+    Wa = (torch.randn(out, mid, generator=g) * 0.2).to(DEV)
+    h_mid = torch.relu(torch.randn(M, mid, generator=g)).to(DEV)
+    h_out = torch.relu(torch.randn(M, out, generator=g)).to(DEV)
+    wide = torch.randn(M, n_in + off + 1, generator=g).to(DEV)
+    g_in = wide[:, off:off + n_in]
+    sm, so = 1.25, 2.0
+    g_mid_ref, g_out_ref = torch.zeros(M, mid, device=DEV), torch.zeros(M, out, device=DEV)
+    ops.mlp_chain_bwd(g_in, Wb, h_mid, sm, g_mid_ref, Wa, h_out, so, g_out_ref)
+    runs = []
+    for rep in range(2):
+        g_out = torch.full((M, out), 7.0, device=DEV)
+        dWa, dba = torch.full((out, mid), 7.0, device=DEV), torch.full((mid,), 7.0, device=DEV)
+        dWb, dbb = torch.full((mid, n_in), 7.0, device=DEV), torch.full((n_in,), 7.0, device=DEV)
+        ops.tail_bwd_fused(g_in, Wb, h_mid, sm, Wa, h_out, so, g_out, dWa, dba, dWb, dbb, ws=ws)
+        runs.append((g_out, dWa, dba, dWb, dbb))
+    g_out, dWa, dba, dWb, dbb = runs[0]
+    assert torch.equal(g_out, g_out_ref)
+    d = lambda t: t.double().cpu()
+    gm64 = (d(g_in) @ d(Wb).t()) * (d(h_mid) > 0) * sm
+    assert_close(dWb.cpu().numpy(), (d(h_mid).t() @ d(g_in)).numpy(), 1e-5, 'dWb')
+    assert_close(dbb.cpu().numpy(), d(g_in).sum(0).numpy(), 1e-5, 'dbb')
+    assert_close(dWa.cpu().numpy(), (d(h_out).t() @ gm64).numpy(), 1e-5, 'dWa')
+    assert_close(dba.cpu().numpy(), gm64.sum(0).numpy(), 1e-5, 'dba')
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b)
