@@ -7,6 +7,7 @@
 // a scalar recursion, and one write of x_L; the backward is a second pass of the same shape
 // plus fixed-order batch reductions for dw / db.  One wave per sample.
 #include "common.h"
+#include <algorithm>
 
 namespace ctr {
 
@@ -157,6 +158,232 @@ __global__ __launch_bounds__(256) void cross_fwd_lds_kernel(const float* __restr
         put4(orow, j, D, vo, make_float4(x[i].x * c + bl.x, x[i].y * c + bl.y, x[i].z * c + bl.z, x[i].w * c + bl.w));
       }
     }
+  }
+}
+
+// ---- Aligned forms: rows 16-byte aligned and at least DP floats apart, buffers below 2 GiB ------------------------------
+// The kernels above spend their time issuing instructions, not waiting for memory (about 1500 per sample where the
+// arithmetic needs 300: every conditional load or store is a branch, the predicates of a row's tail fill the scalar
+// registers until they spill, and six 64-lane reductions per sample cost six steps each).  The forms below address
+// memory through buffer descriptors, whose range check stands in for the branches: a lane that has nothing to load
+// or store passes an offset beyond the buffer and the hardware returns zeros or drops the store.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;            // an offset no buffer here reaches (buffers are below 2 GiB)
+
+__device__ static inline __amdgpu_buffer_rsrc_t buf_of(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ static inline float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ static inline void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+}
+__device__ static inline void buf_st1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+__device__ static inline float4 quad_mask(float4 v, int j, int D) {
+  v.x = j < D ? v.x : 0.f;
+  v.y = j + 1 < D ? v.y : 0.f;
+  v.z = j + 2 < D ? v.z : 0.f;
+  v.w = j + 3 < D ? v.w : 0.f;
+  return v;
+}
+// The quad at columns j .. j+3 of a row of D, at byte offset `off` of the buffer: whole where it fits, float by float
+// where the row ends inside it, not at all past the row.
+__device__ static inline void quad_st_tail(__amdgpu_buffer_rsrc_t r, unsigned off, int j, int D, float4 v) {
+  const bool full = j + 3 < D;
+  buf_st4(r, full ? off : OOB, v);
+  buf_st1(r, !full && j < D ? off : OOB, v.x);
+  buf_st1(r, !full && j + 1 < D ? off + 4 : OOB, v.y);
+  buf_st1(r, !full && j + 2 < D ? off + 8 : OOB, v.z);
+}
+__device__ static inline float row16_sum(float v) {          // total over the 16 lanes of a DPP row, in every lane
+  v = dpp_add<DPP_XOR1>(v);
+  v = dpp_add<DPP_XOR2>(v);
+  v = dpp_add<DPP_ROR + 4>(v);
+  return dpp_add<DPP_ROR + 8>(v);
+}
+
+// Stages `nrows` rows of DPL floats into the LDS: row l < L is w_l, row L (if staged) is BlL; zeros from column D on.
+// Four-byte loads, a wave's lanes on consecutive floats, eight in flight, no branches.
+template <int DPL, int NT>
+__device__ static inline void stage_rows(float* __restrict__ lds, const float* __restrict__ w, int64_t wld,
+                                         const float* __restrict__ BlL, int L, int nrows, int D) {
+  const int n = nrows * DPL;
+  for (int t0 = threadIdx.x; t0 < n; t0 += 8 * NT) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t0 + u * NT < n ? t0 + u * NT : 0;
+      const int l = t / DPL, j = t - l * DPL;
+      const int jc = j < D ? j : 0;
+      const float* src = l < L ? w + (int64_t)l * wld + jc : BlL + jc;
+      v[u] = *src;
+      v[u] = j < D ? v[u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (t0 + u * NT < n) lds[t0 + u * NT] = v[u];
+  }
+}
+
+// Forward, a sample per 16-lane row (four samples per wave, NQ quads of the row per lane, lane k of a row on quads
+// k, k + 16, ...): a layer's dot product is reduced over 16 lanes in four DPP steps, the four samples of a wave
+// share every LDS read of the weights, and nothing in the loop branches.  The last four quads of a lane are the only
+// ones that can lie across or past the end of the row (NQ is the quad count rounded up to a multiple of four).
+// One block of eight waves per CU stages the weights once; its first rows are requested before the staging, which
+// then runs under their latency.
+// LDS: [L + 1][NQ * 64] rows (w_0 .. w_{L-1}, Bl_L; zeros from column D on), then q[L].
+constexpr int R16_NT = 512;
+template <int NQ>
+__global__ __launch_bounds__(R16_NT) void cross_fwd_r16_kernel(const float* __restrict__ x0, int64_t x0_ld,
+                                                              const float* __restrict__ w, int64_t wld,
+                                                              const float* __restrict__ BlL,
+                                                              const float* __restrict__ q, int B, int D, int L,
+                                                              float* __restrict__ xL, int64_t xL_ld,
+                                                              float* __restrict__ aux) {
+  constexpr int DPL = NQ * 64;
+  extern __shared__ __attribute__((aligned(16))) float cross_lds[];
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rx = buf_of(x0, (unsigned)(((int64_t)(B - 1) * x0_ld + D) * 4));
+  const __amdgpu_buffer_rsrc_t ro = buf_of(xL, (unsigned)(((int64_t)(B - 1) * xL_ld + D) * 4));
+  const __amdgpu_buffer_rsrc_t ra = buf_of(aux, (unsigned)((int64_t)B * 2 * L * 4));
+  const float* ql = cross_lds + (L + 1) * DPL;
+  const int64_t stride = (int64_t)gridDim.x * (R16_NT / 16);
+  int64_t b0 = ((int64_t)blockIdx.x * (R16_NT / 64) + (threadIdx.x >> 6)) * 4;
+  float4 x[NQ];
+  auto load_rows = [&](int64_t b) {
+    const unsigned xoff = b < B ? (unsigned)(b * x0_ld * 4) + 16 * l16 : OOB;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      if (i < NQ - 4) x[i] = buf_ld4(rx, xoff + 256 * i);
+      else x[i] = buf_ld4(rx, 64 * i + 4 * l16 < D ? xoff + 256 * i : OOB);
+    }
+  };
+  load_rows(b0 + grp);
+  stage_rows<DPL, R16_NT>(cross_lds, w, wld, BlL, L, L + 1, D);
+  if ((int)threadIdx.x < L) cross_lds[(L + 1) * DPL + threadIdx.x] = q[threadIdx.x];
+  __syncthreads();
+  while (b0 < B) {
+    const int64_t b = b0 + grp;
+#pragma unroll
+    for (int i = NQ - 4; i < NQ; ++i) x[i] = quad_mask(x[i], 64 * i + 4 * l16, D);
+    float c = 1.f, av = 0.f;               // lane l < L of a row keeps p_l, lane L + l keeps c_{l+1}
+    const float* wl = cross_lds + 4 * l16;
+    for (int l = 0; l < L; ++l, wl += DPL) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const float4 wv = *reinterpret_cast<const float4*>(wl + 64 * i);
+        acc.x += x[i].x * wv.x; acc.y += x[i].y * wv.y; acc.z += x[i].z * wv.z; acc.w += x[i].w * wv.w;
+      }
+      const float p = row16_sum((acc.x + acc.y) + (acc.z + acc.w));
+      c += c * p + ql[l];
+      av = l16 == l ? p : av;
+      av = l16 == L + l ? c : av;
+    }
+    buf_st1(ra, b < B && l16 < 2 * L ? (unsigned)(b * 2 * L + l16) * 4 : OOB, av);
+    const unsigned ooff = b < B ? (unsigned)(b * xL_ld * 4) + 16 * l16 : OOB;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const float4 bl = *reinterpret_cast<const float4*>(wl + 64 * i);          // wl is at row L here: Bl_L
+      const float4 o = make_float4(x[i].x * c + bl.x, x[i].y * c + bl.y, x[i].z * c + bl.z, x[i].w * c + bl.w);
+      if (i < NQ - 4) buf_st4(ro, ooff + 256 * i, o);
+      else quad_st_tail(ro, ooff + 256 * i, 64 * i + 4 * l16, D, o);
+    }
+    b0 += stride;
+    if (b0 < B) load_rows(b0 + grp);
+  }
+}
+
+// Backward of the same shape: a = g . x0 per sample (one 16-lane reduction), the scalar recursion backwards from
+// the forward's p_l and c_l (two floats per layer and sample, fetched by the row's first 2L lanes and passed
+// around the row), dx0 = g c_L + sum_l dp_l w_l (+ what dx0 held).  The gradient row is scaled in place and the
+// registers of the x0 row take the old dx0 once the dot product is done.
+// LDS: [L][NQ * 64] weight rows.
+template <int NQ>
+__global__ __launch_bounds__(R16_NT) void cross_bwd_r16_kernel(const float* __restrict__ x0, int64_t x0_ld,
+                                                              const float* __restrict__ w, int64_t wld,
+                                                              const float* __restrict__ aux,
+                                                              const float* __restrict__ g, int64_t g_ld, int B, int D,
+                                                              int L, float* __restrict__ dx0, int64_t dx0_ld,
+                                                              int accumulate, float* __restrict__ dpq) {
+  constexpr int DPL = NQ * 64;
+  extern __shared__ __attribute__((aligned(16))) float cross_lds[];
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rx = buf_of(x0, (unsigned)(((int64_t)(B - 1) * x0_ld + D) * 4));
+  const __amdgpu_buffer_rsrc_t rg = buf_of(g, (unsigned)(((int64_t)(B - 1) * g_ld + D) * 4));
+  const __amdgpu_buffer_rsrc_t rd = buf_of(dx0, (unsigned)(((int64_t)(B - 1) * dx0_ld + D) * 4));
+  const __amdgpu_buffer_rsrc_t ra = buf_of(aux, (unsigned)((int64_t)B * 2 * L * 4));
+  const __amdgpu_buffer_rsrc_t rq = buf_of(dpq, (unsigned)((int64_t)B * 2 * L * 4));
+  const int64_t stride = (int64_t)gridDim.x * (R16_NT / 16);
+  int64_t b0 = ((int64_t)blockIdx.x * (R16_NT / 64) + (threadIdx.x >> 6)) * 4;
+  float4 x[NQ], gv[NQ];
+  float A = 0.f;
+  auto load_rows = [&](int64_t b) {
+    const unsigned xoff = b < B ? (unsigned)(b * x0_ld * 4) + 16 * l16 : OOB;
+    const unsigned goff = b < B ? (unsigned)(b * g_ld * 4) + 16 * l16 : OOB;
+    A = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                      ra, b < B && l16 < 2 * L ? (unsigned)(b * 2 * L + l16) * 4 : OOB, 0, 0));
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const bool in = i < NQ - 4 || 64 * i + 4 * l16 < D;
+      x[i] = buf_ld4(rx, in ? xoff + 256 * i : OOB);
+      gv[i] = buf_ld4(rg, in ? goff + 256 * i : OOB);
+    }
+  };
+  load_rows(b0 + grp);
+  stage_rows<DPL, R16_NT>(cross_lds, w, wld, w, L, L, D);
+  __syncthreads();
+  while (b0 < B) {
+    const int64_t b = b0 + grp;
+#pragma unroll
+    for (int i = NQ - 4; i < NQ; ++i) {
+      x[i] = quad_mask(x[i], 64 * i + 4 * l16, D);
+      gv[i] = quad_mask(gv[i], 64 * i + 4 * l16, D);
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      acc.x += gv[i].x * x[i].x; acc.y += gv[i].y * x[i].y; acc.z += gv[i].z * x[i].z; acc.w += gv[i].w * x[i].w;
+    }
+    const unsigned doff = b < B ? (unsigned)(b * dx0_ld * 4) + 16 * l16 : OOB;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {           // what dx0 holds (zeros if it is not to be kept), into the x0 registers
+      const bool in = accumulate && (i < NQ - 4 || 64 * i + 4 * l16 < D);
+      x[i] = buf_ld4(rd, in ? doff + 256 * i : OOB);
+    }
+    float dc = row16_sum((acc.x + acc.y) + (acc.z + acc.w));
+    const float cL = __shfl(A, 2 * L - 1, 16);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      gv[i].x *= cL; gv[i].y *= cL; gv[i].z *= cL; gv[i].w *= cL;
+    }
+    float keep = 0.f;                      // lane l < L of a row keeps dp_l, lane L + l keeps dq_l
+    const float* wl = cross_lds + (L - 1) * DPL + 4 * l16;
+    for (int l = L - 1; l >= 0; --l, wl -= DPL) {          // backward of c_{l+1} = c_l (1 + p_l) + q_l
+      const float p_l = __shfl(A, l, 16);
+      const float c_l = l == 0 ? 1.f : __shfl(A, L + l - 1, 16);
+      const float dp = dc * c_l;
+      keep = l16 == l ? dp : keep;
+      keep = l16 == L + l ? dc : keep;
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const float4 wv = *reinterpret_cast<const float4*>(wl + 64 * i);
+        gv[i].x += dp * wv.x; gv[i].y += dp * wv.y; gv[i].z += dp * wv.z; gv[i].w += dp * wv.w;
+      }
+      dc *= 1.f + p_l;
+    }
+    buf_st1(rq, b < B && l16 < 2 * L ? (unsigned)(b * 2 * L + l16) * 4 : OOB, keep);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const float4 o = make_float4(gv[i].x + x[i].x, gv[i].y + x[i].y, gv[i].z + x[i].z, gv[i].w + x[i].w);
+      if (i < NQ - 4) buf_st4(rd, doff + 256 * i, o);
+      else quad_st_tail(rd, doff + 256 * i, 64 * i + 4 * l16, D, o);
+    }
+    b0 += stride;
+    if (b0 < B) load_rows(b0 + grp);
   }
 }
 
@@ -505,6 +732,128 @@ __global__ __launch_bounds__(64 * CF_PH) void cross_bwd_final_kernel(const float
     }
 }
 
+// cross_bwd_partial_kernel for aligned rows: the rows come through buffer descriptors (a row past the chunk reads as
+// zeros, so the loop carries no row predicate and its sixteen loads go out together), 64 rows per chunk, and only
+// the first column group adds up the dq sums.  grid (ceil(D/256), nchunks), block 256 = 4 waves over the rows.
+constexpr int PF_ROWS = 64;
+__global__ __launch_bounds__(256) void cross_bwd_partial_fast_kernel(const float* __restrict__ x0, int64_t x0_ld,
+                                                                    const float* __restrict__ g, int64_t g_ld,
+                                                                    const float* __restrict__ dpq, int B, int D, int DP,
+                                                                    int L, float* __restrict__ part,
+                                                                    float* __restrict__ psdq) {
+  __shared__ float4 red[4][64];
+  __shared__ float sdp[PF_ROWS * 2 * LMAX];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = blockIdx.x * 256 + 4 * tx;
+  const int r0 = blockIdx.y * PF_ROWS;
+  const int nr = B - r0 < PF_ROWS ? B - r0 : PF_ROWS;
+  const __amdgpu_buffer_rsrc_t rx = buf_of(x0, (unsigned)(((int64_t)(B - 1) * x0_ld + D) * 4));
+  const __amdgpu_buffer_rsrc_t rg = buf_of(g, (unsigned)(((int64_t)(B - 1) * g_ld + D) * 4));
+  constexpr int RF = 8;                            // rows in flight per wave (rows ty, ty + 4, ..., ty + 28)
+  float4 xs[2][RF], gs[2][RF];
+  auto load_round = [&](int k) {
+#pragma unroll
+    for (int u = 0; u < RF; ++u) {
+      const int r = ty + 4 * (RF * k + u);
+      const bool in = r < nr && j < D;
+      xs[k][u] = buf_ld4(rx, in ? (unsigned)((int64_t)(r0 + r) * x0_ld + j) * 4 : OOB);
+      gs[k][u] = buf_ld4(rg, in ? (unsigned)((int64_t)(r0 + r) * g_ld + j) * 4 : OOB);
+    }
+  };
+  load_round(0);
+  load_round(1);
+  for (int t = threadIdx.x; t < PF_ROWS * 2 * L; t += 256) sdp[t] = t < nr * 2 * L ? dpq[(int64_t)r0 * 2 * L + t] : 0.f;
+  __syncthreads();
+  float4 acc[LMAX + 1];
+#pragma unroll
+  for (int l = 0; l <= LMAX; ++l) acc[l] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int u = 0; u < RF; ++u) {
+      const float* dr = sdp + (ty + 4 * (RF * k + u)) * 2 * L;
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l)
+        if (l < L) {
+          const float d = dr[l];
+          acc[l].x += d * xs[k][u].x; acc[l].y += d * xs[k][u].y; acc[l].z += d * xs[k][u].z; acc[l].w += d * xs[k][u].w;
+        }
+      acc[LMAX].x += gs[k][u].x; acc[LMAX].y += gs[k][u].y; acc[LMAX].z += gs[k][u].z; acc[LMAX].w += gs[k][u].w;
+    }
+#pragma unroll
+  for (int l = 0; l <= LMAX; ++l) {
+    if (l < L || l == LMAX) {
+      red[ty][tx] = acc[l];
+      __syncthreads();
+      if (ty == 0 && j < D) {
+        const int slot = l == LMAX ? L : l;
+        const float4 a0 = red[0][tx], a1 = red[1][tx], a2 = red[2][tx], a3 = red[3][tx];
+        put4(part + ((int64_t)blockIdx.y * (L + 1) + slot) * DP, j, D, true,
+             make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                         (a0.w + a1.w) + (a2.w + a3.w)));
+      }
+      __syncthreads();
+    }
+  }
+  if (blockIdx.x == 0 && ty == 0) {                // dq sums of the chunk: lane r adds row r's, then over the wave
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l)
+      if (l < L) {
+        const float v = wave_sum(sdp[tx * 2 * L + L + l]);          // rows past the chunk were staged as zeros
+        if (tx == 0) psdq[(int64_t)blockIdx.y * LMAX + l] = v;
+      }
+  }
+}
+
+// cross_bwd_final_kernel with a block per (64 columns, slot): slot l < L finishes dw_l, slot L the column sums of g
+// and with them every db row.  The bias prefix sums Bl_l are rebuilt from b here (L loads a column).
+// part: [nchunks][L + 1][DP]; block 256 = 64 columns x 4 chunk phases, eight loads in flight per thread.
+__global__ __launch_bounds__(256) void cross_bwd_final_fast_kernel(const float* __restrict__ part,
+                                                                  const float* __restrict__ psdq, int nchunks,
+                                                                  const float* __restrict__ w,
+                                                                  const float* __restrict__ b, int64_t wld, int D,
+                                                                  int DP, int L, float* __restrict__ dw,
+                                                                  float* __restrict__ db) {
+  __shared__ float red[4][64];
+  __shared__ float sdq[LMAX];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + tx, slot = blockIdx.y;
+  for (int l = ty; l < L; l += 4) {                // wave ty totals the dq sums of layers ty, ty + 4 over the chunks
+    float v = 0.f;
+    for (int c = tx; c < nchunks; c += 64) v += psdq[(int64_t)c * LMAX + l];
+    v = wave_sum(v);
+    if (tx == 0) sdq[l] = v;
+  }
+  float acc = 0.f;
+  const int jc = j < D ? j : 0;
+  for (int c0 = ty; c0 < nchunks; c0 += 32) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + 4 * u;
+      v[u] = part[((int64_t)(c < nchunks ? c : 0) * (L + 1) + slot) * DP + jc];
+      v[u] = c < nchunks ? v[u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty != 0 || j >= D) return;
+  const float tot = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+  if (slot < L) {                                  // dw_l = sum_b dp_l x0 + sdq_l Bl_l
+    float bl = 0.f;
+    for (int l = 0; l < slot; ++l) bl += b[(int64_t)l * wld + j];
+    dw[(int64_t)slot * wld + j] = tot + sdq[slot] * bl;
+  } else {                                         // dBl_L = colsum(g); dBl_l = sdq_l w_l; db_l' = sum_{l > l'} dBl_l
+    float run = tot;
+    for (int l = L - 1; l >= 0; --l) {
+      db[(int64_t)l * wld + j] = run;
+      run += sdq[l] * w[(int64_t)l * wld + j];
+    }
+  }
+}
+
 static int cross_chunks(int B) {
   int64_t n = cdiv(B, 128);       // 128 rows per chunk: 4 waves x 8 rows in flight x 4 rounds
   if (n < 1) n = 1;
@@ -516,6 +865,26 @@ static int cross_chunks(int B) {
 static size_t cross_lds_bytes(int D, int rows) { return (size_t)rows * cross_dp_of(D) * sizeof(float); }
 constexpr size_t CROSS_LDS_LIMIT = 64 * 1024;
 
+// rows that the aligned kernels may read a whole quad at a time, up to column DP, through a 32-bit buffer offset
+static bool quads_ok(const void* p, int64_t ld, int DP, int B) {
+  return ((uintptr_t)p % 16) == 0 && ld % 4 == 0 && ld >= DP && (int64_t)B * ld * 4 < ((int64_t)1 << 31);
+}
+// quads per lane of the sample-per-16-lanes kernels (a multiple of four), their LDS bytes, and whether they apply
+static int r16_nq(int D) { return (int)(cdiv(cdiv(D, 4), 16) + 3) / 4 * 4; }
+static size_t r16_lds_bytes(int D, int rows) { return ((size_t)rows * r16_nq(D) * 64 + LMAX) * sizeof(float); }
+static unsigned r16_blocks(int B) { return (unsigned)std::min<int64_t>(cdiv(B, R16_NT / 16), 256); }   // one per CU
+#define R16_DISPATCH(KERNEL, NQV, GRID, BLOCK, LDS, ST, ...)                                  \
+  switch (NQV) {                                                                              \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, GRID, BLOCK, LDS, ST, __VA_ARGS__); break;          \
+    case 8: hipLaunchKernelGGL(KERNEL<8>, GRID, BLOCK, LDS, ST, __VA_ARGS__); break;          \
+    case 12: hipLaunchKernelGGL(KERNEL<12>, GRID, BLOCK, LDS, ST, __VA_ARGS__); break;        \
+    case 16: hipLaunchKernelGGL(KERNEL<16>, GRID, BLOCK, LDS, ST, __VA_ARGS__); break;        \
+    case 20: hipLaunchKernelGGL(KERNEL<20>, GRID, BLOCK, LDS, ST, __VA_ARGS__); break;        \
+    case 24: hipLaunchKernelGGL(KERNEL<24>, GRID, BLOCK, LDS, ST, __VA_ARGS__); break;        \
+    case 28: hipLaunchKernelGGL(KERNEL<28>, GRID, BLOCK, LDS, ST, __VA_ARGS__); break;        \
+    default: hipLaunchKernelGGL(KERNEL<32>, GRID, BLOCK, LDS, ST, __VA_ARGS__); break;        \
+  }
+static bool r16_ok(int D, int rows) { return r16_nq(D) <= 32 && r16_lds_bytes(D, rows) <= CROSS_LDS_LIMIT; }
 static int cross_dp(int D) { return cross_dp_of(D); }     // row stride of the workspace's own [.., D] arrays
 static size_t cross_prep_floats(int D, int L) { return align_up((size_t)(L + 1) * cross_dp(D) + LMAX, 64); }
 
@@ -525,9 +894,11 @@ using namespace ctr;
 
 extern "C" size_t ctr_cross_fwd_workspace_bytes(int D, int L) { return cross_prep_floats(D, L) * sizeof(float); }
 
+static int cross_chunks_fast(int B) { return (int)cdiv(B, PF_ROWS); }
 extern "C" size_t ctr_cross_bwd_workspace_bytes(int B, int D, int L) {
-  return (cross_prep_floats(D, L) + align_up((size_t)B * 2 * L, 64) + (size_t)cross_chunks(B) * LMAX +
-          (size_t)cross_chunks(B) * (L + 1) * cross_dp(D)) * sizeof(float);
+  const size_t chunks = (size_t)std::max(cross_chunks(B), cross_chunks_fast(B));
+  return (cross_prep_floats(D, L) + align_up((size_t)B * 2 * L, 64) + chunks * LMAX +
+          chunks * (L + 1) * cross_dp(D)) * sizeof(float);
 }
 
 #define CROSS_DISPATCH(KERNEL, ...)                                                              \
@@ -572,7 +943,14 @@ extern "C" int ctr_cross_fwd(const float* x0, int64_t x0_ld, const float* w, con
   float* Bl = (float*)workspace;
   float* q = Bl + (size_t)(L + 1) * DP;
   hipLaunchKernelGGL(cross_prep_kernel, dim3(1), dim3(PREP_THREADS), 0, st, w, b, wld, D, DP, L, Bl, q);
-  if (D <= 2048 && cross_lds_bytes(D, L + 1) <= CROSS_LDS_LIMIT)
+  const bool lds_fits = D <= 2048 && cross_lds_bytes(D, L + 1) <= CROSS_LDS_LIMIT;
+  if (aux_out && r16_ok(D, L + 1) && quads_ok(x0, x0_ld, DP, B) && quads_ok(xL, xL_ld, DP, B)) {
+    const size_t lds = r16_lds_bytes(D, L + 1);
+    const dim3 grid(r16_blocks(B)), block(R16_NT);
+    R16_DISPATCH(cross_fwd_r16_kernel, r16_nq(D), grid, block, lds, st, x0, x0_ld, w, wld, Bl + (size_t)L * DP, q, B, D, L,
+                 xL, xL_ld, aux_out);
+  }
+  else if (lds_fits)
     CROSS_DISPATCH_LDS(cross_fwd_lds_kernel, cross_lds_bytes(D, L + 1), x0, x0_ld, w, wld, Bl, DP, q, B, D, L, xL, xL_ld,
                        aux_out);
   else
@@ -595,11 +973,25 @@ extern "C" int ctr_cross_bwd(const float* x0, int64_t x0_ld, const float* w, con
   }
   hipStream_t st = (hipStream_t)stream;
   const int DP = cross_dp(D);
-  const int nchunks = cross_chunks(B);
-  const int rows_per_chunk = (int)cdiv(B, nchunks);
   float* Bl = (float*)workspace;
   float* q = Bl + (size_t)(L + 1) * DP;
   float* dpq = Bl + cross_prep_floats(D, L);
+  if (r16_ok(D, L) && quads_ok(x0, x0_ld, DP, B) && quads_ok(g, g_ld, DP, B) && quads_ok(dx0, dx0_ld, DP, B)) {
+    const int nchunks = cross_chunks_fast(B);
+    float* psdq = dpq + align_up((size_t)B * 2 * L, 64);
+    float* part = psdq + (size_t)nchunks * LMAX;
+    const dim3 grid(r16_blocks(B)), block(R16_NT);
+    R16_DISPATCH(cross_bwd_r16_kernel, r16_nq(D), grid, block, r16_lds_bytes(D, L), st, x0, x0_ld, w, wld, aux, g, g_ld, B, D,
+                 L, dx0, dx0_ld, accumulate, dpq);
+    hipLaunchKernelGGL(cross_bwd_partial_fast_kernel, dim3((unsigned)cdiv(D, 256), nchunks), dim3(256), 0, st, x0, x0_ld, g,
+                       g_ld, dpq, B, D, DP, L, part, psdq);
+    hipLaunchKernelGGL(cross_bwd_final_fast_kernel, dim3((unsigned)cdiv(D, 64), L + 1), dim3(256), 0, st, part, psdq,
+                       nchunks, w, b, wld, D, DP, L, dw, db);
+    CTR_LAUNCH_CHECK();
+    return CTR_OK;
+  }
+  const int nchunks = cross_chunks(B);
+  const int rows_per_chunk = (int)cdiv(B, nchunks);
   float* psdq = dpq + align_up((size_t)B * 2 * L, 64);
   float* part = psdq + (size_t)nchunks * LMAX;
   hipLaunchKernelGGL(cross_prep_kernel, dim3(1), dim3(PREP_THREADS), 0, st, w, b, wld, D, DP, L, Bl, q);

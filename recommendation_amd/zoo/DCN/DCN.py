@@ -45,8 +45,9 @@ class DCN(CTRModel):
         bufs['x0'] = z(B, round_up(D + 1, 4))          # one spare column of ones: the bias gradient rides the wgrad
         bufs['x0'][:, D] = 1.0
         bufs['dx0'] = z(B, round_up(D, 4))
-        bufs['stack'] = z(B, self.stack_width)
-        bufs['dstack'] = z(B, self.stack_width)
+        # rows 16 bytes apart in multiples: the cross kernels move x_L and its gradient sixteen bytes per lane
+        bufs['stack'] = z(B, round_up(self.stack_width, 4))[:, :self.stack_width]
+        bufs['dstack'] = z(B, round_up(self.stack_width, 4))[:, :self.stack_width]
         bufs['aux'] = z(B, 2 * self.cross_layer_num)
         padded = [ones_padded(B, L, dev) for L in Ls[:-1]]
         bufs['acts'] = [a for a, _ in padded] + [bufs['stack'][:, D:]]

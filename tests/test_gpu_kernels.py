@@ -413,6 +413,52 @@ def test_cross_network_fwd_bwd(ops_ws, D, L, B):
     assert rel_err(db.cpu().numpy(), np.stack([t.grad.numpy().reshape(-1) for t in tb])) < 1e-5
 
 
+@pytest.mark.parametrize('D,L,B,acc', [(1677, 6, 8192, True), (1677, 6, 37, False), (50, 3, 37, True), (64, 2, 33, False),
+                                       (1024, 3, 100, True), (2047, 6, 19, True), (429, 3, 65536, True),
+                                       (300, 1, 5, False), (7, 8, 3, True)])
+def test_cross_network_aligned_rows(ops_ws, D, L, B, acc):
+    """Rows 16 bytes aligned and padded, the layout the DCN model feeds: the kernels then address memory through
+    buffer descriptors, a sample per 16 lanes.  The padding of every input row holds NaN and that of every output
+    row a sentinel: neither may leak into a result or be overwritten.  Shapes: the benchmark's, rows that end
+    inside a lane's last quad, exactly at one, 1 and 32 quads per lane, batches that are not multiples of the four
+    samples of a wave, with and without accumulation into dx0."""
+    ops, ws = ops_ws
+    rng = np.random.default_rng(7 * D + L)
+    DP = (D + 3) // 4 * 4
+    x0 = (rng.standard_normal((B, D)) * 0.5).astype(np.float32)
+    w = (rng.standard_normal((L, D)) * 0.05).astype(np.float32)
+    b = (rng.standard_normal((L, D)) * 0.05).astype(np.float32)
+    g = rng.standard_normal((B, D)).astype(np.float32)
+    old = rng.standard_normal((B, D)).astype(np.float32)
+
+    def padded(a, width, fill):
+        out = np.full((a.shape[0], width), fill, dtype=np.float32)
+        out[:, :a.shape[1]] = a
+        return dev(out)
+    d_x0 = padded(x0, DP + 4, np.nan)[:, :D]
+    d_g = padded(g, DP + 8, np.nan)[:, :D]
+    xL_buf = torch.full((B, DP + 8), 7.0, device=DEV)
+    dx_buf = padded(old if acc else np.zeros_like(old), DP, 7.0)
+    aux = torch.zeros(B, 2 * L, device=DEV)
+    ops.cross_fwd(d_x0, dev(w), dev(b), xL_buf[:, :D], aux, ws)
+    tx = torch.tensor(x0, dtype=torch.float64, requires_grad=True)
+    tw = [torch.tensor(w[l].reshape(D, 1), dtype=torch.float64, requires_grad=True) for l in range(L)]
+    tb = [torch.tensor(b[l].reshape(D, 1), dtype=torch.float64, requires_grad=True) for l in range(L)]
+    ref = O.dcn_cross(tx, tw, tb)
+    out = xL_buf.cpu().numpy()
+    assert (out[:, D:] == 7.0).all()
+    assert rel_err(out[:, :D], ref.detach().numpy()) < 1e-5
+    ref.backward(torch.tensor(g, dtype=torch.float64))
+    dw, db = torch.zeros(L, D, device=DEV), torch.zeros(L, D, device=DEV)
+    ops.cross_bwd(d_x0, dev(w), dev(b), aux, d_g, dx_buf[:, :D], dw, db, ws, accumulate=acc)
+    dx = dx_buf.cpu().numpy()
+    assert (dx[:, D:] == 7.0).all()
+    want = tx.grad.numpy() + (old if acc else 0.0)
+    assert rel_err(dx[:, :D], want) < 1e-5
+    assert rel_err(dw.cpu().numpy(), np.stack([t.grad.numpy().reshape(-1) for t in tw])) < 1e-5
+    assert rel_err(db.cpu().numpy(), np.stack([t.grad.numpy().reshape(-1) for t in tb])) < 1e-5
+
+
 def test_cross_network_short_rows_ignore_stale_lds(ops_ws):
     """Rows much shorter than a wave's 256-column reach (D = 43): the lanes past the row must not read the LDS
     behind the staged weights.  A GEMM over NaN operands first leaves NaN bit patterns in every CU's LDS."""

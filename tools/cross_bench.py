@@ -13,8 +13,9 @@ sess = ra.Session('cuda:0')
 B, D = 8192, 1677
 DP = (D + 3) // 4 * 4
 x0 = torch.randn(B, DP, device='cuda')[:, :D]
-xL = torch.empty(B, DP + 1024, device='cuda')[:, :D]
-g = torch.randn(B, DP + 1024, device='cuda')[:, :D]
+PAD = int(os.environ.get('CROSS_STACK_LD', DP + 1024))      # row stride of the [x_L | tower] buffers (2701 = unpadded)
+xL = torch.empty(B, PAD, device='cuda')[:, :D]
+g = torch.randn(B, PAD, device='cuda')[:, :D]
 dx0 = torch.zeros(B, DP, device='cuda')[:, :D]
 
 
@@ -31,7 +32,7 @@ def timeit(fn, n=30):
     return a.elapsed_time(b) / n * 1e3
 
 
-for L in (2, 3, 6):
+for L in (6,):
     w = (torch.randn(L, DP, device="cuda") * 0.01)[:, :D]
     b = (torch.randn(L, DP, device="cuda") * 0.01)[:, :D]
     aux = torch.zeros(B, 2 * L, device='cuda')
