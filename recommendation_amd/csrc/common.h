@@ -111,4 +111,30 @@ __device__ static inline float wave_sum(float v) {
   return half_swap_sum(v, v);
 }
 
+// Buffer-descriptor addressing: the hardware checks every access against the buffer's size, so a lane that has
+// nothing to load or store passes an offset beyond the buffer (OOB) and gets zeros back, or has its store dropped,
+// where plain pointers need a branch around the access.  Buffers must stay below 2 GiB (32-bit byte offsets).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;            // an offset no buffer here reaches
+
+__device__ static inline __amdgpu_buffer_rsrc_t buf_of(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ static inline float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ static inline void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+}
+__device__ static inline void buf_st1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+__device__ static inline float buf_ld1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ static inline int buf_ld1i(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return (int)__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
+}
+static inline bool fits_buffer(int64_t bytes) { return bytes >= 0 && bytes < ((int64_t)1 << 31); }
+
 }  // namespace ctr

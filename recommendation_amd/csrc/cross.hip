@@ -167,21 +167,6 @@ __global__ __launch_bounds__(256) void cross_fwd_lds_kernel(const float* __restr
 // registers until they spill, and six 64-lane reductions per sample cost six steps each).  The forms below address
 // memory through buffer descriptors, whose range check stands in for the branches: a lane that has nothing to load
 // or store passes an offset beyond the buffer and the hardware returns zeros or drops the store.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned OOB = 0x80000000u;            // an offset no buffer here reaches (buffers are below 2 GiB)
-
-__device__ static inline __amdgpu_buffer_rsrc_t buf_of(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-__device__ static inline float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
-  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
-}
-__device__ static inline void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
-}
-__device__ static inline void buf_st1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
-}
 __device__ static inline float4 quad_mask(float4 v, int j, int D) {
   v.x = j < D ? v.x : 0.f;
   v.y = j + 1 < D ? v.y : 0.f;

@@ -132,6 +132,119 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
   }
 }
 
+// embed_fwd_kernel's gather path (tables in this process, no DENSE / assembled input) written so that the loop
+// issues few instructions: the kernel above spends its time issuing them (about 2300 per wave for 39 fields of 16
+// floats: a branch around every conditional access, 64-bit address arithmetic for every row of Z), not waiting for
+// memory.  Here the ids, x_cont, Z and the first-order terms go through buffer descriptors (32-bit offsets, a lane
+// with nothing to do passes an out-of-range offset, so no access sits behind a branch); a lane whose id is out of
+// range reads the offsets array instead of a table row and the row is zeroed afterwards.  A lane keeps the rows
+// n = slot, slot + SLOTS, ... of its sample, table rows first, then the continuous ones, in the same order as the
+// kernel above, and adds them up in that order, so both kernels return the same bits.
+template <int G>
+__global__ __launch_bounds__(256) void embed_fwd_lean_kernel(
+    const float* __restrict__ tables, const int64_t* __restrict__ row_offset,
+    const int32_t* __restrict__ idx, const float* __restrict__ x_cont,
+    const float* __restrict__ cont_w, int B, int F, int C,
+    float* __restrict__ z_out, int64_t z_ld, int cont_tail,
+    float* __restrict__ first_out, int64_t first_ld, float* __restrict__ s_out,
+    float* __restrict__ second_out, int64_t second_ld, Drop d_first, Drop d_second,
+    int32_t* __restrict__ oor_count) {
+  constexpr int SLOTS = 16 / G, CH = 4, E = 4 * G;
+  extern __shared__ int64_t offs_lds[];                     // [F + 1] first row of every field
+  for (int f = threadIdx.x; f <= F; f += 256) offs_lds[f] = row_offset[f];
+  __syncthreads();
+  const int l16 = threadIdx.x & 15, g = l16 % G, slot = l16 / G;
+  const int64_t b = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = b < B;
+  const int NC = cont_w ? C : 0, N = F + NC;
+  const __amdgpu_buffer_rsrc_t ri = buf_of(idx, (unsigned)((int64_t)B * F * 4));
+  const __amdgpu_buffer_rsrc_t rc = buf_of(x_cont, x_cont ? (unsigned)((int64_t)B * C * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t rz = buf_of(z_out, z_out ? (unsigned)((int64_t)B * z_ld * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t rf = buf_of(first_out, first_out ? (unsigned)((int64_t)B * first_ld * 4) : 0u);
+  const unsigned ibase = live ? (unsigned)(b * F + slot) * 4 : OOB;
+  const unsigned zbase = live ? (unsigned)(b * z_ld + slot * E + g * 4) * 4 : OOB;
+  const unsigned fbase = live && g == 0 ? (unsigned)(b * first_ld + slot) * 4 : OOB;
+  const float* const dummy = reinterpret_cast<const float*>(row_offset);      // 16 readable bytes (F >= 1)
+  float4 s = f4_zero(), q = f4_zero();
+  auto take = [&](float4 zz, int n, bool active) {          // one row of Z: store, sums, first-order term
+    buf_st4(rz, active ? zbase + (unsigned)n * (E * 4) - (unsigned)slot * (E * 4) : OOB, zz);
+    s.x += zz.x; s.y += zz.y; s.z += zz.z; s.w += zz.w;
+    q.x += zz.x * zz.x; q.y += zz.y * zz.y; q.z += zz.z * zz.z; q.w += zz.w * zz.w;
+    if (first_out) {
+      const float t = row_group_sum<G>((zz.x + zz.y) + (zz.z + zz.w));
+      buf_st1(rf, active ? fbase + (unsigned)(n - slot) * 4 : OOB, t * drop_mul(d_first, (uint64_t)b * N + n));
+    }
+  };
+  for (int n0 = slot; n0 < F + slot; n0 += SLOTS * CH) {    // table rows n0 + u * SLOTS of this lane
+    int x[CH];
+    float4 z[CH];
+    bool ok[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int n = n0 + u * SLOTS;
+      x[u] = buf_ld1i(ri, n < F ? ibase + (unsigned)(n - slot) * 4 : OOB);
+    }
+    bool bad = false;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int n = n0 + u * SLOTS, nn = n < F ? n : F - 1;
+      const int64_t off = offs_lds[nn], V = offs_lds[nn + 1] - off;
+      ok[u] = live && n < F && x[u] >= 0 && x[u] < V;
+      bad |= live && n < F && !ok[u];
+      const float* src = ok[u] ? tables + (off + x[u]) * E + g * 4 : dummy;
+      z[u] = *reinterpret_cast<const float4*>(src);
+    }
+    if (oor_count && __builtin_amdgcn_ballot_w64(bad)) {    // rare: count the ids outside their tables
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+        if (live && n0 + u * SLOTS < F && !ok[u] && g == 0) atomicAdd(oor_count, 1);
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      float4 zz = z[u];
+      zz.x = ok[u] ? zz.x : 0.f; zz.y = ok[u] ? zz.y : 0.f; zz.z = ok[u] ? zz.z : 0.f; zz.w = ok[u] ? zz.w : 0.f;
+      take(zz, n0 + u * SLOTS, live && n0 + u * SLOTS < F);
+    }
+  }
+  // continuous rows: this lane's next row numbers n = slot (mod SLOTS) from F on
+  const unsigned cbase = live ? (unsigned)(b * C) * 4 : OOB;
+  for (int n0 = F + (slot - F % SLOTS + SLOTS) % SLOTS; n0 < N; n0 += SLOTS * CH) {
+    float v[CH];
+    float4 wv[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int n = n0 + u * SLOTS, c = n < N ? n - F : 0;
+      v[u] = buf_ld1(rc, n < N ? cbase + (unsigned)c * 4 : OOB);
+      wv[u] = *reinterpret_cast<const float4*>(cont_w + (int64_t)c * E + g * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int n = n0 + u * SLOTS;
+      const float m = live && n < N ? v[u] : 0.f;
+      take(make_float4(wv[u].x * m, wv[u].y * m, wv[u].z * m, wv[u].w * m), n, live && n < N);
+    }
+  }
+  if (s_out || second_out) {
+    // column sums over the row slots of the sample: lanes G apart inside the 16-lane row
+    s.x = row_stride_sum<G>(s.x); s.y = row_stride_sum<G>(s.y); s.z = row_stride_sum<G>(s.z); s.w = row_stride_sum<G>(s.w);
+    q.x = row_stride_sum<G>(q.x); q.y = row_stride_sum<G>(q.y); q.z = row_stride_sum<G>(q.z); q.w = row_stride_sum<G>(q.w);
+    if (live && slot == 0) {
+      if (s_out) *reinterpret_cast<float4*>(s_out + b * E + g * 4) = s;
+      if (second_out) {
+        const uint64_t base = (uint64_t)b * E + g * 4;
+        float* o = second_out + b * second_ld + g * 4;
+        o[0] = 0.5f * (s.x * s.x - q.x) * drop_mul(d_second, base + 0);
+        o[1] = 0.5f * (s.y * s.y - q.y) * drop_mul(d_second, base + 1);
+        o[2] = 0.5f * (s.z * s.z - q.z) * drop_mul(d_second, base + 2);
+        o[3] = 0.5f * (s.w * s.w - q.w) * drop_mul(d_second, base + 3);
+      }
+    }
+  }
+  if (cont_tail && z_out && live) {
+    for (int c = l16; c < C; c += 16) z_out[b * z_ld + (int64_t)N * E + c] = x_cont[b * C + c];
+  }
+}
+
 // Same front end for E = 128 and 256 (G = 32, 64 lanes per row): one wave per sample.
 template <int G, bool DENSE>
 __global__ __launch_bounds__(256) void embed_fwd_wide_kernel(
@@ -415,6 +528,22 @@ static int embed_fwd_impl(const float* tables, const int64_t* row_offset, const 
       case 64: GATHER(64); break;
     }
 #undef GATHER
+    CTR_LAUNCH_CHECK();
+    return CTR_OK;
+  }
+  if (!blk && F > 0 && E <= 64 && fits_buffer((int64_t)B * F * 4) && fits_buffer((int64_t)B * C * 4) &&
+      fits_buffer((int64_t)B * z_ld * 4) && fits_buffer((int64_t)B * first_ld * 4)) {
+#define LEAN(GG)                                                                                           \
+  hipLaunchKernelGGL((embed_fwd_lean_kernel<GG>), grid, block, lds, st, tables, row_offset, idx, x_cont, cont_w, B, F, C, \
+                     z_out, z_ld, cont_tail, first_out, first_ld, s_out, second_out, second_ld, d1, d2, oor_count)
+    switch (E / 4) {
+      case 1: LEAN(1); break;
+      case 2: LEAN(2); break;
+      case 4: LEAN(4); break;
+      case 8: LEAN(8); break;
+      case 16: LEAN(16); break;
+    }
+#undef LEAN
     CTR_LAUNCH_CHECK();
     return CTR_OK;
   }
