@@ -148,6 +148,176 @@ __global__ __launch_bounds__(256) void sparse_apply_kernel(
   }
 }
 
+// opt_apply4 on registers (same expressions, so the same bits): the caller loads and stores the rows.
+__device__ static inline void opt_math4(const Opt& o, float4 g, float4& p, float4& a, float4& c) {
+  if (o.kind == CTR_OPT_ADAM) {
+    float4& m = a; float4& v = c;
+    m.x = o.b1 * m.x + (1.f - o.b1) * g.x; m.y = o.b1 * m.y + (1.f - o.b1) * g.y;
+    m.z = o.b1 * m.z + (1.f - o.b1) * g.z; m.w = o.b1 * m.w + (1.f - o.b1) * g.w;
+    v.x = o.b2 * v.x + (1.f - o.b2) * g.x * g.x; v.y = o.b2 * v.y + (1.f - o.b2) * g.y * g.y;
+    v.z = o.b2 * v.z + (1.f - o.b2) * g.z * g.z; v.w = o.b2 * v.w + (1.f - o.b2) * g.w * g.w;
+    p.x -= o.LR() * m.x / (sqrtf(v.x) + o.eps); p.y -= o.LR() * m.y / (sqrtf(v.y) + o.eps);
+    p.z -= o.LR() * m.z / (sqrtf(v.z) + o.eps); p.w -= o.LR() * m.w / (sqrtf(v.w) + o.eps);
+  } else if (o.kind == CTR_OPT_ADAGRAD) {
+    a.x += g.x * g.x; a.y += g.y * g.y; a.z += g.z * g.z; a.w += g.w * g.w;
+    p.x -= o.LR() * g.x / sqrtf(a.x); p.y -= o.LR() * g.y / sqrtf(a.y);
+    p.z -= o.LR() * g.z / sqrtf(a.z); p.w -= o.LR() * g.w / sqrtf(a.w);
+  } else if (o.kind == CTR_OPT_SGD) {
+    p.x -= o.LR() * g.x; p.y -= o.LR() * g.y; p.z -= o.LR() * g.z; p.w -= o.LR() * g.w;
+  } else if (o.kind == CTR_OPT_FTRL) {
+    ftrl1(o, g.x, p.x, a.x, c.x); ftrl1(o, g.y, p.y, a.y, c.y);
+    ftrl1(o, g.z, p.z, a.z, c.z); ftrl1(o, g.w, p.w, a.w, c.w);
+  } else {
+    a = g;
+  }
+}
+
+// Exact n / d for 32-bit n and a divisor fixed at launch (multiply-high, two shifts), in place of the hardware-less
+// integer division the compiler expands to some twenty-five instructions.
+struct DivU32 {
+  uint32_t m;
+  int sh1, sh2;
+  __device__ uint32_t quot(uint32_t n) const {
+    const uint32_t t = __umulhi(m, n);
+    return (t + ((n - t) >> sh1)) >> sh2;
+  }
+};
+static inline DivU32 make_div(uint32_t d) {
+  int l = 0;
+  while ((1ull << l) < d) ++l;
+  DivU32 r;
+  r.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+  r.sh1 = l < 1 ? l : 1;
+  r.sh2 = l > 1 ? l - 1 : 0;
+  return r;
+}
+
+// sparse_apply_kernel written for instruction count: the kernel above issues about 2000 instructions per 64 pairs (a segmented scan of four
+// rounds through the LDS crossbar, a division per pair to find its gradient row, every access behind a branch) and
+// is bound by that, not by memory.  Here a group of G lanes owns G consecutive pairs: their keys and sources come
+// straight from memory (no lane exchange), the rows are added along the run inside the lane, and one segmented scan
+// over the groups' last runs links the groups.  A pair past the end or with a key outside the tables reads gradient
+// row 0 (its sum joins no run that is applied); table rows of the pairs that end no run are not touched (their
+// lanes load row 0 and store nothing).  Same outputs as the kernel above (part, part_head, head_key
+// for the tail pass); a run's rows are added in pair order, grouped as ((lane-serial) + groups scan).
+template <int G>
+__global__ __launch_bounds__(256) void sparse_apply_lean_kernel(
+    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ src, int64_t n_items, int N, DivU32 divN,
+    int64_t total_rows, const float* __restrict__ dz, int64_t dz_ld, const float* __restrict__ src_scale,
+    float* __restrict__ tables, float* __restrict__ slot0, float* __restrict__ slot1, Opt opt,
+    float* __restrict__ part, float* __restrict__ part_head, uint32_t* __restrict__ head_key) {
+  constexpr int R = 64 / G, IPG = G, E = 4 * G;
+  const int lane = threadIdx.x & 63;
+  const int g = lane % G, q = lane / G;
+  const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t start = blk * SEG;
+  if (start >= n_items) return;
+  const int cnt = (int)(n_items - start < SEG ? n_items - start : SEG);
+  const __amdgpu_buffer_rsrc_t rk = buf_of(keys, (unsigned)(n_items * 4));
+  const __amdgpu_buffer_rsrc_t rs = buf_of(src, (unsigned)(n_items * 4));
+  const uint32_t first_key = keys[start];
+  const bool first_is_head = start == 0 || keys[start - 1] != first_key;
+  const unsigned kbase = (unsigned)(start + q * IPG) * 4;
+  // keys of this group's pairs, of the pair before the group and of the pair after each one (0 past the array)
+  uint32_t k[IPG], nk[IPG], sr[IPG];
+  const uint32_t kprev = (uint32_t)buf_ld1i(rk, q > 0 ? kbase - 4 : OOB);
+#pragma unroll
+  for (int u = 0; u < IPG; ++u) {
+    k[u] = (uint32_t)buf_ld1i(rk, kbase + 4 * u);
+    sr[u] = (uint32_t)buf_ld1i(rs, kbase + 4 * u);
+  }
+  nk[IPG - 1] = (uint32_t)buf_ld1i(rk, kbase + 4 * IPG);
+#pragma unroll
+  for (int u = 0; u + 1 < IPG; ++u) nk[u] = k[u + 1];
+  // Which pairs end a run, and how, follows from the keys alone: the table rows of those that get an optimizer step
+  // are requested here, together with the gradient rows, so a wave waits for memory twice (keys, then rows), not
+  // three times.  A pair that ends nothing loads row 0 and stores nothing.
+  float4 val[IPG], p[IPG], a[IPG], c[IPG];
+  bool in[IPG], live[IPG], more[IPG];                  // in the block; key inside the tables; next pair has the same key
+  bool app[IPG], to_part[IPG], to_head[IPG];
+  uint32_t recorded = NO_KEY;
+#pragma unroll
+  for (int u = 0; u < IPG; ++u) {
+    const int i = q * IPG + u;
+    in[u] = i < cnt;
+    live[u] = in[u] && (int64_t)k[u] < total_rows;
+    more[u] = start + i + 1 < n_items && nk[u] == k[u];
+    const bool last = i == cnt - 1;
+    const bool ends = live[u] && (!more[u] || last);
+    const bool open = k[u] == first_key && !first_is_head;   // started in an earlier block: a piece for the tail pass
+    const bool leaves = last && more[u];                      // goes on in the next block: the head piece
+    app[u] = ends && !open && !leaves;
+    to_part[u] = ends && open;
+    to_head[u] = ends && !open && leaves;
+    if (to_head[u]) recorded = k[u];
+    if (in[u] && last && g == 0) head_key[blk] = recorded;
+    const int64_t off = app[u] ? (int64_t)k[u] * E + g * 4 : 0;
+    p[u] = a[u] = c[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (opt.kind != CTR_OPT_GRAD_ONLY) p[u] = *reinterpret_cast<const float4*>(tables + off);
+    if (opt.kind == CTR_OPT_ADAM || opt.kind == CTR_OPT_ADAGRAD || opt.kind == CTR_OPT_FTRL)
+      a[u] = *reinterpret_cast<const float4*>(slot0 + off);
+    if (opt.kind == CTR_OPT_ADAM || opt.kind == CTR_OPT_FTRL) c[u] = *reinterpret_cast<const float4*>(slot1 + off);
+  }
+#pragma unroll
+  for (int u = 0; u < IPG; ++u) {
+    const uint32_t sb = divN.quot(sr[u]), sn = sr[u] - sb * (uint32_t)N;      // source = sample * N + row of the sample
+    // a pair outside the block or the tables reads row 0: its sum joins no run that is applied
+    val[u] = *reinterpret_cast<const float4*>(dz + (live[u] ? (int64_t)sb * dz_ld + sn * E : 0) + g * 4);
+  }
+  if (src_scale) {
+#pragma unroll
+    for (int u = 0; u < IPG; ++u) {
+      const float sc = src_scale[live[u] ? sr[u] : 0u];
+      val[u].x *= sc; val[u].y *= sc; val[u].z *= sc; val[u].w *= sc;
+    }
+  }
+  // along the run inside the lane; chain[u]: pairs 0..u of the group are one run
+  bool chain[IPG];
+  chain[0] = true;
+#pragma unroll
+  for (int u = 1; u < IPG; ++u) {
+    const bool same = in[u] && k[u] == k[u - 1];
+    chain[u] = chain[u - 1] && same;
+    if (same) { val[u].x += val[u - 1].x; val[u].y += val[u - 1].y; val[u].z += val[u - 1].z; val[u].w += val[u - 1].w; }
+  }
+  // the groups' last runs: T = sum of the group's last run, head = it does not continue the previous group's
+  const bool joins = q > 0 && in[0] && k[0] == kprev;        // the group's first pair continues the previous group
+  float4 T = val[IPG - 1];
+  bool head = !(chain[IPG - 1] && joins);
+#pragma unroll
+  for (int d = 1; d < R; d <<= 1) {
+    const float4 pT = shfl_up4(T, d * G);
+    const int ph = __shfl_up((int)head, d * G);
+    if (q >= d && !head) {
+      T.x = pT.x + T.x; T.y = pT.y + T.y; T.z = pT.z + T.z; T.w = pT.w + T.w;
+      head = ph != 0;
+    }
+  }
+  float4 carry = shfl_up4(T, G);                             // the run that ends the previous group, whole
+  if (!joins) carry = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int u = 0; u < IPG; ++u) {
+    if (chain[u]) { val[u].x = carry.x + val[u].x; val[u].y = carry.y + val[u].y; val[u].z = carry.z + val[u].z; val[u].w = carry.w + val[u].w; }
+    if (to_part[u]) *reinterpret_cast<float4*>(part + blk * E + g * 4) = val[u];
+    if (to_head[u]) *reinterpret_cast<float4*>(part_head + blk * E + g * 4) = val[u];
+  }
+#pragma unroll
+  for (int u = 0; u < IPG; ++u) opt_math4(opt, val[u], p[u], a[u], c[u]);
+#pragma unroll
+  for (int u = 0; u < IPG; ++u) {
+    if (!app[u]) continue;
+    const int64_t off = (int64_t)k[u] * E + g * 4;
+    if (opt.kind != CTR_OPT_GRAD_ONLY) *reinterpret_cast<float4*>(tables + off) = p[u];
+    if (opt.kind != CTR_OPT_SGD) *reinterpret_cast<float4*>(slot0 + off) = a[u];
+    if (opt.kind == CTR_OPT_ADAM || opt.kind == CTR_OPT_FTRL) *reinterpret_cast<float4*>(slot1 + off) = c[u];
+  }
+}
+
+// Pass 2: one wave per block with a recorded head adds part_head + the continuation pieces in block order and applies
+// the optimizer.  Most heads belong to short runs that end in the next block or two, so the first trip looks at R
+// blocks only; a hot key's run spans hundreds of blocks, and from the second trip on the wave asks for the first keys
+// and the pieces of 8 * R blocks together (no load waits for another: a block past the arrays reads the last one's).
+// Every lane adds its pieces in ascending order, then the lanes are combined by a fixed shuffle tree.
 template <int G>
 __global__ __launch_bounds__(256) void sparse_apply_tail_kernel(
     const uint32_t* __restrict__ keys, int64_t n_items, int64_t n_blocks, int E,
@@ -155,6 +325,7 @@ __global__ __launch_bounds__(256) void sparse_apply_tail_kernel(
     const float* __restrict__ part, const float* __restrict__ part_head,
     const uint32_t* __restrict__ head_key) {
   constexpr int R = 64 / G;
+  constexpr int TU = 8;
   const int lane = threadIdx.x & 63;
   const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blk >= n_blocks) return;
@@ -164,32 +335,33 @@ __global__ __launch_bounds__(256) void sparse_apply_tail_kernel(
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (r == 0) acc = *reinterpret_cast<const float4*>(part_head + blk * E + g * 4);
   // continuation pieces sit in blocks blk+1, blk+2, ... while the block's first key is `key`
-  // Four steps of R blocks per round trip: a hot key's run spans hundreds of blocks and one wave walks it,
-  // so the walk is a chain of dependent (key, partial row) loads; each lane still adds its blocks in
-  // ascending order (same bits as one step at a time).
-  constexpr int TU = 4;
-  for (int64_t k0 = blk + 1; k0 < n_blocks; k0 += TU * R) {
-    bool ok[TU];
-#pragma unroll
-    for (int u = 0; u < TU; ++u) {
-      const int64_t k = k0 + u * R + r;
-      ok[u] = k < n_blocks && keys[k * SEG] == key;
-    }
+  bool more;
+  {
+    const int64_t k = blk + 1 + r, kc = k < n_blocks ? k : n_blocks - 1;
+    const uint32_t fk = keys[kc * SEG];
+    const float4 v = *reinterpret_cast<const float4*>(part + kc * E + g * 4);
+    const bool ok = k < n_blocks && fk == key;
+    if (ok) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    more = __ballot(ok) == __ballot(1);            // the run ends inside a trip as soon as one slot misses
+  }
+  for (int64_t k0 = blk + 1 + R; more && k0 < n_blocks; k0 += TU * R) {
+    uint32_t fk[TU];
     float4 v[TU];
 #pragma unroll
     for (int u = 0; u < TU; ++u) {
-      const int64_t k = k0 + u * R + r;
-      // a block past the run's first miss can carry the key again only if it is the same run: keys are sorted
-      v[u] = ok[u] ? *reinterpret_cast<const float4*>(part + k * E + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int64_t k = k0 + u * R + r, kc = k < n_blocks ? k : n_blocks - 1;
+      fk[u] = keys[kc * SEG];
+      v[u] = *reinterpret_cast<const float4*>(part + kc * E + g * 4);
     }
     bool all = true;
 #pragma unroll
     for (int u = 0; u < TU; ++u) {
-      if (ok[u]) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
-      all = all && ok[u];
+      // a block past the run's first miss can carry the key again only if it is the same run: keys are sorted
+      const bool ok = k0 + u * R + r < n_blocks && fk[u] == key;
+      if (ok) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+      all = all && ok;
     }
-    // the run ends inside this trip as soon as one slot misses (wave-uniform exit)
-    if (__ballot(all) != __ballot(1)) break;
+    more = __ballot(all) == __ballot(1);
   }
 #pragma unroll
   for (int o = G; o < 64; o <<= 1) {
@@ -284,6 +456,24 @@ extern "C" int ctr_emb_sparse_apply(const uint32_t* keys_sorted, const uint32_t*
   const dim3 grid2((unsigned)cdiv(nb, 4));
   // GRAD_ONLY writes through slot0 only; give the kernel a non-null table pointer it never uses.
   float* tab = tables ? tables : slot0;
+  // pair arrays addressable with 32-bit offsets: the short kernel
+  if (G <= 8 && fits_buffer(n_items * 4 + 4) && tables) {
+    const DivU32 divN = make_div((uint32_t)N);
+#define LEAN(GG)                                                                                          \
+  hipLaunchKernelGGL(sparse_apply_lean_kernel<GG>, grid, block, 0, st, keys_sorted, src_sorted, n_items, N, divN,      \
+                     total_rows, dz, dz_ld, src_scale, tab, slot0, slot1, o, part, part_head, head_key);               \
+  hipLaunchKernelGGL(sparse_apply_tail_kernel<GG>, grid2, block, 0, st, keys_sorted, n_items, nb, E, tab, \
+                     slot0, slot1, o, part, part_head, head_key)
+    switch (G) {
+      case 1: LEAN(1); break;
+      case 2: LEAN(2); break;
+      case 4: LEAN(4); break;
+      case 8: LEAN(8); break;
+    }
+#undef LEAN
+    CTR_LAUNCH_CHECK();
+    return CTR_OK;
+  }
 #define LAUNCH(GG)                                                                                   \
   hipLaunchKernelGGL(sparse_apply_kernel<GG>, grid, block, 0, st, keys_sorted, src_sorted, n_items, N, \
                      E, total_rows, dz, dz_ld, src_scale, tab, slot0, slot1, o, part, part_head, head_key); \
