@@ -148,14 +148,16 @@ def load_traffic(model):
         return out
     paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_%s_*pmc_traffic.json' % tag)))
     if paths:
-        # operator -> the kernel symbols one call of it launches (the cross operators have an LDS-resident form and,
-        # backward, the two kernels of the dw/db reduction; the sparse update its tail)
-        parts = {'embed_fwd_kernel': ('embed_fwd_kernel', 'embed_fwd_wide_kernel'),
-                 'sparse_apply_kernel': ('sparse_apply_kernel', 'sparse_apply_tail_kernel'),
+        # operator -> the kernel symbols one call of it launches (every operator has a general and an aligned /
+        # short-instruction-stream form; the cross backward adds the two kernels of the dw/db reduction, the sparse
+        # update its tail)
+        parts = {'embed_fwd_kernel': ('embed_fwd_kernel', 'embed_fwd_wide_kernel', 'embed_fwd_lean_kernel'),
+                 'sparse_apply_kernel': ('sparse_apply_kernel', 'sparse_apply_lean_kernel', 'sparse_apply_tail_kernel'),
                  'embed_bwd_dz_kernel': ('embed_bwd_dz_kernel',),
-                 'cross_fwd_kernel': ('cross_fwd_kernel', 'cross_fwd_lds_kernel'),
-                 'cross_bwd_kernel': ('cross_bwd_kernel', 'cross_bwd_lds_kernel', 'cross_bwd_partial_kernel',
-                                      'cross_bwd_final_kernel')}
+                 'cross_fwd_kernel': ('cross_fwd_kernel', 'cross_fwd_lds_kernel', 'cross_fwd_r16_kernel'),
+                 'cross_bwd_kernel': ('cross_bwd_kernel', 'cross_bwd_lds_kernel', 'cross_bwd_r16_kernel',
+                                      'cross_bwd_partial_kernel', 'cross_bwd_partial_fast_kernel',
+                                      'cross_bwd_final_kernel', 'cross_bwd_final_fast_kernel')}
         for k, v in json.load(open(paths[-1])).items():
             for op, syms in parts.items():
                 if any(sym + '<' in k or sym + '(' in k for sym in syms):
