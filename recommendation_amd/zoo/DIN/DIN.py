@@ -17,11 +17,14 @@ import torch
 from recommendation_amd import ops
 from recommendation_amd.engine import BufferCache, DenseParams, EmbeddingTables
 from recommendation_amd._lib import LOSS_SCE_LOGIT, OPT_SGD
+from recommendation_amd.model_base import _capture
 
 BN_EPS = 1e-3
 
 
 class DIN(object):
+    GRAPH_SIZES = 4                        # captured (B, T) shapes kept per model
+
     def __init__(self, args, user_count, item_count, cate_count, cate_list):
         self.H = H = int(args.hidden_units)
         if H % 2 or (H // 2) & (H // 2 - 1) or H < 8:
@@ -53,6 +56,8 @@ class DIN(object):
         # the attention scoring network as three fused launches (H = 16 or 32, the reference's default); any other
         # width, or fused_attention=False, goes layer by layer through the materialised [B*T, 4H]
         self.fused_attention = bool(getattr(args, 'fused_attention', True)) and ops.din_attn_mlp_supported(H)
+        self._train_graphs = {}            # (B, T) -> captured training step
+        self._lr_dev = None                # the device word a captured step reads its learning rate from
         self._ready = False
         self._bufs = BufferCache()
 
@@ -156,7 +161,8 @@ class DIN(object):
         dev, H = self.session.device, self.H
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         n = B + B * T
-        b = dict(pair=torch.zeros(n, 2, dtype=torch.int32, device=dev), emb=z(n, H), demb=z(n, H),
+        b = dict(ids=torch.zeros(n, dtype=torch.int32, device=dev),
+                 pair=torch.zeros(n, 2, dtype=torch.int32, device=dev), emb=z(n, H), demb=z(n, H),
                  ib4=z(B, 4), dib4=z(B, 4), din_all=z(0 if self.fused_attention else B * T, 4 * H), d1=z(B * T, 80), d2=z(B * T, 40),
                  g1=z(B * T, 80), g2=z(B * T, 40), score=z(B * T), dscore=z(B * T), att=z(B * T),
                  pooled=z(B, H), dpooled=z(B, H), xhat1=z(B, H), hist_bn=z(B, H), dhist_bn=z(B, H),
@@ -267,7 +273,10 @@ class DIN(object):
         b = self._buffers(B, T)
         d, H, ws = self.dense, self.H, sess.ws
         # forward
-        self._lookup(torch.cat([i, hist.reshape(-1)]), b)
+        ids = b['ids']                             # [i | hist]: one lookup for the target and the history
+        ids[:B].copy_(i.reshape(-1))
+        ids[B:].copy_(hist.reshape(-1))
+        self._lookup(ids, b)
         self._item_bias(i, b['ib4'])
         self._user_vector(b, sl, B, T)
         self._fcn(b, b['emb'][:B], 'i', B, keep=True)
@@ -316,7 +325,7 @@ class DIN(object):
             self._attention_mlp_backward_unfused(b, ds, i_emb, h_emb, dq, dk, B, T)
         ops.copy2d(b['ddin'][:, H:], dq, accumulate=True)                                # i_emb also feeds the FCN
         # sparse updates (SGD) on item/category tables and on item_b
-        sgd = ops.make_opt(OPT_SGD, lr=float(l))
+        sgd = ops.make_opt(OPT_SGD, lr=float(l), lr_dev=self._lr_dev)      # a captured step reads l from a device word
         n = B + B * T
         t = self.tables
         ops.emb_sort(b['pair'][:n], t.row_offset, N=2, total_rows=t.total_rows, rmode=False, keys_out=b['keys'],
@@ -331,6 +340,37 @@ class DIN(object):
                              tables=bt.weight, ws=ws)
         # dense variables (the reference never passes global_step to minimize(): it stays 0, DIN/DIN.py:110)
         self.dense.apply(sgd)
+        return self._loss_dev
+
+    def train_step_graphed(self, i, y, hist, sl, l):
+        """train_step replayed from a captured HIP graph, one per (B, T): at B = 2048 the step is some seventy
+        launches on small tensors and a third of its time is the host's launch cost.  The inputs are copied into the
+        graph's own buffers and the learning rate into a device word the update kernels read; same arithmetic as
+        train_step.  Callers whose T changes from batch to batch (the reference loop pads to each batch's longest
+        history) fall back to train_step once GRAPH_SIZES graphs exist."""
+        B, T = hist.shape
+        entry = self._train_graphs.get((B, T))
+        if entry is None and len(self._train_graphs) >= self.GRAPH_SIZES:
+            return self.train_step(i, y, hist, sl, l)
+        if entry is None:
+            loss = self.train_step(i, y, hist, sl, l)           # buffers and the workspace reach their final size
+            dev = self.session.device
+            lr_w = torch.zeros(1, dtype=torch.float32, device=dev)
+            s_in = (i.clone(), y.clone(), hist.clone(), sl.clone())
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            self._lr_dev = lr_w
+            try:
+                _capture(graph, lambda: self.train_step(*s_in, 0.0))
+            finally:
+                self._lr_dev = None
+            self._train_graphs[(B, T)] = (graph, s_in, lr_w)
+            return loss
+        graph, s_in, lr_w = entry
+        for dst, src in zip(s_in, (i, y, hist, sl)):
+            dst.copy_(src)
+        ops.set_step_words(None, 0, lr_w, float(l))
+        graph.replay()
         return self._loss_dev
 
     def eval(self, sess, uij):

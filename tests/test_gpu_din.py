@@ -81,3 +81,27 @@ def test_din_padding_positions_do_not_matter(sess):
     l1 = m.train(sess, (u, i, y, hist, sl), 0.0)
     l2 = m.train(sess, (u, i, y, hist2, sl), 0.0)
     assert abs(float(l1) - float(l2)) < 1e-6
+
+
+def test_din_graph_replay_matches_eager_steps(sess):
+    """train_step_graphed (one captured graph per (B, T), learning rate through a device word) against train_step on
+    a second model: the same bits after four steps on changing batches and two learning rates."""
+    B, T, H = 64, 50, 32
+    m1, _, uij, _ = _setup(sess, H, seed=11, B=B, T=T, item_count=500, cate_count=20)
+    m2, _, _, _ = _setup(sess, H, seed=11, B=B, T=T, item_count=500, cate_count=20)
+    rng = np.random.default_rng(5)
+    dev = sess.device
+    for step, lr in enumerate((0.1, 0.1, 0.05, 0.05)):
+        sl = rng.integers(1, T + 1, B)
+        hist = rng.integers(0, 500, (B, T))
+        hist[np.arange(T)[None, :] >= sl[:, None]] = 0
+        args = (torch.as_tensor(rng.integers(0, 500, B).astype(np.int32)).to(dev),
+                torch.as_tensor(rng.integers(0, 2, B).astype(np.float32)).to(dev),
+                torch.as_tensor(hist.astype(np.int32)).to(dev), torch.as_tensor(sl.astype(np.int32)).to(dev))
+        l1 = m1.train_step(*args, lr)
+        l2 = m2.train_step_graphed(*args, lr)
+        assert float(l1.item()) == float(l2.item()), step
+    assert len(m2._train_graphs) == 1
+    p1, p2 = m1.get_params(), m2.get_params()
+    for k in p1:
+        assert np.array_equal(p1[k], p2[k]), k

@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--T', type=int, default=200)
     ap.add_argument('--H', type=int, default=32)
     ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--graph', type=int, default=0, help='1: replay the step from a captured graph')
     a = ap.parse_args()
     import recommendation_amd as ra
     from recommendation_amd import ops
@@ -43,19 +44,22 @@ def main():
         batches.append((torch.as_tensor(rng.integers(0, items, a.B).astype(np.int32)).to(dev),
                         torch.as_tensor((rng.random(a.B) < 0.5).astype(np.float32)).to(dev),
                         torch.as_tensor(hist.astype(np.int32)).to(dev), torch.as_tensor(sl.astype(np.int32)).to(dev)))
+    step = m.train_step_graphed if a.graph else m.train_step
     for k in range(3):
-        m.train_step(*batches[k % 4], 0.1)
+        step(*batches[k % 4], 0.1)
     timer = ops.KernelTimer(pool=a.steps * 120)
-    ops.set_timer(timer)
+    if not a.graph:                      # per-operator events cannot be recorded into a replayed graph
+        ops.set_timer(timer)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        m.train_step(*batches[k % 4], 0.1)
+        step(*batches[k % 4], 0.1)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ops.set_timer(None)
     ks = timer.summary()
-    print(json.dumps(dict(workload='DIN Amazon-Books shape, B=%d T=%d H=%d, fwd+bwd+SGD' % (a.B, a.T, a.H),
+    print(json.dumps(dict(workload='DIN Amazon-Books shape, B=%d T=%d H=%d, fwd+bwd+SGD%s' % (
+                              a.B, a.T, a.H, ', graph replay' if a.graph else ''),
                           samples_per_s=a.B * a.steps / dt, ms_per_step=1e3 * dt / a.steps,
                           loss=float(m._loss_dev.item()),
                           kernel_ms_per_step={n: round(v['total_ms'] / a.steps, 4) for n, v in
