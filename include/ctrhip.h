@@ -173,7 +173,7 @@ int ctr_emb_bag_sort(const int32_t* idx, const int32_t* bag_offsets, int64_t nnz
                      void* workspace, size_t workspace_bytes, void* stream);
 /* ctr_emb_sort for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and the same result,
- * bit for bit, as ctr_emb_sort, but the scratch is a 24 MiB array built into the library's device image (one copy
+ * bit for bit, as ctr_emb_sort, but the scratch is a 36 MiB array built into the library's device image (one copy
  * per GPU, held until the process ends) instead of a caller workspace; the call allocates and frees nothing.
  * Limit: B*F <= CTR_EMB_SORT_STATIC_MAX_ITEMS, larger inputs are rejected with CTR_EINVAL.  All calls on one GPU
  * share that GPU's array: calls that overlap in time on one GPU (different streams) race; calls on one stream,

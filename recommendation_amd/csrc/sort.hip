@@ -1,17 +1,22 @@
 // Stable LSD radix sort of (uint32 key, uint32 value) pairs, 9 bits per pass, and the
 // (key, src) pair builder of the embedding backward.  Each pass is three launches:
-// per-tile digit histogram -> exclusive scan of the [digit][tile] counts -> stable scatter.
+// per-tile digit histogram -> exclusive scan of the [tile][digit] counts -> stable scatter.
 // Stability inside a tile comes from wave-level peer masks (ballots over the digit bits)
 // plus per-wave running digit counters in LDS, so the result is bitwise reproducible.
+// Between passes the pairs travel as one uint2 per pair, and a tile is put into digit order
+// in LDS before it is written, so that neighbouring lanes store to neighbouring addresses
+// (a pass used to end in one 4-byte store per lane and array to ~500 places per tile, which
+// bound it by the number of write requests, not by bytes).
 #include "common.h"
 #include <mutex>
 
 namespace ctr {
 
-constexpr int SORT_THREADS = 256;
+constexpr int SORT_THREADS = 512;
 constexpr int SORT_WAVES = SORT_THREADS / 64;
 constexpr int SORT_CHUNKS = 8;                       // 64-key chunks per wave
-constexpr int SORT_TILE = SORT_THREADS * SORT_CHUNKS;  // 2048 keys per block
+constexpr int SORT_TILE = SORT_THREADS * SORT_CHUNKS;  // 4096 keys per block
+constexpr int SCAN_PARTS = 64, SCAN_DIGITS = 16;      // the count scan: tile ranges per digit, digits per block
 // digit width RB: 9 bits (26-bit row keys sort in 3 passes), or 10 where that saves a pass (19-20, 28-30 bits)
 constexpr int RBITS_MAX = 10;
 constexpr int RBINS_MAX = 1 << RBITS_MAX;
@@ -19,18 +24,70 @@ static inline int digit_bits(int key_bits) {
   return (key_bits + 9) / 10 < (key_bits + 8) / 9 ? 10 : 9;
 }
 
+// Exclusive prefix over the block's BPT * SORT_THREADS values (thread t owns entries BPT*t .. BPT*t + BPT - 1).
+// Contains one __syncthreads(); wtot is SORT_WAVES words of LDS that no other scan uses at the same time.
+template <int BPT>
+__device__ __forceinline__ void block_excl_scan(uint32_t (&v)[BPT], uint32_t* wtot, int lane, int wave) {
+  uint32_t loc = 0;
+#pragma unroll
+  for (int u = 0; u < BPT; ++u) loc += v[u];
+  uint32_t incl = loc;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  uint32_t run = incl - loc;
+  for (int w = 0; w < wave; ++w) run += wtot[w];
+#pragma unroll
+  for (int u = 0; u < BPT; ++u) {
+    const uint32_t t = v[u];
+    v[u] = run;
+    run += t;
+  }
+}
+
+// Lane mask of the run of neighbouring lanes that carry the same digit, for the run's first lane (its head);
+// other lanes get head == false.  Sorted or Zipf-distributed keys put long runs of one digit into a chunk, and
+// same-address LDS atomics are served one lane at a time: a run then costs one atomic instead of one per lane.
+// Invalid lanes (past the end of the input: always the chunk's last lanes) join no run.
+__device__ __forceinline__ unsigned long long run_mask(uint32_t d, bool valid, bool& head) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t dd = valid ? d : 0xFFFFFFFFu;
+  const uint32_t dprev = (uint32_t)__shfl_up((int)dd, 1);
+  const bool first = lane == 0 || dd != dprev;
+  const unsigned long long heads = __ballot(first);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const unsigned long long above = heads & ~(below | (1ull << lane));   // heads of later runs
+  head = first && valid;
+  return ((above & (0ull - above)) - 1ull) & ~below;                   // this lane .. the lane before the next head
+}
+
+// Adds a chunk's digits to the tile histogram, one atomic per run of equal digits.
+__device__ __forceinline__ void hist_add_chunk(uint32_t* hist, uint32_t d, bool valid) {
+  bool head;
+  const unsigned long long run = run_mask(d, valid, head);
+  if (head) atomicAdd(&hist[d], (uint32_t)__popcll(run));
+}
+
+constexpr int BUILD_OFFS_LDS = 1024;   // field offsets are staged in LDS up to this many entries
+
 // One block per sort tile: builds the tile's pairs and, while the keys are in registers, the tile's digit
-// histogram of the first radix pass (counts[digit][tile], what radix_hist_kernel would write for shift 0), so the
-// first pass starts at its scan.  32-bit index arithmetic: B*F < 2^32 is required by the callers.
+// histogram of the first radix pass (counts[tile][digit], what radix_hist_kernel would write for shift 0), so the
+// first pass starts at its scan.  32-bit index arithmetic: B*F < 2^32 - 4096 is required by the callers.
 template <int RB>
 __global__ __launch_bounds__(SORT_THREADS) void build_pairs_kernel(
     const int32_t* __restrict__ idx, const int64_t* __restrict__ row_offset, int B, int F, int N,
-    int64_t total_rows, int rmode, uint32_t* __restrict__ keys, uint32_t* __restrict__ src, int nblocks,
-    uint32_t* __restrict__ counts) {  constexpr int RBITS = RB, RBINS = 1 << RB, BINS_PER_THREAD = RBINS / SORT_THREADS;
-
+    int64_t total_rows, int rmode, uint2* __restrict__ pairs, uint32_t* __restrict__ counts) {
+  constexpr int RBINS = 1 << RB;
   __shared__ uint32_t hist[RBINS];
+  __shared__ int64_t offs[BUILD_OFFS_LDS];
+  const bool offs_lds = F < BUILD_OFFS_LDS;
   for (int d = threadIdx.x; d < RBINS; d += SORT_THREADS) hist[d] = 0;
-  __syncthreads();
+  if (offs_lds)
+    for (int f = threadIdx.x; f <= F; f += SORT_THREADS) offs[f] = row_offset[f];
   const uint32_t n = (uint32_t)B * (uint32_t)F;
   const uint32_t base = blockIdx.x * (uint32_t)SORT_TILE;
   int x[SORT_CHUNKS];
@@ -39,28 +96,36 @@ __global__ __launch_bounds__(SORT_THREADS) void build_pairs_kernel(
     const uint32_t i = base + c * SORT_THREADS + threadIdx.x;
     x[c] = i < n ? idx[i] : 0;
   }
+  // (sample, field) of the thread's first item; every further item is SORT_THREADS items on
+  uint32_t b = (base + threadIdx.x) / (uint32_t)F, f = (base + threadIdx.x) - b * (uint32_t)F;
+  const uint32_t step_b = (uint32_t)SORT_THREADS / (uint32_t)F, step_f = (uint32_t)SORT_THREADS % (uint32_t)F;
+  __syncthreads();
 #pragma unroll
   for (int c = 0; c < SORT_CHUNKS; ++c) {
     const uint32_t i = base + c * SORT_THREADS + threadIdx.x;
-    if (i >= n) continue;
-    const uint32_t b = i / (uint32_t)F, f = i - b * (uint32_t)F;
-    const int64_t off = row_offset[f];
-    const int64_t V = row_offset[f + 1] - off;
-    const bool ok = x[c] >= 0 && x[c] < V;
-    uint32_t k, s;
-    if (rmode) {
-      k = ok ? (uint32_t)(off + 1) : (uint32_t)total_rows;
-      s = ok ? (uint32_t)((int64_t)b * N + off + x[c]) : 0u;
-    } else {
-      k = ok ? (uint32_t)(off + x[c]) : (uint32_t)total_rows;
-      s = b * (uint32_t)N + f;
+    const bool valid = i < n;
+    uint32_t k = 0;
+    if (valid) {
+      const int64_t off = offs_lds ? offs[f] : row_offset[f];
+      const int64_t V = (offs_lds ? offs[f + 1] : row_offset[f + 1]) - off;
+      const bool ok = x[c] >= 0 && x[c] < V;
+      uint32_t s;
+      if (rmode) {
+        k = ok ? (uint32_t)(off + 1) : (uint32_t)total_rows;
+        s = ok ? (uint32_t)((int64_t)b * N + off + x[c]) : 0u;
+      } else {
+        k = ok ? (uint32_t)(off + x[c]) : (uint32_t)total_rows;
+        s = b * (uint32_t)N + f;
+      }
+      pairs[i] = make_uint2(k, s);
     }
-    keys[i] = k;
-    src[i] = s;
-    atomicAdd(&hist[k & (RBINS - 1)], 1u);
+    hist_add_chunk(hist, k & (RBINS - 1), valid);
+    b += step_b;
+    f += step_f;
+    if (f >= (uint32_t)F) { f -= (uint32_t)F; ++b; }
   }
   __syncthreads();
-  for (int d = threadIdx.x; d < RBINS; d += SORT_THREADS) counts[(int64_t)d * nblocks + blockIdx.x] = hist[d];
+  for (int d = threadIdx.x; d < RBINS; d += SORT_THREADS) counts[(int64_t)blockIdx.x * RBINS + d] = hist[d];
 }
 
 // Pair builder for multi-hot bags (CSR): one pair per member j of bag (b, f), key = the member's table row,
@@ -83,10 +148,11 @@ __global__ __launch_bounds__(256) void build_bag_pairs_kernel(
   }
 }
 
-template <int RB>
+// counts[tile][digit] of one pass.  SPLIT: the keys are an array of their own; otherwise the .x of uint2 pairs.
+template <int RB, bool SPLIT>
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(
-    const uint32_t* __restrict__ keys, int64_t n, int shift, int nblocks, uint32_t* __restrict__ counts) {  constexpr int RBITS = RB, RBINS = 1 << RB, BINS_PER_THREAD = RBINS / SORT_THREADS;
-
+    const void* __restrict__ in, int64_t n, int shift, uint32_t* __restrict__ counts) {
+  constexpr int RBINS = 1 << RB;
   __shared__ uint32_t hist[RBINS];
   for (int d = threadIdx.x; d < RBINS; d += SORT_THREADS) hist[d] = 0;
   __syncthreads();
@@ -95,136 +161,183 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(
 #pragma unroll
   for (int c = 0; c < SORT_CHUNKS; ++c) {
     const int64_t p = base + c * SORT_THREADS + threadIdx.x;
-    k[c] = p < n ? keys[p] : 0u;
+    k[c] = p < n ? (SPLIT ? ((const uint32_t*)in)[p] : ((const uint2*)in)[p].x) : 0u;
   }
 #pragma unroll
   for (int c = 0; c < SORT_CHUNKS; ++c) {
     const int64_t p = base + c * SORT_THREADS + threadIdx.x;
-    if (p < n) atomicAdd(&hist[(k[c] >> shift) & (RBINS - 1)], 1u);
+    hist_add_chunk(hist, (k[c] >> shift) & (RBINS - 1), p < n);
   }
   __syncthreads();
-  for (int d = threadIdx.x; d < RBINS; d += SORT_THREADS) counts[(int64_t)d * nblocks + blockIdx.x] = hist[d];
+  for (int d = threadIdx.x; d < RBINS; d += SORT_THREADS) counts[(int64_t)blockIdx.x * RBINS + d] = hist[d];
 }
 
-// Block d turns row d of counts[digit][tile] into its exclusive prefix over the tiles and
-// stores the row total in totals[d]; the scatter kernel adds the prefix over the digits itself.
-__global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ counts, int nblocks,
-                                                        uint32_t* __restrict__ totals) {
-  __shared__ uint32_t wsum[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t* row = counts + (int64_t)blockIdx.x * nblocks;
-  uint32_t carry = 0;
-  for (int base = 0; base < nblocks; base += 1024) {
-    // four consecutive tiles per thread, then a scan over the threads
-    uint32_t c[4], loc = 0;
+// Turns every column of counts[tile][digit] into its exclusive prefix over the tiles and stores the column
+// totals in totals[digit]; the scatter kernel adds the prefix over the digits itself.  A block owns SCAN_DIGITS
+// digits and splits the tiles into SCAN_PARTS ranges, a thread per (range, digit): up to 8 tiles per range stay in
+// registers, so the kernel is one round of loads, one exchange through LDS and one round of stores.
+__global__ __launch_bounds__(SCAN_PARTS * SCAN_DIGITS) void radix_scan_kernel(uint32_t* __restrict__ counts,
+                                                                              int nblocks, int rbins,
+                                                                              uint32_t* __restrict__ totals) {
+  __shared__ uint32_t psum[SCAN_PARTS][SCAN_DIGITS + 1];
+  const int dl = threadIdx.x % SCAN_DIGITS, part = threadIdx.x / SCAN_DIGITS;
+  const int d = blockIdx.x * SCAN_DIGITS + dl;
+  const int per = (nblocks + SCAN_PARTS - 1) / SCAN_PARTS;
+  const int lo = part * per < nblocks ? part * per : nblocks, hi = lo + per < nblocks ? lo + per : nblocks;
+  uint32_t* col = counts + d;
+  uint32_t c[8], s = 0;
+  const bool in_regs = per <= 8;
+  if (in_regs) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = base + 4 * threadIdx.x + u;
-      c[u] = i < nblocks ? row[i] : 0u;
-      loc += c[u];
+    for (int u = 0; u < 8; ++u) c[u] = lo + u < hi ? col[(int64_t)(lo + u) * rbins] : 0u;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += c[u];
+  } else {
+    int t = lo;
+    for (; t + 8 <= hi; t += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c[u] = col[(int64_t)(t + u) * rbins];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += c[u];
     }
-    uint32_t incl = loc;
+    for (; t < hi; ++t) s += col[(int64_t)t * rbins];
+  }
+  psum[part][dl] = s;
+  __syncthreads();
+  uint32_t run = 0, tot = 0;
+#pragma unroll 8
+  for (int q = 0; q < SCAN_PARTS; ++q) {
+    const uint32_t v = psum[q][dl];
+    if (q < part) run += v;
+    tot += v;
+  }
+  if (in_regs) {
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t v = __shfl_up(incl, o);
-      if (lane >= o) incl += v;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t woff = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (w < wave) woff += wsum[w];
-      tot += wsum[w];
-    }
-    uint32_t run = carry + woff + incl - loc;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = base + 4 * threadIdx.x + u;
-      if (i < nblocks) row[i] = run;
+    for (int u = 0; u < 8; ++u) {
+      if (lo + u < hi) col[(int64_t)(lo + u) * rbins] = run;
       run += c[u];
     }
-    carry += tot;
-    __syncthreads();
+  } else {
+    int t = lo;
+    for (; t + 8 <= hi; t += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c[u] = col[(int64_t)(t + u) * rbins];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        col[(int64_t)(t + u) * rbins] = run;
+        run += c[u];
+      }
+    }
+    for (; t < hi; ++t) {
+      const uint32_t v = col[(int64_t)t * rbins];
+      col[(int64_t)t * rbins] = run;
+      run += v;
+    }
   }
-  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+  if (part == 0) totals[d] = tot;
 }
 
-template <int RB>
+// One pass's stable scatter.  IN_SPLIT / OUT_SPLIT: keys and values in two arrays (in_a / in_b, out_a / out_b: what
+// the callers hand in and get back) instead of one uint2 per pair in in_a / out_a (between passes).
+//
+// Ranking inside a wave: the lanes of a 64-key chunk that carry the same digit find each other through a 64-bit
+// lane mask per digit in LDS (an atomic OR of the bits of each run of neighbouring lanes with that digit, read back,
+// cleared; the OR commutes, so the mask does not depend on the order the hardware serves the lanes in).  The chunk's lowest lane of a digit adds the group's
+// size to the wave's running count of that digit and receives the count before it (LDS operations of a wave
+// execute in program order, so chunk c is counted before chunk c + 1); the other lanes of the group fetch it
+// from that lane.  A key's rank in the wave is that count plus the number of lower lanes in its group.
+// The running counts are 16-bit halves of 32-bit words (a wave holds 512 keys, so no half overflows).
+template <int RB, bool IN_SPLIT, bool OUT_SPLIT>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
-    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t n, int shift,
-    int nblocks, const uint32_t* __restrict__ scanned, const uint32_t* __restrict__ totals,
-    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {  constexpr int RBITS = RB, RBINS = 1 << RB, BINS_PER_THREAD = RBINS / SORT_THREADS;
-
-  __shared__ uint32_t whist[SORT_WAVES][RBINS];
-  __shared__ uint32_t dbase[RBINS];
-  __shared__ uint32_t wtot[SORT_WAVES];
+    const void* __restrict__ in_a, const void* __restrict__ in_b, int64_t n, int shift,
+    const uint32_t* __restrict__ scanned, const uint32_t* __restrict__ totals, void* __restrict__ out_a,
+    void* __restrict__ out_b) {
+  constexpr int RBINS = 1 << RB, BPT = RBINS / SORT_THREADS, MSLOTS = 512;
+  static_assert(SORT_WAVES * MSLOTS == SORT_TILE, "the lane masks and the staged tile share one LDS array");
+  __shared__ uint32_t whist32[SORT_WAVES][RBINS / 2];   // per wave: running digit counts, then the wave's offset in the run
+  __shared__ uint32_t tstart[RBINS];                    // where digit d's run starts in the tile's digit order
+  __shared__ uint32_t goff[RBINS];                      // (global position of that run) - tstart[d]
+  __shared__ unsigned long long lds64[SORT_TILE];       // lane masks [wave][digit mod 512]; later the tile in digit order
+  __shared__ uint32_t wtot_a[SORT_WAVES], wtot_b[SORT_WAVES];
+  uint16_t* whist = (uint16_t*)&whist32[0][0];          // [wave][digit]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  // the tile's keys first: their loads overlap the prefix work below
-  const int64_t wbase = (int64_t)blockIdx.x * SORT_TILE + (int64_t)wave * SORT_CHUNKS * 64;
+  const int64_t tbase = (int64_t)blockIdx.x * SORT_TILE;
+  // the tile's pairs first: their loads overlap the prefix work below
+  const int64_t wbase = tbase + (int64_t)wave * SORT_CHUNKS * 64;
   uint32_t key[SORT_CHUNKS], val[SORT_CHUNKS], rank[SORT_CHUNKS];
 #pragma unroll
   for (int c = 0; c < SORT_CHUNKS; ++c) {
     const int64_t p = wbase + c * 64 + lane;
-    const bool valid = p < n;
-    key[c] = valid ? keys_in[p] : 0u;
-    val[c] = valid ? vals_in[p] : 0u;
-  }
-  {  // exclusive prefix of the digit totals; thread t owns digits BINS_PER_THREAD*t ...
-    uint32_t tv[BINS_PER_THREAD], loc = 0;
-#pragma unroll
-    for (int u = 0; u < BINS_PER_THREAD; ++u) {
-      tv[u] = totals[BINS_PER_THREAD * threadIdx.x + u];
-      loc += tv[u];
-    }
-    uint32_t incl = loc;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t v = __shfl_up(incl, o);
-      if (lane >= o) incl += v;
-    }
-    if (lane == 63) wtot[wave] = incl;
-    for (int i = threadIdx.x; i < SORT_WAVES * RBINS; i += SORT_THREADS) (&whist[0][0])[i] = 0;
-    __syncthreads();
-    uint32_t run = incl - loc;
-    for (int w = 0; w < wave; ++w) run += wtot[w];
-#pragma unroll
-    for (int u = 0; u < BINS_PER_THREAD; ++u) {
-      dbase[BINS_PER_THREAD * threadIdx.x + u] = run;
-      run += tv[u];
+    key[c] = 0u;
+    val[c] = 0u;
+    if (p < n) {
+      if (IN_SPLIT) {
+        key[c] = ((const uint32_t*)in_a)[p];
+        val[c] = ((const uint32_t*)in_b)[p];
+      } else {
+        const uint2 kv = ((const uint2*)in_a)[p];
+        key[c] = kv.x;
+        val[c] = kv.y;
+      }
     }
   }
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  uint32_t gb[BPT], sc[BPT];   // thread t owns digits BPT*t ...: global start of the digit, this tile's offset in it
+#pragma unroll
+  for (int u = 0; u < BPT; ++u) {
+    gb[u] = totals[BPT * threadIdx.x + u];
+    sc[u] = scanned[(int64_t)blockIdx.x * RBINS + BPT * threadIdx.x + u];
+  }
+  for (int i = threadIdx.x; i < SORT_WAVES * RBINS / 2; i += SORT_THREADS) (&whist32[0][0])[i] = 0u;
+  for (int i = threadIdx.x; i < SORT_TILE; i += SORT_THREADS) lds64[i] = 0ull;
+  block_excl_scan<BPT>(gb, wtot_a, lane, wave);   // its barrier also orders the clearing above
+  unsigned long long* mrow = lds64 + wave * MSLOTS;
 #pragma unroll
   for (int c = 0; c < SORT_CHUNKS; ++c) {
     const int64_t p = wbase + c * 64 + lane;
     const bool valid = p < n;
     const uint32_t d = (key[c] >> shift) & (RBINS - 1);
-    unsigned long long peers = __ballot(valid);
-#pragma unroll
-    for (int bit = 0; bit < RBITS; ++bit) {
-      const bool set = (d >> bit) & 1u;
-      const unsigned long long m = __ballot(valid && set);
-      peers &= set ? m : ~m;
+    const uint32_t slot = d & (MSLOTS - 1);
+    bool head;
+    const unsigned long long run = run_mask(d, valid, head);
+    if (head) atomicOr(&mrow[slot], run);
+    unsigned long long peers = mrow[slot];
+    mrow[slot] = 0ull;
+    if (RB > 9) {   // digits that share a slot differ in bit 9
+      const uint32_t t = (uint32_t)__builtin_amdgcn_sbfe((int)d, 9, 1);   // all ones if the bit is set
+      const unsigned long long m = __ballot(valid && t != 0u);
+      peers &= ~(m ^ (((unsigned long long)t << 32) | t));
     }
+    if (!valid) peers = 1ull << lane;
+    const uint32_t in_chunk =
+        __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+    const uint32_t hshift = (d & 1u) * 16u;
     uint32_t prior = 0;
-    if (valid) prior = whist[wave][d];
-    const uint32_t in_chunk = (uint32_t)__popcll(peers & lt_mask);
-    rank[c] = prior + in_chunk;
-    // the lowest peer lane publishes the chunk's count for this digit
-    if (valid && in_chunk == 0) whist[wave][d] = prior + (uint32_t)__popcll(peers);
+    if (valid && in_chunk == 0) prior = atomicAdd(&whist32[wave][d >> 1], (uint32_t)__popcll(peers) << hshift);
+    prior = (uint32_t)__shfl((int)prior, __ffsll((long long)peers) - 1);
+    rank[c] = ((prior >> hshift) & 0xFFFFu) + in_chunk;
   }
   __syncthreads();
-  // per digit: exclusive prefix over the waves + this tile's global base
-  for (int d = threadIdx.x; d < RBINS; d += SORT_THREADS) {
-    uint32_t run = dbase[d] + scanned[(int64_t)d * nblocks + blockIdx.x];
+  // per digit: exclusive prefix over the waves, the tile's count
+  uint32_t ts[BPT];
+#pragma unroll
+  for (int u = 0; u < BPT; ++u) {
+    const int d = BPT * threadIdx.x + u;
+    uint32_t run = 0;
 #pragma unroll
     for (int w = 0; w < SORT_WAVES; ++w) {
-      const uint32_t c = whist[w][d];
-      whist[w][d] = run;
+      const uint32_t c = whist[w * RBINS + d];
+      whist[w * RBINS + d] = (uint16_t)run;
       run += c;
     }
+    ts[u] = run;
+  }
+  block_excl_scan<BPT>(ts, wtot_b, lane, wave);
+#pragma unroll
+  for (int u = 0; u < BPT; ++u) {
+    const int d = BPT * threadIdx.x + u;
+    tstart[d] = ts[u];
+    goff[d] = gb[u] + sc[u] - ts[u];
   }
   __syncthreads();
 #pragma unroll
@@ -232,9 +345,25 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const int64_t p = wbase + c * 64 + lane;
     if (p < n) {
       const uint32_t d = (key[c] >> shift) & (RBINS - 1);
-      const uint32_t dst = whist[wave][d] + rank[c];
-      keys_out[dst] = key[c];
-      vals_out[dst] = val[c];
+      lds64[tstart[d] + whist[wave * RBINS + d] + rank[c]] = (unsigned long long)key[c] | ((unsigned long long)val[c] << 32);
+    }
+  }
+  __syncthreads();
+  const int64_t left = n - tbase;
+  const uint32_t tile_n = left < SORT_TILE ? (uint32_t)left : (uint32_t)SORT_TILE;
+#pragma unroll
+  for (int c = 0; c < SORT_CHUNKS; ++c) {
+    const uint32_t i = c * SORT_THREADS + threadIdx.x;
+    if (i < tile_n) {
+      const unsigned long long kv = lds64[i];
+      const uint32_t k = (uint32_t)kv;
+      const uint32_t dst = goff[(k >> shift) & (RBINS - 1)] + i;
+      if (OUT_SPLIT) {
+        ((uint32_t*)out_a)[dst] = k;
+        ((uint32_t*)out_b)[dst] = (uint32_t)(kv >> 32);
+      } else {
+        ((unsigned long long*)out_a)[dst] = kv;
+      }
     }
   }
 }
@@ -246,50 +375,74 @@ static int bits_for(uint64_t max_value) {
 }
 
 struct SortWs {
-  uint32_t *keys_tmp, *vals_tmp, *counts, *totals;
+  uint2 *pa, *pb;              // the pairs between passes (ping-pong)
+  uint32_t *counts, *totals;   // counts[tile][digit], totals[digit]
   int nblocks;
 };
 
 static size_t sort_ws_bytes(int64_t n) {
   const int64_t nblocks = cdiv(n > 0 ? n : 1, SORT_TILE);
-  return align_up((size_t)n * 4, 256) * 2 + align_up((size_t)nblocks * RBINS_MAX * 4, 256) + RBINS_MAX * 4;
+  return align_up((size_t)n * 8, 256) * 2 + align_up((size_t)nblocks * RBINS_MAX * 4, 256) + RBINS_MAX * 4;
 }
 
 static SortWs carve(void* ws, int64_t n) {
   SortWs w;
   char* p = (char*)ws;
   w.nblocks = (int)cdiv(n > 0 ? n : 1, SORT_TILE);
-  w.keys_tmp = (uint32_t*)p; p += align_up((size_t)n * 4, 256);
-  w.vals_tmp = (uint32_t*)p; p += align_up((size_t)n * 4, 256);
+  w.pa = (uint2*)p; p += align_up((size_t)n * 8, 256);
+  w.pb = (uint2*)p; p += align_up((size_t)n * 8, 256);
   w.counts = (uint32_t*)p; p += align_up((size_t)w.nblocks * RBINS_MAX * 4, 256);
   w.totals = (uint32_t*)p;
   return w;
 }
 
-// Sorts the pairs currently in (ka, va); the result lands in (keys_out, vals_out).
-// (ka, va) must be (keys_out, vals_out) when the pass count is even, else the tmp pair.
-static int run_passes(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, int64_t n, int passes, int rb,
-                      const SortWs& w, hipStream_t st, bool first_hist_done = false) {
-  for (int p = 0; p < passes; ++p) {
-    const int shift = rb * p;
-    if (p > 0 || !first_hist_done) {
-      if (rb == 10)
-        hipLaunchKernelGGL(radix_hist_kernel<10>, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, n, shift, w.nblocks,
-                           w.counts);
-      else
-        hipLaunchKernelGGL(radix_hist_kernel<9>, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, n, shift, w.nblocks,
-                           w.counts);
-    }
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(1 << rb), dim3(256), 0, st, w.counts, w.nblocks, w.totals);
-    if (rb == 10)
-      hipLaunchKernelGGL(radix_scatter_kernel<10>, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, va, n, shift,
-                         w.nblocks, w.counts, w.totals, kb, vb);
+template <int RB>
+static void launch_pass(const void* ia, const void* ib, bool in_split, void* oa, void* ob, bool out_split, int64_t n,
+                        int shift, bool need_hist, const SortWs& w, hipStream_t st) {
+  const dim3 grid(w.nblocks), block(SORT_THREADS);
+  if (need_hist) {
+    if (in_split)
+      hipLaunchKernelGGL((radix_hist_kernel<RB, true>), grid, block, 0, st, ia, n, shift, w.counts);
     else
-      hipLaunchKernelGGL(radix_scatter_kernel<9>, dim3(w.nblocks), dim3(SORT_THREADS), 0, st, ka, va, n, shift,
-                         w.nblocks, w.counts, w.totals, kb, vb);
-    uint32_t* t;
-    t = ka; ka = kb; kb = t;
-    t = va; va = vb; vb = t;
+      hipLaunchKernelGGL((radix_hist_kernel<RB, false>), grid, block, 0, st, ia, n, shift, w.counts);
+  }
+  hipLaunchKernelGGL(radix_scan_kernel, dim3((1 << RB) / SCAN_DIGITS), dim3(SCAN_PARTS * SCAN_DIGITS), 0, st, w.counts,
+                     w.nblocks, 1 << RB, w.totals);
+  if (in_split && out_split)
+    hipLaunchKernelGGL((radix_scatter_kernel<RB, true, true>), grid, block, 0, st, ia, ib, n, shift, w.counts, w.totals,
+                       oa, ob);
+  else if (in_split)
+    hipLaunchKernelGGL((radix_scatter_kernel<RB, true, false>), grid, block, 0, st, ia, ib, n, shift, w.counts,
+                       w.totals, oa, ob);
+  else if (out_split)
+    hipLaunchKernelGGL((radix_scatter_kernel<RB, false, true>), grid, block, 0, st, ia, ib, n, shift, w.counts,
+                       w.totals, oa, ob);
+  else
+    hipLaunchKernelGGL((radix_scatter_kernel<RB, false, false>), grid, block, 0, st, ia, ib, n, shift, w.counts,
+                       w.totals, oa, ob);
+}
+
+// Sorts n pairs into (keys_out, vals_out).  The input is (keys_in, vals_in), or, with keys_in == nullptr, the
+// uint2 pairs already in w.pa (first_hist_done: w.counts then holds the first pass's tile histograms).
+// (keys_in, vals_in) may be (keys_out, vals_out) when there are at least two passes.
+static int run_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                      int64_t n, int passes, int rb, const SortWs& w, hipStream_t st, bool first_hist_done = false) {
+  const void *ia = keys_in ? (const void*)keys_in : (const void*)w.pa, *ib = vals_in;
+  bool in_split = keys_in != nullptr;
+  uint2* next = keys_in ? w.pa : w.pb;
+  for (int p = 0; p < passes; ++p) {
+    const bool last = p == passes - 1;
+    void* oa = last ? (void*)keys_out : (void*)next;
+    void* ob = last ? (void*)vals_out : nullptr;
+    const bool need_hist = p > 0 || !first_hist_done;
+    if (rb == 10)
+      launch_pass<10>(ia, ib, in_split, oa, ob, last, n, rb * p, need_hist, w, st);
+    else
+      launch_pass<9>(ia, ib, in_split, oa, ob, last, n, rb * p, need_hist, w, st);
+    ia = next;
+    ib = nullptr;
+    in_split = false;
+    next = next == w.pa ? w.pb : w.pa;
   }
   return 0;
 }
@@ -378,14 +531,9 @@ extern "C" int ctr_auc(const float* score, const float* label, int64_t n, float*
   double* part = (double*)p; p += AUC_BLOCKS * 3 * sizeof(double);
   const SortWs w = carve(p, n);
   const int64_t blocks = cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048;
-  const int rb = digit_bits(32), passes = (32 + rb - 1) / rb;
-  // the pass count decides which buffer pair the sort starts from so that it ends in (keys, vals)
-  uint32_t* ka = (passes % 2 == 0) ? keys : w.keys_tmp;
-  uint32_t* va = (passes % 2 == 0) ? vals : w.vals_tmp;
-  uint32_t* kb = (passes % 2 == 0) ? w.keys_tmp : keys;
-  uint32_t* vb = (passes % 2 == 0) ? w.vals_tmp : vals;
-  hipLaunchKernelGGL(auc_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, st, score, label, n, ka, va);
-  run_passes(ka, va, kb, vb, n, passes, rb, w, st);
+  const int rb = digit_bits(32), passes = (32 + rb - 1) / rb;   // four passes: sorting in place is allowed
+  hipLaunchKernelGGL(auc_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, st, score, label, n, keys, vals);
+  run_passes(keys, vals, keys, vals, n, passes, rb, w, st);
   const int nb = (int)(cdiv(n, 256) < AUC_BLOCKS ? cdiv(n, 256) : AUC_BLOCKS);
   hipLaunchKernelGGL(auc_partial_kernel, dim3(nb), dim3(256), 0, st, keys, vals, n, score, label, part);
   hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(1), 0, st, part, nb, n, auc_out, logloss_out);
@@ -412,17 +560,13 @@ extern "C" int ctr_emb_sort(const int32_t* idx, const int64_t* row_offset, int B
   hipStream_t st = (hipStream_t)stream;
   const SortWs w = carve(workspace, n);
   const int kbits = bits_for((uint64_t)total_rows), rb = digit_bits(kbits), passes = (kbits + rb - 1) / rb;
-  uint32_t* ka = (passes % 2 == 0) ? keys_out : w.keys_tmp;
-  uint32_t* va = (passes % 2 == 0) ? src_out : w.vals_tmp;
-  uint32_t* kb = (passes % 2 == 0) ? w.keys_tmp : keys_out;
-  uint32_t* vb = (passes % 2 == 0) ? w.vals_tmp : src_out;
   if (rb == 10)
     hipLaunchKernelGGL(build_pairs_kernel<10>, dim3((unsigned)w.nblocks), dim3(SORT_THREADS), 0, st, idx, row_offset, B,
-                       F, N, total_rows, rmode, ka, va, w.nblocks, w.counts);
+                       F, N, total_rows, rmode, w.pa, w.counts);
   else
     hipLaunchKernelGGL(build_pairs_kernel<9>, dim3((unsigned)w.nblocks), dim3(SORT_THREADS), 0, st, idx, row_offset, B,
-                       F, N, total_rows, rmode, ka, va, w.nblocks, w.counts);
-  run_passes(ka, va, kb, vb, n, passes, rb, w, st, true);
+                       F, N, total_rows, rmode, w.pa, w.counts);
+  run_passes(nullptr, nullptr, keys_out, src_out, n, passes, rb, w, st, true);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
@@ -443,15 +587,15 @@ extern "C" int ctr_emb_bag_sort(const int32_t* idx, const int32_t* bag_offsets, 
   hipStream_t st = (hipStream_t)stream;
   const SortWs w = carve(workspace, nnz);
   const int kbits = bits_for((uint64_t)total_rows), rb = digit_bits(kbits), passes = (kbits + rb - 1) / rb;
-  uint32_t* ka = (passes % 2 == 0) ? keys_out : w.keys_tmp;
-  uint32_t* va = (passes % 2 == 0) ? src_out : w.vals_tmp;
-  uint32_t* kb = (passes % 2 == 0) ? w.keys_tmp : keys_out;
-  uint32_t* vb = (passes % 2 == 0) ? w.vals_tmp : src_out;
+  // the builder's split pairs go where the result will: with one pass the sort would read and write the same
+  // arrays, so that case builds into the second ping-pong buffer instead (unused by a one-pass sort)
+  uint32_t* bk = passes > 1 ? keys_out : (uint32_t*)w.pb;
+  uint32_t* bv = passes > 1 ? src_out : (uint32_t*)w.pb + nnz;
   const int64_t nbags = (int64_t)B * F;
   const int64_t blocks = cdiv(nbags, 256) < 2048 ? cdiv(nbags, 256) : 2048;
   hipLaunchKernelGGL(build_bag_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, idx, bag_offsets, row_offset,
-                     B, F, N, total_rows, ka, va);
-  run_passes(ka, va, kb, vb, nnz, passes, rb, w, st);
+                     B, F, N, total_rows, bk, bv);
+  run_passes(bk, bv, keys_out, src_out, nnz, passes, rb, w, st);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
@@ -461,7 +605,7 @@ extern "C" int ctr_emb_bag_sort(const int32_t* idx, const int32_t* bag_offsets, 
 // callers that cannot allocate device memory.  Each GPU holds its own copy of the array (at its own address)
 // from the moment the library is loaded on it until the process ends.
 // ---------------------------------------------------------------------------------------
-constexpr size_t SORT_STATIC_BYTES = (size_t)24 << 20;
+constexpr size_t SORT_STATIC_BYTES = (size_t)36 << 20;
 static __device__ __align__(256) unsigned char sort_static_scratch[SORT_STATIC_BYTES];
 
 namespace {
@@ -516,14 +660,9 @@ extern "C" int ctr_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in, 
   hipStream_t st = (hipStream_t)stream;
   const SortWs w = carve(workspace, n);
   const int rb = digit_bits(key_bits), passes = (key_bits + rb - 1) / rb;
-  uint32_t* ka = (passes % 2 == 0) ? keys_out : w.keys_tmp;
-  uint32_t* va = (passes % 2 == 0) ? vals_out : w.vals_tmp;
-  uint32_t* kb = (passes % 2 == 0) ? w.keys_tmp : keys_out;
-  uint32_t* vb = (passes % 2 == 0) ? w.vals_tmp : vals_out;
-  hipError_t e = hipMemcpyAsync(ka, keys_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(va, vals_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
-  if (e != hipSuccess) { set_error("ctr_sort_pairs: copy failed: %s", hipGetErrorString(e)); return (int)e; }
-  run_passes(ka, va, kb, vb, n, passes, rb, w, st);
+  CTR_REQUIRE(passes > 1 || (keys_in != keys_out && vals_in != vals_out),
+              "ctr_sort_pairs: a one-pass sort cannot work in place");
+  run_passes(keys_in, vals_in, keys_out, vals_out, n, passes, rb, w, st);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
