@@ -233,8 +233,27 @@ int ctr_emb_sparse_apply(const uint32_t* keys_sorted, const uint32_t* src_sorted
  * epilogue, in this order: += bias[n] (optional); accumulate (C += result, when
  * accumulate != 0); relu (when relu != 0); dropout (optional); mask: where
  * mask_src[m*mask_ld+n] <= 0 the result is 0, elsewhere it is multiplied by mask_scale
- * (optional; this is the relu+dropout backward given the layer's stored output).
+ * (optional; this is the relu+dropout backward given the layer's stored output); fm_bwd (optional, last): the
+ * product is the tower's gradient with respect to x0 = [Z | x_cont], and the FM terms of ctr_embed_bwd_dz are
+ * added to its first n_rows*E columns on the way out (the same arithmetic in the same order, so the same bits
+ * as the separate pass over gz):
+ *   C[m, n*E + e] += g_first[m,n] + g_second[m,e]*(s[m,e] - z[m, n*E + e])
+ * (gradient of DeepFM/DeepFM.py:55-66).  g_first / g_second are the gradients with respect to the first- and
+ * second-order terms BEFORE their dropout (ctr_dropout_apply puts the keep masks on them); each is optional;
+ * s ([M,E] contiguous) and z are needed with g_second and must be 16-byte aligned with z_ld % 4 == 0, E % 4 == 0.
  * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* g_first;
+  int64_t g_first_ld;
+  const float* g_second;
+  int64_t g_second_ld;
+  const float* s;
+  const float* z;
+  int64_t z_ld;
+  int n_rows; /* rows of Z per sample */
+  int E;
+} ctr_fm_bwd_t;
+
 typedef struct {
   const float* bias;
   int relu; /* 0 none, 1 relu, 2 sigmoid (DIN attention MLP, DIN/DIN.py:175-176) */
@@ -243,6 +262,7 @@ typedef struct {
   const float* mask_src;
   int64_t mask_ld;
   float mask_scale;
+  const ctr_fm_bwd_t* fm_bwd;
 } ctr_epilogue_t;
 
 /* Arithmetic of the tiled GEMM (process-wide; default CTR_GEMM_SPLIT_BF16):
@@ -577,6 +597,13 @@ int ctr_mul2d(const float* a, int64_t lda, const float* b, int64_t ldb, float* o
               void* stream);
 int ctr_dropout_apply(float* x, int64_t ld, int rows, int cols, const ctr_dropout_t* drop,
                       void* stream);
+/* Two neighbouring column blocks of one buffer, each under its own dropout, in one launch: the keep masks of the
+ * first- and second-order FM terms (DeepFM/DeepFM.py:58,63) put onto their gradients [g_first | g_second] before
+ * ctr_gemm_f32's fm_bwd epilogue consumes them:
+ *   x[r, c] *= keep_a(r*cols_a + c) for c < cols_a;  x[r, cols_a + c] *= keep_b(r*cols_b + c) for c < cols_b
+ * (the element indices ctr_embed_fwd / ctr_embed_bwd_dz use).  Either descriptor may be NULL (block untouched). */
+int ctr_dropout_apply2(float* x, int64_t ld, int rows, int cols_a, const ctr_dropout_t* drop_a,
+                       int cols_b, const ctr_dropout_t* drop_b, void* stream);
 
 #ifdef __cplusplus
 }

@@ -30,10 +30,16 @@ class Opt(C.Structure):
                 ('lr_dev', C.c_void_p)]
 
 
+class FmBwd(C.Structure):
+    _fields_ = [('g_first', C.c_void_p), ('g_first_ld', C.c_int64), ('g_second', C.c_void_p),
+                ('g_second_ld', C.c_int64), ('s', C.c_void_p), ('z', C.c_void_p), ('z_ld', C.c_int64),
+                ('n_rows', C.c_int), ('E', C.c_int)]
+
+
 class Epilogue(C.Structure):
     _fields_ = [('bias', C.c_void_p), ('relu', C.c_int), ('accumulate', C.c_int),
                 ('dropout', C.POINTER(Dropout)), ('mask_src', C.c_void_p),
-                ('mask_ld', C.c_int64), ('mask_scale', C.c_float)]
+                ('mask_ld', C.c_int64), ('mask_scale', C.c_float), ('fm_bwd', C.POINTER(FmBwd))]
 
 
 OPT_GRAD_ONLY, OPT_ADAM, OPT_ADAGRAD, OPT_SGD, OPT_FTRL = 0, 1, 2, 3, 4
@@ -131,6 +137,7 @@ SIGNATURES = {
     'ctr_copy2d': (i, [vp, i64, vp, i64, i, i, i, vp]),
     'ctr_mul2d': (i, [vp, i64, vp, i64, vp, i64, i, i, vp]),
     'ctr_dropout_apply': (i, [vp, i64, i, i, DP, vp]),
+    'ctr_dropout_apply2': (i, [vp, i64, i, i, DP, i, DP, vp]),
 }
 
 _lib = None

@@ -217,6 +217,20 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(float* __restrict__ 
   }
 }
 
+// Two column blocks under two dropouts; LW = log2 of the lanes given to a row (>= cols_a + cols_b), so the row and
+// column of a thread are a shift and a mask.
+__global__ __launch_bounds__(256) void dropout_apply2_kernel(float* __restrict__ x, int64_t ld, int rows, int cols_a,
+                                                            Drop da, int cols_b, Drop db, int LW) {
+  const int c = threadIdx.x & ((1 << LW) - 1);
+  const int rstep = 256 >> LW;
+  if (c >= cols_a + cols_b) return;
+  const bool first = c < cols_a;
+  for (int64_t r = (int64_t)blockIdx.x * rstep + (threadIdx.x >> LW); r < rows; r += (int64_t)gridDim.x * rstep) {
+    const float k = first ? drop_mul(da, (uint64_t)r * cols_a + c) : drop_mul(db, (uint64_t)r * cols_b + (c - cols_a));
+    x[r * ld + c] *= k;
+  }
+}
+
 // g *= (act > 0 ? scale : 0): backward of relu followed by dropout, given the stored output
 __global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ g, int64_t g_ld,
                                                        const float* __restrict__ act, int64_t act_ld, int rows,
@@ -551,6 +565,27 @@ extern "C" int ctr_dropout_apply(float* x, int64_t ld, int rows, int cols, const
   CTR_REQUIRE(x, "ctr_dropout_apply: null pointer");
   hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid_for((int64_t)rows * cols)), dim3(256), 0,
                      (hipStream_t)stream, x, ld, rows, cols, d);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_dropout_apply2(float* x, int64_t ld, int rows, int cols_a, const ctr_dropout_t* drop_a, int cols_b,
+                                  const ctr_dropout_t* drop_b, void* stream) {
+  CTR_REQUIRE(rows >= 0 && cols_a >= 0 && cols_b >= 0 && ld >= cols_a + cols_b, "ctr_dropout_apply2: bad size");
+  const Drop da = make_drop(drop_a), db = make_drop(drop_b);
+  if ((int64_t)rows * (cols_a + cols_b) == 0 || (!da.on && !db.on)) return CTR_OK;
+  CTR_REQUIRE(x, "ctr_dropout_apply2: null pointer");
+  if (cols_a + cols_b > 256) {   // wide blocks: one plain launch each
+    int rc = CTR_OK;
+    if (da.on) rc = ctr_dropout_apply(x, ld, rows, cols_a, drop_a, stream);
+    if (rc == CTR_OK && db.on) rc = ctr_dropout_apply(x + cols_a, ld, rows, cols_b, drop_b, stream);
+    return rc;
+  }
+  int lw = 0;
+  while ((1 << lw) < cols_a + cols_b) ++lw;
+  const int64_t steps = cdiv(rows, 256 >> lw);
+  hipLaunchKernelGGL(dropout_apply2_kernel, dim3((unsigned)(steps < 4096 ? steps : 4096)), dim3(256), 0,
+                     (hipStream_t)stream, x, ld, rows, cols_a, da, cols_b, db, lw);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }

@@ -381,10 +381,12 @@ __global__ __launch_bounds__(256) void embed_bwd_dz_kernel(
       const float4 ss = *reinterpret_cast<const float4*>(s + b * E + g * 4);
       const float* g2 = g_second + b * g_second_ld + g * 4;
       const uint64_t base = (uint64_t)b * E + g * 4;
-      a.x += g2[0] * drop_mul(d_second, base + 0) * (ss.x - zz.x);
-      a.y += g2[1] * drop_mul(d_second, base + 1) * (ss.y - zz.y);
-      a.z += g2[2] * drop_mul(d_second, base + 2) * (ss.z - zz.z);
-      a.w += g2[3] * drop_mul(d_second, base + 3) * (ss.w - zz.w);
+      // the fused multiply-add is spelled out: the GEMM epilogue that folds this pass into the tower's last product
+      // (ctr_fm_bwd_t) rounds the same way
+      a.x = fmaf(g2[0] * drop_mul(d_second, base + 0), ss.x - zz.x, a.x);
+      a.y = fmaf(g2[1] * drop_mul(d_second, base + 1), ss.y - zz.y, a.y);
+      a.z = fmaf(g2[2] * drop_mul(d_second, base + 2), ss.z - zz.z, a.z);
+      a.w = fmaf(g2[3] * drop_mul(d_second, base + 3), ss.w - zz.w, a.w);
     }
     if (g_sum) {
       const float4 gs = *reinterpret_cast<const float4*>(g_sum + b * E + g * 4);

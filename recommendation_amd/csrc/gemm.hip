@@ -16,6 +16,13 @@ constexpr int BK = 16;
 // LDS row stride: tile rows + 2 for operands loaded k-contiguous (scalar transposing writes land on
 // distinct banks), + 4 for operands loaded mn-contiguous (16-byte aligned vector writes).
 
+// FM terms of the front end's backward, added to the first `cols` columns of the product (see ctr_fm_bwd_t)
+struct FmBwd {
+  int on, E, cols, eshift;   // eshift: log2(E) when E is a power of two, else -1
+  const float *g1, *g2, *s, *z;
+  int64_t g1_ld, g2_ld, z_ld;
+};
+
 struct Epi {
   const float* bias;
   int relu, accumulate;
@@ -23,6 +30,7 @@ struct Epi {
   const float* mask_src;
   int64_t mask_ld;
   float mask_scale;
+  FmBwd fm;
 };
 
 __device__ static inline float epilogue(const Epi& e, float v, int m, int n, int N, const float* cptr) {
@@ -32,6 +40,12 @@ __device__ static inline float epilogue(const Epi& e, float v, int m, int n, int
   else if (e.relu == 2) v = 1.f / (1.f + expf(-v));
   if (e.drop.on) v *= drop_mul(e.drop, (uint64_t)m * (uint64_t)N + (uint64_t)n);
   if (e.mask_src) v = e.mask_src[(int64_t)m * e.mask_ld + n] > 0.f ? v * e.mask_scale : 0.f;
+  if (e.fm.on && n < e.fm.cols) {
+    const int f = n / e.fm.E, c = n - f * e.fm.E;
+    if (e.fm.g1) v += e.fm.g1[(int64_t)m * e.fm.g1_ld + f];
+    if (e.fm.g2)
+      v = fmaf(e.fm.g2[(int64_t)m * e.fm.g2_ld + c], e.fm.s[(int64_t)m * e.fm.E + c] - e.fm.z[(int64_t)m * e.fm.z_ld + n], v);
+  }
   return v;
 }
 
@@ -121,8 +135,41 @@ __device__ static inline void tile_epilogue(f32x16 (&acc)[TM][TN], float* smem, 
   const bool vec_out = (ldo % 4 == 0) && ((uintptr_t)out % 16 == 0);
   const bool vec_mask = epi.mask_src && (epi.mask_ld % 4 == 0) && ((uintptr_t)epi.mask_src % 16 == 0);
   const int srow = lane >> 3, sc4 = (lane & 7) * 4;
+  // FM terms (ctr_fm_bwd_t): with E in {4, 8, 16, 32} every 32-column tile of a row sees the same columns of s and
+  // g_second, and all operands of a row of wave tiles are requested before the first tile is written (requested
+  // tile by tile, sixteen dependent round trips per block cost half as much as the product itself)
+  const bool fm_fast = epi.fm.on && !partial && epi.fm.eshift >= 2 && epi.fm.eshift <= 5;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i) {
+    float4 fz[TN][4], fs[4];
+    float fg1[TN][4], fg2[4][4];
+    if (fm_fast) {
+      const int nb = n0 + wn * (32 * TN) + sc4;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int m = m0 + wm * (32 * TM) + i * 32 + it * 8 + srow;
+        fs[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fg2[it][u] = 0.f;
+        if (m < M && nb < epi.fm.cols && epi.fm.g2) {
+          const int c = nb & (epi.fm.E - 1);
+          fs[it] = *reinterpret_cast<const float4*>(epi.fm.s + (int64_t)m * epi.fm.E + c);
+          const float* g2 = epi.fm.g2 + (int64_t)m * epi.fm.g2_ld + c;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) fg2[it][u] = g2[u];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = nb + j * 32;
+          fz[j][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+          fg1[j][it] = 0.f;
+          if (m < M && n < epi.fm.cols) {
+            if (epi.fm.g2) fz[j][it] = *reinterpret_cast<const float4*>(epi.fm.z + (int64_t)m * epi.fm.z_ld + n);
+            if (epi.fm.g1) fg1[j][it] = epi.fm.g1[(int64_t)m * epi.fm.g1_ld + (n >> epi.fm.eshift)];
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -172,6 +219,36 @@ __device__ static inline void tile_epilogue(f32x16 (&acc)[TM][TN], float* smem, 
             if (epi.mask_src) x = mk[u] > 0.f ? x * epi.mask_scale : 0.f;
             v[u] = x;
           }
+          if (epi.fm.on && n < epi.fm.cols) {   // cols % 4 == 0: the four columns belong to one row of Z
+            if (fm_fast) {
+              if (epi.fm.g1) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] += fg1[j][it];
+              }
+              if (epi.fm.g2) {
+                v[0] = fmaf(fg2[it][0], fs[it].x - fz[j][it].x, v[0]);
+                v[1] = fmaf(fg2[it][1], fs[it].y - fz[j][it].y, v[1]);
+                v[2] = fmaf(fg2[it][2], fs[it].z - fz[j][it].z, v[2]);
+                v[3] = fmaf(fg2[it][3], fs[it].w - fz[j][it].w, v[3]);
+              }
+            } else {
+              const int f = n / epi.fm.E, c = n - f * epi.fm.E;
+              if (epi.fm.g1) {
+                const float t = epi.fm.g1[(int64_t)m * epi.fm.g1_ld + f];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] += t;
+              }
+              if (epi.fm.g2) {
+                const float4 zz = *reinterpret_cast<const float4*>(epi.fm.z + (int64_t)m * epi.fm.z_ld + n);
+                const float4 ss = *reinterpret_cast<const float4*>(epi.fm.s + (int64_t)m * epi.fm.E + c);
+                const float* g2 = epi.fm.g2 + (int64_t)m * epi.fm.g2_ld + c;
+                v[0] = fmaf(g2[0], ss.x - zz.x, v[0]);
+                v[1] = fmaf(g2[1], ss.y - zz.y, v[1]);
+                v[2] = fmaf(g2[2], ss.z - zz.z, v[2]);
+                v[3] = fmaf(g2[3], ss.w - zz.w, v[3]);
+              }
+            }
+          }
         }
         if (full && vec_out) {
           *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -182,6 +259,7 @@ __device__ static inline void tile_epilogue(f32x16 (&acc)[TM][TN], float* smem, 
         }
       }
     }
+  }
 }
 
 // A_K: A stored [M,K] (k contiguous).  B_K: B stored [N,K] (k contiguous).
@@ -650,7 +728,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(int M, int N, int K, c
         if (n >= N) continue;
         float* cp = C + (int64_t)m * ldc + n;
         float v[4];
-        if (vec_mask && n + 3 < N && !epi.bias && !epi.accumulate && !epi.relu && !epi.drop.on) {
+        if (vec_mask && n + 3 < N && !epi.bias && !epi.accumulate && !epi.relu && !epi.drop.on && !epi.fm.on) {
           const float mv[4] = {mk[t].x, mk[t].y, mk[t].z, mk[t].w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = mv[r] > 0.f ? acc[rt][t][r] * epi.mask_scale : 0.f;
@@ -984,11 +1062,28 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
   Epi e;
   e.bias = nullptr; e.relu = 0; e.accumulate = 0; e.drop = make_drop(nullptr);
   e.mask_src = nullptr; e.mask_ld = 0; e.mask_scale = 1.f;
+  e.fm.on = 0; e.fm.E = e.fm.cols = 0; e.fm.eshift = -1;
+  e.fm.g1 = e.fm.g2 = e.fm.s = e.fm.z = nullptr; e.fm.g1_ld = e.fm.g2_ld = e.fm.z_ld = 0;
   if (epi) {
     e.bias = epi->bias; e.relu = epi->relu; e.accumulate = epi->accumulate;
     e.drop = make_drop(epi->dropout);
     e.mask_src = epi->mask_src; e.mask_ld = epi->mask_ld; e.mask_scale = epi->mask_scale;
     CTR_REQUIRE(!e.mask_src || e.mask_ld >= N, "ctr_gemm_f32: mask_ld too small");
+    if (epi->fm_bwd) {
+      const ctr_fm_bwd_t* q = epi->fm_bwd;
+      CTR_REQUIRE(q->n_rows > 0 && q->E > 0 && q->E % 4 == 0 && (int64_t)q->n_rows * q->E <= N,
+                  "ctr_gemm_f32: fm_bwd needs n_rows*E <= N and E %% 4 == 0");
+      CTR_REQUIRE(!q->g_first || q->g_first_ld >= q->n_rows, "ctr_gemm_f32: fm_bwd g_first_ld too small");
+      CTR_REQUIRE(!q->g_second || (q->g_second_ld >= q->E && q->s && q->z && q->z_ld >= (int64_t)q->n_rows * q->E &&
+                                   q->z_ld % 4 == 0 && ((uintptr_t)q->z % 16) == 0 && ((uintptr_t)q->s % 16) == 0),
+                  "ctr_gemm_f32: fm_bwd with g_second needs s and a 16-byte aligned z with z_ld %% 4 == 0");
+      e.fm.on = 1; e.fm.E = q->E; e.fm.cols = q->n_rows * q->E;
+      e.fm.eshift = -1;
+      for (int sh = 2; sh < 31; ++sh)
+        if ((1 << sh) == q->E) e.fm.eshift = sh;
+      e.fm.g1 = q->g_first; e.fm.g1_ld = q->g_first_ld; e.fm.g2 = q->g_second; e.fm.g2_ld = q->g_second_ld;
+      e.fm.s = q->s; e.fm.z = q->z; e.fm.z_ld = q->z_ld;
+    }
   }
   hipStream_t st = (hipStream_t)stream;
   // narrow tower layers: the whole B chunk in LDS, A streamed (see skinny_gemm_kernel)

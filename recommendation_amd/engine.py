@@ -326,12 +326,13 @@ class Tower:
         return self._chain
 
     def backward(self, x, acts, g_last, gbufs, rates, dx, ws, accumulate_dx=False, g_last_masked=False, side=None,
-                 ext=None):
+                 ext=None, dx_fm=None):
         """g_last: gradient w.r.t. acts[-1] (post relu+dropout); it is masked in place unless the caller
         already did (g_last_masked).
         gbufs[i]: scratch [B, L_i] for i < n-1.  dx (optional): [B, >= d_in] receives dL/dx
         (added to its content when accumulate_dx).  ext (optional): per layer, the layer's input as a [B, K+1] view
-        whose last column is ones (ones_padded), or None."""
+        whose last column is ones (ones_padded), or None.  dx_fm (optional): the fm_bwd argument of ops.gemm for the
+        product that writes dx (the FM terms of dZ added in its epilogue instead of by a pass over dx)."""
         n = len(self.names)
         scale = [1.0 / (1.0 - r) if r else 1.0 for r in rates]
         if not g_last_masked:
@@ -365,7 +366,8 @@ class Tower:
                              mask_scale=scale[i - 1], ws=ws)
                 gs[i - 1] = gbufs[i - 1]
             elif dx is not None:
-                ops.gemm(gs[0], self.dense.p(wn), dx[:, :self.d_in], trans_b=True, accumulate=accumulate_dx, ws=ws)
+                ops.gemm(gs[0], self.dense.p(wn), dx[:, :self.d_in], trans_b=True, accumulate=accumulate_dx,
+                         fm_bwd=dx_fm, ws=ws)
         # ... then the weight gradients: dW = h_in^T g, db.  With `side` (a Session) they go to its side stream
         # and overlap whatever the caller launches next; the caller joins before the dense optimizer.
         ctx = side.side_stream() if side is not None else contextlib.nullcontext()

@@ -12,7 +12,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import Dropout, Epilogue, Opt, check
+from ._lib import Dropout, Epilogue, FmBwd, Opt, check
 
 KEEP_ONE = 1 << 24
 
@@ -549,8 +549,10 @@ def get_gemm_mode():
 
 @_timed
 def gemm(A, B_, Cout, *, trans_a=False, trans_b=False, bias=None, relu=False, sigmoid=False, accumulate=False,
-         dropout=None, mask_src=None, mask_scale=1.0, ws=None):
-    """Cout[M,N] = epilogue(op(A) @ op(B_)); all three are 2-D views with contiguous last dim."""
+         dropout=None, mask_src=None, mask_scale=1.0, fm_bwd=None, ws=None):
+    """Cout[M,N] = epilogue(op(A) @ op(B_)); all three are 2-D views with contiguous last dim.
+    fm_bwd (optional): dict(N, E, g_first, g_second, s, z) - the FM terms of embed_bwd_dz are added to the first N*E
+    columns of the product on its way out (ctr_fm_bwd_t; g_first / g_second already carry their keep masks)."""
     M, N = Cout.shape
     ap, lda = _rows(A, 'A')
     bp, ldb = _rows(B_, 'B')
@@ -571,6 +573,15 @@ def gemm(A, B_, Cout, *, trans_a=False, trans_b=False, bias=None, relu=False, si
                    dropout=C.pointer(dropout) if dropout is not None else None,
                    mask_src=None if mask_src is None else mask_src.data_ptr(), mask_ld=mld,
                    mask_scale=float(mask_scale))
+    if fm_bwd is not None:
+        g1, g2 = fm_bwd.get('g_first'), fm_bwd.get('g_second')
+        g1p, g1ld = _rows(g1, 'g_first') if g1 is not None else (None, 0)
+        g2p, g2ld = _rows(g2, 'g_second') if g2 is not None else (None, 0)
+        zp, zld = _rows(fm_bwd['z'], 'z') if g2 is not None else (None, 0)
+        fm = FmBwd(g_first=g1p, g_first_ld=g1ld, g_second=g2p, g_second_ld=g2ld,
+                   s=_ptr(fm_bwd['s'], torch.float32) if g2 is not None else None, z=zp, z_ld=zld,
+                   n_rows=int(fm_bwd['N']), E=int(fm_bwd['E']))
+        epi.fm_bwd = C.pointer(fm)
     need = lib().ctr_gemm_f32_workspace_bytes(M, N, K)
     wp, wn = (None, 0)
     if need:
@@ -753,6 +764,17 @@ def dropout_apply(x, drop):
     rows, cols = x.shape
     xp, ld = _rows(x, 'x')
     check(lib().ctr_dropout_apply(xp, ld, rows, cols, C.byref(drop), _stream()), 'ctr_dropout_apply')
+
+
+@_timed
+def dropout_apply2(x, cols_a, drop_a, cols_b, drop_b):
+    """x[:, :cols_a] under drop_a and x[:, cols_a:cols_a + cols_b] under drop_b in one launch."""
+    if drop_a is None and drop_b is None:
+        return
+    xp, ld = _rows(x, 'x')
+    check(lib().ctr_dropout_apply2(xp, ld, x.shape[0], int(cols_a), C.byref(drop_a) if drop_a is not None else None,
+                                   int(cols_b), C.byref(drop_b) if drop_b is not None else None, _stream()),
+          'ctr_dropout_apply2')
 
 
 # ------------------------------------------------------------------ PNN / AFM interaction pieces

@@ -1,4 +1,6 @@
 """DeepFM on the HIP hot path; same class surface as the reference's DeepFM/DeepFM.py:5-131."""
+import os
+
 import torch
 
 from recommendation_amd import ops
@@ -17,6 +19,9 @@ class DeepFM(CTRModel):
         self.deep_layers = [int(v) for v in args.deep_layers]
         self.dropout_fm = float(args.dropout_fm)
         self.dropout_deep = float(args.dropout_deep)
+        # dZ's FM terms ride the epilogue of the product that forms the tower's dx0 (one pass over [B, N*E] less);
+        # CTR_FUSE_DZ=0 keeps the separate pass (the same bits either way)
+        self.fuse_dz = os.environ.get('CTR_FUSE_DZ', '1') != '0'
 
     def _dense_shapes(self, sh):
         n = len(self.deep_layers)
@@ -67,11 +72,16 @@ class DeepFM(CTRModel):
         wn, bn = 'output_unit/output_w_%d' % (n - 1), 'output_unit/output_b_%d' % (n - 1)
         # output unit backward + the last tower layer's relu/dropout mask in one pass over concat
         fused = unit_backward(self.dense, wn, bn, concat, dconcat, dl, ws, mask_from=N + E, rate=self.dropout_deep)
+        route = self._dz_route(B)
+        d1, d2 = self._drop(self.dropout_fm, 1, True), self._drop(self.dropout_fm, 2, True)
+        fm = dict(g_first=dconcat[:, :N], g_second=dconcat[:, N:N + E], s=bufs['s'], z=bufs['x0'])
+        fuse = self.fuse_dz and not route and E % 4 == 0     # a sharded front end wants dZ in its exchange layout
+        if fuse:
+            # the keep masks of the two FM dropouts go onto their gradients first; the product then needs no hashing
+            ops.dropout_apply2(dconcat[:, :N + E], N, d1, E, d2)
         self.tower.backward(bufs['x0'], bufs['acts'], dconcat[:, N + E:], bufs['gbufs'],
                             [self.dropout_deep] * n, bufs['dx0'], ws, g_last_masked=fused, side=self.session,
-                            ext=bufs['ext'])
-        ops.embed_bwd_dz(bufs['dx0'], B=B, N=N, E=E, gz=bufs['dx0'], g_first=dconcat[:, :N],
-                         g_second=dconcat[:, N:N + E], s=bufs['s'], z=bufs['x0'],
-                         drop_first=self._drop(self.dropout_fm, 1, True),
-                         drop_second=self._drop(self.dropout_fm, 2, True), **self._dz_route(B))
+                            ext=bufs['ext'], dx_fm=dict(fm, N=N, E=E) if fuse else None)
+        if not fuse:
+            ops.embed_bwd_dz(bufs['dx0'], B=B, N=N, E=E, gz=bufs['dx0'], drop_first=d1, drop_second=d2, **fm, **route)
         self._tables_backward(idx, bufs['dx0'], bufs, routed=True)

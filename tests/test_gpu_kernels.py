@@ -340,6 +340,63 @@ def test_gemm_epilogues(ops_ws):
     assert rel_err(C.cpu().numpy(), np.where(act > 0, (A.astype(np.float64) @ Bm) * 1.25, 0)) < 1e-5
 
 
+@pytest.mark.parametrize('M,K,N_rows,E,C', [
+    (4096, 256, 26, 16, 13),    # 128 x 128 tiles (N = 429: what the DeepFM step runs)
+    (2048, 64, 5, 8, 3),        # narrow product: the strip kernel's per-element epilogue
+    (130, 4096, 6, 4, 2),       # few rows under a long K: split-K slabs, epilogue in the reduction
+    (300, 45, 3, 12, 0),        # ragged tile edges, no continuous tail, E that does not divide 32
+    (700, 300, 9, 8, 5),        # several column tiles at E = 8
+])
+def test_gemm_fm_backward_epilogue_matches_the_separate_pass(ops_ws, M, K, N_rows, E, C):
+    """dx0 = g W^T with the FM terms of dZ added in the epilogue (ctr_fm_bwd_t) against the same product followed by
+    ctr_embed_bwd_dz over it (gradient of DeepFM/DeepFM.py:55-66): the same bits, dropout on and off, and the
+    columns of the continuous tail untouched by the FM terms."""
+    ops, ws = ops_ws
+    g = torch.Generator(device=DEV); g.manual_seed(M + K)
+    rnd = lambda *sh: torch.randn(*sh, device=DEV, generator=g)
+    D = N_rows * E + C
+    ld = (D + 1 + 3) // 4 * 4
+    gact, W = rnd(M, K), rnd(D, K) * 0.1
+    x0 = rnd(M, ld)
+    dcat = rnd(M, N_rows + E + 7)                    # g_first / g_second as unaligned column blocks of one buffer
+    g1, g2, s = dcat[:, :N_rows], dcat[:, N_rows:N_rows + E], rnd(M, E)
+    for rate in (0.0, 0.5):
+        d1 = ops.make_dropout(rate, seed=7, stream_id=1)
+        d2 = ops.make_dropout(rate, seed=7, stream_id=2)
+        sep = torch.full((M, ld), 0.25, device=DEV)
+        ops.gemm(gact, W, sep[:, :D], trans_b=True, ws=ws)
+        plain = sep.clone()
+        ops.embed_bwd_dz(sep, B=M, N=N_rows, E=E, gz=sep, g_first=g1, g_second=g2, s=s, z=x0, drop_first=d1,
+                         drop_second=d2)
+        # the epilogue takes the gradients with their keep masks already on them
+        kept = dcat.clone()
+        k1, k2 = kept[:, :N_rows], kept[:, N_rows:N_rows + E]
+        ops.dropout_apply2(kept[:, :N_rows + E], N_rows, d1, E, d2)
+        ref1, ref2 = g1.clone(), g2.clone()
+        ops.dropout_apply(ref1, d1)
+        ops.dropout_apply(ref2, d2)
+        assert torch.equal(k1, ref1) and torch.equal(k2, ref2) and torch.equal(kept[:, N_rows + E:], dcat[:, N_rows + E:])
+        fused = torch.full((M, ld), 0.25, device=DEV)
+        ops.gemm(gact, W, fused[:, :D], trans_b=True, ws=ws, fm_bwd=dict(N=N_rows, E=E, g_first=k1, g_second=k2, s=s, z=x0))
+        assert torch.equal(fused, sep)
+        assert torch.equal(fused[:, N_rows * E:], plain[:, N_rows * E:])
+        assert not torch.equal(fused[:, :N_rows * E], plain[:, :N_rows * E])
+        # each term alone
+        for kw, kwf in ((dict(g_first=g1), dict(g_first=k1)), (dict(g_second=g2, s=s, z=x0), dict(g_second=k2, s=s, z=x0))):
+            sep = plain.clone()
+            ops.embed_bwd_dz(sep, B=M, N=N_rows, E=E, gz=sep, drop_first=d1, drop_second=d2, **kw)
+            fused = torch.full((M, ld), 0.25, device=DEV)
+            ops.gemm(gact, W, fused[:, :D], trans_b=True, ws=ws, fm_bwd=dict(N=N_rows, E=E, **kwf))
+            assert torch.equal(fused, sep)
+    # float64 statement of the whole expression, dropout off
+    ref = gact.double() @ W.double().t()
+    zz = x0[:, :N_rows * E].double().view(M, N_rows, E)
+    ref[:, :N_rows * E] += (g1.double()[:, :, None] + g2.double()[:, None, :] * (s.double()[:, None, :] - zz)).reshape(M, -1)
+    out = torch.zeros(M, ld, device=DEV)
+    ops.gemm(gact, W, out[:, :D], trans_b=True, ws=ws, fm_bwd=dict(N=N_rows, E=E, g_first=g1, g_second=g2, s=s, z=x0))
+    assert_close(out[:, :D].cpu().numpy(), ref.cpu().numpy(), 1e-5, "dx0 + FM terms")
+
+
 def test_colsum_rowdot_loss(ops_ws):
     ops, ws = ops_ws
     rng = np.random.default_rng(6)
