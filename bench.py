@@ -349,6 +349,9 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
                                         us={n: round(v, 2) for n, v in us.items()},
                                         cold_copy_us={n: round(v, 2) for n, v in cold.items()},
                                         frac_of_cold_copy=sum(cold.values()) / tot_us)
+        if 'embed_bwd_dz' not in path and variant == 'DeepFM':
+            out['roofline_emb_path']['note'] = ('dZ (FM terms added to the tower gradient) has no launch of its own: it rides '
+                                                'the epilogue of the dx0 product (gemm_%dx%dx%d_NT)' % (B, D, 256))
     out['pmc_traffic_file'] = traffic.get('_file')
     out['unique_rows_per_step'] = uniq
     out['profile_steps'] = PROFILE_STEPS
