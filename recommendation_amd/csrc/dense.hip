@@ -326,13 +326,18 @@ __global__ __launch_bounds__(256) void unit_bwd_kernel(int B, int K, const float
                                                       const float* __restrict__ w, const float* __restrict__ X,
                                                       int64_t ldx, float* __restrict__ dX, int64_t lddx,
                                                       int mask_from, float mask_scale, int rows_per_block,
-                                                      float* __restrict__ part) {
+                                                      float* __restrict__ part, int keep_a_cols, Drop keep_a,
+                                                      int keep_b_cols, Drop keep_b) {
   __shared__ float red[256], dred[256];
   const int rps = 256 / K;                          // sample rows per step
   const int r = threadIdx.x / K, k = threadIdx.x - r * K;
   const bool on = r < rps;
   const float wv = on ? w[k] : 0.f;
   const bool masked = k >= mask_from;
+  // columns [0, keep_a_cols) and the keep_b_cols after them carry the keep masks of two dropouts (what
+  // ctr_dropout_apply2 would put on dX afterwards)
+  const bool in_a = keep_a.on && k < keep_a_cols;
+  const bool in_b = keep_b.on && k >= keep_a_cols && k < keep_a_cols + keep_b_cols;
   const int64_t b0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t b1 = b0 + rows_per_block < B ? b0 + rows_per_block : B;
   float acc = 0.f, dsum = 0.f;
@@ -353,6 +358,8 @@ __global__ __launch_bounds__(256) void unit_bwd_kernel(int B, int K, const float
         if (k == 0) dsum += d[u];
         float g = d[u] * wv;
         if (masked) g = x[u] > 0.f ? g * mask_scale : 0.f;
+        if (in_a) g *= drop_mul(keep_a, (uint64_t)bb * keep_a_cols + k);
+        else if (in_b) g *= drop_mul(keep_b, (uint64_t)bb * keep_b_cols + (k - keep_a_cols));
         if (bb < b1) dX[bb * lddx + k] = g;
       }
     }
@@ -471,6 +478,17 @@ extern "C" size_t ctr_unit_bwd_workspace_bytes(int B, int K) {
 extern "C" int ctr_unit_bwd(int B, int K, const float* dl, const float* w, const float* X, int64_t ldx, float* dX,
                             int64_t lddx, int mask_from, float mask_scale, float* dw, float* db, void* workspace,
                             size_t workspace_bytes, void* stream) {
+  return ctr_unit_bwd_keep(B, K, dl, w, X, ldx, dX, lddx, mask_from, mask_scale, 0, nullptr, 0, nullptr, dw, db,
+                           workspace, workspace_bytes, stream);
+}
+
+extern "C" int ctr_unit_bwd_keep(int B, int K, const float* dl, const float* w, const float* X, int64_t ldx, float* dX,
+                                 int64_t lddx, int mask_from, float mask_scale, int keep_a_cols,
+                                 const ctr_dropout_t* keep_a, int keep_b_cols, const ctr_dropout_t* keep_b, float* dw,
+                                 float* db, void* workspace, size_t workspace_bytes, void* stream) {
+  CTR_REQUIRE(keep_a_cols >= 0 && keep_b_cols >= 0 && keep_a_cols + keep_b_cols <= K,
+              "ctr_unit_bwd_keep: keep blocks wider than K");
+  const Drop ka = make_drop(keep_a), kb = make_drop(keep_b);
   CTR_REQUIRE(B > 0 && ctr_unit_bwd_supported(K), "ctr_unit_bwd: need B > 0 and 1 <= K <= %d", UB_KWIDE);
   CTR_REQUIRE(dl && w && X && dX && dw && workspace, "ctr_unit_bwd: null pointer");
   CTR_REQUIRE(ldx >= K && lddx >= K, "ctr_unit_bwd: leading dimension < K");
@@ -485,7 +503,7 @@ extern "C" int ctr_unit_bwd(int B, int K, const float* dl, const float* w, const
   const int rpb = unit_bwd_rows_per_block(B, K);
   if (K <= UB_KMAX) {
     hipLaunchKernelGGL(unit_bwd_kernel, dim3(nb), dim3(256), 0, st, B, K, dl, w, X, ldx, dX, lddx, mask_from, mask_scale,
-                       rpb, part);
+                       rpb, part, keep_a_cols, ka, keep_b_cols, kb);
   } else {
 #define UW(NC_)                                                                                                  \
   hipLaunchKernelGGL(unit_bwd_wide_kernel<NC_>, dim3(nb), dim3(256), 0, st, B, K, dl, w, X, ldx, dX, lddx, mask_from, \
@@ -496,6 +514,9 @@ extern "C" int ctr_unit_bwd(int B, int K, const float* dl, const float* w, const
   }
   hipLaunchKernelGGL(unit_bwd_final_kernel, dim3((unsigned)cdiv(K + 1, 64)), dim3(1024), 0, st, part, nb, K, dw, db);
   CTR_LAUNCH_CHECK();
+  // the wide kernel leaves the keep masks to a pass of their own
+  if (K > UB_KMAX && (ka.on || kb.on))
+    return ctr_dropout_apply2(dX, lddx, B, keep_a_cols, keep_a, keep_b_cols, keep_b, stream);
   return CTR_OK;
 }
 

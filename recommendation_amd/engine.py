@@ -412,18 +412,21 @@ class Tower:
         return self._bwd_chain
 
 
-def unit_backward(dense, wn, bn, x, dx, dl, ws, mask_from=-1, rate=0.0):
+def unit_backward(dense, wn, bn, x, dx, dl, ws, mask_from=-1, rate=0.0, keep=None):
     """Backward of an output unit y = x w + b: dx = dl w^T, dw, db.  Columns mask_from.. of x are the output of
     a tower's last relu (+ dropout at `rate`) layer; returns True when their mask was applied to dx here (one
-    fused pass), False when the caller (Tower.backward) still has to."""
+    fused pass), False when the caller (Tower.backward) still has to.  keep (optional): (cols_a, drop_a, cols_b,
+    drop_b), the keep masks of two dropouts for dx's leading column blocks (ops.unit_bwd)."""
     B, K = x.shape
     w = dense.p(wn).reshape(-1)
     if ops.unit_bwd_supported(K):
         scale = 1.0 / (1.0 - rate) if rate else 1.0
         ops.unit_bwd(dl, w, x, dx, dense.g(wn).reshape(-1), dense.g(bn).reshape(-1), mask_from=mask_from,
-                     mask_scale=scale, ws=ws)
+                     mask_scale=scale, keep=keep, ws=ws)
         return mask_from >= 0
     ops.rowdot_bwd_x(dl, w, dx)
+    if keep is not None:
+        ops.dropout_apply2(dx, *keep)
     ops.dense_wgrad(x, dl.view(B, 1), dense.g(wn), dense.g(bn), ws=ws)
     return False
 

@@ -70,15 +70,14 @@ class DeepFM(CTRModel):
         ws = self.session.ws
         concat, dconcat, dl = bufs['concat'], bufs['dconcat'], bufs['dlogit']
         wn, bn = 'output_unit/output_w_%d' % (n - 1), 'output_unit/output_b_%d' % (n - 1)
-        # output unit backward + the last tower layer's relu/dropout mask in one pass over concat
-        fused = unit_backward(self.dense, wn, bn, concat, dconcat, dl, ws, mask_from=N + E, rate=self.dropout_deep)
         route = self._dz_route(B)
         d1, d2 = self._drop(self.dropout_fm, 1, True), self._drop(self.dropout_fm, 2, True)
-        fm = dict(g_first=dconcat[:, :N], g_second=dconcat[:, N:N + E], s=bufs['s'], z=bufs['x0'])
         fuse = self.fuse_dz and not route and E % 4 == 0     # a sharded front end wants dZ in its exchange layout
-        if fuse:
-            # the keep masks of the two FM dropouts go onto their gradients first; the product then needs no hashing
-            ops.dropout_apply2(dconcat[:, :N + E], N, d1, E, d2)
+        # output unit backward + the last tower layer's relu/dropout mask in one pass over concat; when dZ's FM terms
+        # ride the dx0 product, the keep masks of the two FM dropouts go onto their gradients here as well
+        fused = unit_backward(self.dense, wn, bn, concat, dconcat, dl, ws, mask_from=N + E, rate=self.dropout_deep,
+                              keep=(N, d1, E, d2) if fuse and (d1 is not None or d2 is not None) else None)
+        fm = dict(g_first=dconcat[:, :N], g_second=dconcat[:, N:N + E], s=bufs['s'], z=bufs['x0'])
         self.tower.backward(bufs['x0'], bufs['acts'], dconcat[:, N + E:], bufs['gbufs'],
                             [self.dropout_deep] * n, bufs['dx0'], ws, g_last_masked=fused, side=self.session,
                             ext=bufs['ext'], dx_fm=dict(fm, N=N, E=E) if fuse else None)

@@ -142,6 +142,29 @@ def test_emb_sort_pairs_small_and_large_batches(ops_ws, B, rmode):
     assert np.array_equal(src.cpu().numpy().view(np.uint32), v[order])
 
 
+@pytest.mark.parametrize('B,F', [(9, 600), (5, 1100), (3000, 1), (700, 13)])
+def test_emb_sort_field_counts_around_the_builder_block(ops_ws, B, F):
+    """The pair builder walks (sample, field) by fixed steps of its block size and keeps the field offsets in LDS up to
+    1023 fields: more fields than threads of a block, more than the LDS table holds, and a single field."""
+    ops, ws = ops_ws
+    rng = np.random.default_rng(B * F)
+    cards = rng.integers(2, 40, F)
+    offs = np.zeros(F + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(cards)
+    total = int(offs[-1])
+    idx = np.stack([rng.integers(0, v, B) for v in cards], 1).astype(np.int32)
+    idx[B // 2, F // 2] = -3
+    ok = idx >= 0
+    k = np.where(ok, offs[:-1][None] + idx, total).reshape(-1).astype(np.uint32)
+    v = (np.arange(B, dtype=np.int64)[:, None] * F + np.arange(F, dtype=np.int64)[None]).reshape(-1).astype(np.uint32)
+    order = np.argsort(k, kind='stable')
+    keys = torch.zeros(B * F, dtype=torch.int32, device=DEV)
+    src = torch.zeros(B * F, dtype=torch.int32, device=DEV)
+    ops.emb_sort(dev(idx), dev(offs), N=F, total_rows=total, rmode=False, keys_out=keys, src_out=src, ws=ws)
+    assert np.array_equal(keys.cpu().numpy().view(np.uint32), k[order])
+    assert np.array_equal(src.cpu().numpy().view(np.uint32), v[order])
+
+
 @pytest.mark.parametrize('skew', [False, True])
 @pytest.mark.parametrize('E', [4, 16, 64])
 def test_sort_segment_reduce_matches_scatter_add(ops_ws, E, skew):
@@ -675,6 +698,29 @@ def test_fused_output_unit_backward(ops_ws, B, K, mask_from):
     assert (dxd[:, K:] == 7.0).all()
     assert rel_err(dw.cpu().numpy(), x.astype(np.float64).T @ dl) < 1e-5
     assert abs(float(db.item()) - float(dl.astype(np.float64).sum())) < 1e-6
+
+
+@pytest.mark.parametrize('B,K,ca,cb', [(3000, 74, 26, 16), (257, 40, 0, 8), (1000, 600, 26, 16)])
+def test_output_unit_backward_with_keep_masks(ops_ws, B, K, ca, cb):
+    """ctr_unit_bwd_keep == ctr_unit_bwd followed by ctr_dropout_apply2 on dX's leading column blocks, bit for bit
+    (narrow kernel: masks inside the pass; wide kernel: the pass of their own), dw / db untouched by the masks."""
+    ops, ws = ops_ws
+    g = torch.Generator(device=DEV); g.manual_seed(B + K)
+    x = torch.randn(B, K, device=DEV, generator=g)
+    dl = torch.randn(B, device=DEV, generator=g)
+    w = torch.randn(K, device=DEV, generator=g)
+    da = ops.make_dropout(0.5, seed=3, stream_id=1) if ca else None
+    db = ops.make_dropout(0.3, seed=3, stream_id=2)
+    out = []
+    for keep in (None, (ca, da, cb, db)):
+        dx = torch.zeros(B, K, device=DEV)
+        dw, dbias = torch.zeros(K, device=DEV), torch.zeros(1, device=DEV)
+        ops.unit_bwd(dl, w, x, dx, dw, dbias, mask_from=ca + cb, mask_scale=1.25, keep=keep, ws=ws)
+        out.append((dx, dw, dbias))
+    ref = out[0][0].clone()
+    ops.dropout_apply2(ref[:, :ca + cb], ca, da, cb, db)
+    assert torch.equal(out[1][0], ref) and not torch.equal(out[1][0], out[0][0])
+    assert torch.equal(out[1][1], out[0][1]) and torch.equal(out[1][2], out[0][2])
 
 
 @pytest.mark.parametrize('M,widths,offset', [(1000, (32, 64, 128), 0), (77, (16, 32, 64), 3), (4099, (32, 64, 128), 2),
