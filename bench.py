@@ -314,6 +314,26 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
                     traffic=None, avg_us=k['avg_us'])
 
     out['roofline'] = roof_of(dom_name)
+    if variant == 'DeepFM' and world == 1 and getattr(model, 'fuse_dz', False) and dom_name.startswith('gemm_%dx%dx' % (B, D)):
+        # the dominant launch is the dx0 product WITH dZ's FM terms in its epilogue (the 65 us dZ pass it replaced has
+        # no launch any more): its duration covers both, its flops only the product.  The same product without the
+        # epilogue, on the same buffers, timed here for the matrix-core fraction of the product by itself.
+        bufs = model._buffers(B)
+        g0, w0 = bufs['gbufs'][0], model.dense.p('deep_part/deep_w_0')
+        scratch = torch.empty_like(bufs['dx0'])
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(42)]
+        for i in range(21):
+            evs[2 * i].record()
+            ops.gemm(g0, w0, scratch[:, :D], trans_b=True, ws=sess.ws)
+            evs[2 * i + 1].record()
+        torch.cuda.synchronize()
+        plain_us = 1e3 * float(np.mean([evs[2 * i].elapsed_time(evs[2 * i + 1]) for i in range(1, 21)]))
+        r = out['roofline']
+        r['kernel'] += ' + dZ epilogue (FM terms of the embedding backward: 124 MB of operand reads, no launch of its own)'
+        r['product_alone'] = dict(avg_us=plain_us, achieved=2.0 * B * D * w0.shape[1] / (plain_us * 1e-6) / 1e12,
+                                  frac=2.0 * B * D * w0.shape[1] / (plain_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                  note='same product, same buffers, epilogue off, timed after the run')
+        del scratch
     out['roofline_emb'] = roof_of('embed_fwd') if 'embed_fwd' in ks else None
     out['roofline_emb_bwd'] = roof_of('emb_sparse_apply') if 'emb_sparse_apply' in ks else None
     if out['roofline_emb_bwd'] and 'emb_sparse_apply' in profile:
