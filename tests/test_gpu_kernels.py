@@ -27,7 +27,8 @@ def ops_ws(sess):
 
 @pytest.mark.parametrize('n,bits', [(1, 3), (63, 8), (64, 9), (4097, 17), (200000, 26), (70001, 32), (300000, 2),
                                     (5000, 2), (8192, 26), (8193, 26), (777, 32),
-                                    (50000, 19), (100000, 20), (4097, 10), (30000, 30), (6000, 28)])   # 10-bit digits
+                                    (50000, 19), (100000, 20), (4097, 10), (30000, 30), (6000, 28),   # 10-bit digits
+                                    (4300000, 27), (65537, 18), (4194304, 9)])   # several thousand tiles: the scan walks its tile ranges in a loop
 def test_sort_pairs_stable_exact(ops_ws, n, bits):
     ops, ws = ops_ws
     rng = np.random.default_rng(n + bits)
