@@ -35,7 +35,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak; the split GEMM spends 6 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: 65536 DeepFM, 8192 DCN)')
     ap.add_argument('--no-bf16-leg', action='store_true', help='skip the extra timing of the reduced-precision GEMM mode')
