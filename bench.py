@@ -7,7 +7,7 @@ the Criteo-1TB per-GPU share beside it).
 
 A "step" is one pass of the hot path (embedding gather + FM + tower forward, loss, backward,
 sorted segment-reduce + sparse Adam, dense Adam) over one batch that already sits in HBM.
-Rank 0 prints ONE JSON line (see README/DESIGN for the fields).
+Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
