@@ -85,6 +85,24 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict
   if (lane == 0) out[b] = acc + (bias ? bias[0] : 0.f);
 }
 
+// The same for rows of a few hundred floats at most: a row per 16 lanes (four rows per wave instead of one wave per
+// row, whose lanes past K / 64 * 64 idle), the sum inside the 16-lane row on the data-parallel path.
+__global__ __launch_bounds__(256) void rowdot_fwd_r16_kernel(const float* __restrict__ X, int64_t ld,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ bias, int B, int K,
+                                                            float* __restrict__ out) {
+  const int l16 = threadIdx.x & 15;
+  const int64_t b = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int64_t bc = b < B ? b : (int64_t)B - 1;       // every lane takes part in the row sums
+  float acc = 0.f;
+  for (int k = l16; k < K; k += 16) acc += X[bc * ld + k] * w[k];
+  acc = dpp_add<DPP_XOR1>(acc);
+  acc = dpp_add<DPP_XOR2>(acc);
+  acc = dpp_add<DPP_ROR + 4>(acc);
+  acc = dpp_add<DPP_ROR + 8>(acc);
+  if (l16 == 0 && b < B) out[b] = acc + (bias ? bias[0] : 0.f);
+}
+
 __global__ __launch_bounds__(256) void rowdot_bwd_x_kernel(const float* __restrict__ g,
                                                           const float* __restrict__ w, int B, int K,
                                                           float* __restrict__ dX, int64_t ld, int accumulate) {
@@ -293,8 +311,12 @@ extern "C" int ctr_rowdot_fwd(const float* X, int64_t ld, const float* w, const 
   CTR_REQUIRE(B >= 0 && K >= 0, "ctr_rowdot_fwd: bad size");
   if (B == 0) return CTR_OK;
   CTR_REQUIRE(X && w && out, "ctr_rowdot_fwd: null pointer");
-  hipLaunchKernelGGL(rowdot_fwd_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, X, ld,
-                     w, bias, B, K, out);
+  if (K <= 512)
+    hipLaunchKernelGGL(rowdot_fwd_r16_kernel, dim3((unsigned)cdiv(B, 16)), dim3(256), 0, (hipStream_t)stream, X, ld,
+                       w, bias, B, K, out);
+  else
+    hipLaunchKernelGGL(rowdot_fwd_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, X, ld,
+                       w, bias, B, K, out);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
