@@ -232,6 +232,34 @@ def test_graph_replayed_training_matches_eager(sess, name, mode):
         assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
 
 
+@pytest.mark.parametrize('variant', ['tiny', 'criteo_like'])
+def test_deepfm_dz_in_the_gemm_epilogue_leaves_the_same_bits(sess, variant):
+    """DeepFM training steps with dZ's FM terms added in the epilogue of the dx0 product (the default on one process)
+    and with the separate ctr_embed_bwd_dz pass (what sharded tables use): same losses, same weights, bit for bit,
+    dropout on (gradient of DeepFM/DeepFM.py:55-66)."""
+    outs = []
+    for fuse in (True, False):
+        if variant == 'tiny':
+            cfg = tiny_cfg('DeepFM', 'S')
+            B = 48
+        else:
+            cfg = _criteo_like_cfg('DeepFM', 'DeepFM')
+            cfg.dropout_fm, cfg.dropout_deep = 0.5, 0.2      # the reference's rates (DeepFM/main.py:55-56)
+            B = 300
+        cfg.adam_mode = 'tf1'
+        P = O.init_params('DeepFM', cfg, seed=21, std=0.3 if variant == 'tiny' else 0.05)
+        m = _build(sess, 'DeepFM', cfg, P)
+        m.fuse_dz = fuse
+        losses = []
+        for step in range(4):
+            Xc, Xf, y = tiny_batch(cfg, B=B, seed=step)
+            losses.append(float(m.train_step(*m._upload(Xc, Xf, y)).item()))
+        outs.append((losses, m.get_params()))
+    assert outs[0][0] == outs[1][0]
+    for k in outs[0][1]:
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+
+
 @pytest.mark.gpu
 def test_graph_replay_survives_workspace_growth(sess):
     """Train graph captured at a small batch, then a much larger evaluation batch makes the scratch workspace
