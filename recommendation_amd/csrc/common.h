@@ -81,6 +81,14 @@ __device__ static inline float drop_mul(const Drop& d, uint64_t index) {
   return hash24(d.seed + (d.seed_add ? *d.seed_add : 0ull), d.stream_id, index) < d.thr ? d.scale : 0.f;
 }
 
+// The descriptor with the device word already added to its seed.  A kernel that draws many masks calls this once on
+// its by-value copy: inside drop_mul the word is a load the compiler must repeat after every store that might alias it.
+__device__ static inline Drop resolve_drop(Drop d) {
+  if (d.on && d.seed_add) d.seed += *d.seed_add;
+  d.seed_add = nullptr;
+  return d;
+}
+
 // x + (x of the lane CTRL names inside this lane's row of 16), on the VALU's data-parallel path (no LDS)
 template <int CTRL>
 __device__ static inline float dpp_add(float x) {

@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ s
 
 __global__ __launch_bounds__(256) void dropout_apply_kernel(float* __restrict__ x, int64_t ld, int rows,
                                                            int cols, Drop d) {
+  d = resolve_drop(d);
   const int64_t total = (int64_t)rows * cols;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total;
        p += (int64_t)gridDim.x * blockDim.x) {
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(float* __restrict__ 
 // column of a thread are a shift and a mask.
 __global__ __launch_bounds__(256) void dropout_apply2_kernel(float* __restrict__ x, int64_t ld, int rows, int cols_a,
                                                             Drop da, int cols_b, Drop db, int LW) {
+  da = resolve_drop(da); db = resolve_drop(db);
   const int c = threadIdx.x & ((1 << LW) - 1);
   const int rstep = 256 >> LW;
   if (c >= cols_a + cols_b) return;
@@ -350,6 +352,7 @@ __global__ __launch_bounds__(256) void unit_bwd_kernel(int B, int K, const float
                                                       int mask_from, float mask_scale, int rows_per_block,
                                                       float* __restrict__ part, int keep_a_cols, Drop keep_a,
                                                       int keep_b_cols, Drop keep_b) {
+  keep_a = resolve_drop(keep_a); keep_b = resolve_drop(keep_b);
   __shared__ float red[256], dred[256];
   const int rps = 256 / K;                          // sample rows per step
   const int r = threadIdx.x / K, k = threadIdx.x - r * K;

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
     float* __restrict__ second_out, int64_t second_ld, Drop d_first, Drop d_second,
     int32_t* __restrict__ oor_count, const float* __restrict__ blk, const int64_t* __restrict__ fbase,
     const int64_t* __restrict__ fstride) {
+  d_first = resolve_drop(d_first); d_second = resolve_drop(d_second);
   constexpr int SLOTS = 16 / G;
   constexpr int CH = 8;
   extern __shared__ int64_t offs_lds[];                     // [F + 1] first row of every field (gather path only)
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(256) void embed_fwd_lean_kernel(
     float* __restrict__ first_out, int64_t first_ld, float* __restrict__ s_out,
     float* __restrict__ second_out, int64_t second_ld, Drop d_first, Drop d_second,
     int32_t* __restrict__ oor_count) {
+  d_first = resolve_drop(d_first); d_second = resolve_drop(d_second);
   constexpr int SLOTS = 16 / G, CH = 4, E = 4 * G;
   extern __shared__ int64_t offs_lds[];                     // [F + 1] first row of every field
   for (int f = threadIdx.x; f <= F; f += 256) offs_lds[f] = row_offset[f];
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(256) void embed_fwd_wide_kernel(
     float* __restrict__ second_out, int64_t second_ld, Drop d_first, Drop d_second,
     int32_t* __restrict__ oor_count, const float* __restrict__ blk, const int64_t* __restrict__ fbase,
     const int64_t* __restrict__ fstride) {
+  d_first = resolve_drop(d_first); d_second = resolve_drop(d_second);
   constexpr int R = 64 / G;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -362,6 +365,7 @@ __global__ __launch_bounds__(256) void embed_bwd_dz_kernel(
     const float* __restrict__ z, int64_t z_ld, const float* __restrict__ g_sum, int B, int N, int E,
     Drop d_first, Drop d_second, float* dz, int64_t dz_ld, float* __restrict__ blk, const int64_t* __restrict__ fbase,
     const int64_t* __restrict__ fstride, int F) {
+  d_first = resolve_drop(d_first); d_second = resolve_drop(d_second);
   const int G = E / 4;
   const int64_t total = (int64_t)B * N * G;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total;

@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(int M, int N, int K, c
                                                       int64_t ldb, bool vecB, float* __restrict__ C,
                                                       int64_t ldc, Epi epi, int k_chunk,
                                                       float* __restrict__ partial) {
+  epi.drop = resolve_drop(epi.drop);
   constexpr int WGN = 4 / WGM;
   constexpr int TM = TBM / WGM / 32, TN = TBN / WGN / 32;
   constexpr int SA = A_K ? TBM + 2 : TBM + 4;
@@ -443,6 +444,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_split_kernel(int M, int N, in
                                                            int64_t ldb, bool vecB, float* __restrict__ C,
                                                            int64_t ldc, Epi epi, int k_chunk,
                                                            float* __restrict__ partial) {
+  epi.drop = resolve_drop(epi.drop);
   constexpr int NT = 64 * NW;                            // threads: NW waves, each a 64 x 64 output tile
   constexpr int WGN = NW / WGM;
   constexpr int TM = TBM / WGM / 32, TN = TBN / WGN / 32;
@@ -637,6 +639,7 @@ template <int NT, bool B_K>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(int M, int N, int K, const float* __restrict__ A,
                                                          int64_t lda, const float* __restrict__ Bm, int64_t ldb,
                                                          float* __restrict__ C, int64_t ldc, Epi epi) {
+  epi.drop = resolve_drop(epi.drop);
   extern __shared__ float Ws[];  // [K][SN]
   constexpr int NC = 16 * NT, SN = NC + 4;
   const int n0 = blockIdx.y * NC;
@@ -751,6 +754,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(int M, int N, int K, c
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splits,
                                                            int M, int N, float* __restrict__ C, int64_t ldc,
                                                            Epi epi) {
+  epi.drop = resolve_drop(epi.drop);
   const int64_t total = (int64_t)M * N;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total;
        p += (int64_t)gridDim.x * blockDim.x) {

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(512) void mlp_chain_fwd_kernel(int M, int K0, const
                                                            Drop d1, Drop d2, Drop d3, float* __restrict__ H1, int64_t ld1,
                                                            float* __restrict__ H2, int64_t ld2, float* __restrict__ H3,
                                                            int64_t ld3, int last_scalar) {
+  d1 = resolve_drop(d1); d2 = resolve_drop(d2); d3 = resolve_drop(d3);
   extern __shared__ float Ws[];  // W1 as [K0][N1 + 4]
   constexpr int N1 = 16 * NT1, N2 = 16 * NT2, N3 = 16 * NT3, SN = N1 + 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
