@@ -121,7 +121,9 @@ __device__ static inline void tile_store(float* __restrict__ S, int t, const flo
 // row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).  Each 32 x 32 tile goes through a per-wave LDS tile and
 // leaves as 16-byte stores (8 rows x 128 bytes per wave instruction): a quarter of the store
 // instructions of the register layout.  smem must hold 4 * 32 * 36 floats and no longer be in use.
-template <int TM, int TN>
+// PRE: the operands of the mask and FM epilogues are requested a row of wave tiles at a time (registers the
+// 128-register fp32-MFMA kernel does not have: it fetches them where they are used).
+template <int TM, int TN, bool PRE>
 __device__ static inline void tile_epilogue(f32x16 (&acc)[TM][TN], float* smem, int M, int N, int m0, int n0, int wm,
                                             int wn, float* __restrict__ C, int64_t ldc, const Epi& epi,
                                             float* __restrict__ partial) {
@@ -138,7 +140,15 @@ __device__ static inline void tile_epilogue(f32x16 (&acc)[TM][TN], float* smem, 
   // FM terms (ctr_fm_bwd_t): with E in {4, 8, 16, 32} every 32-column tile of a row sees the same columns of s and
   // g_second, and all operands of a row of wave tiles are requested before the first tile is written (requested
   // tile by tile, sixteen dependent round trips per block cost half as much as the product itself)
-  const bool fm_fast = epi.fm.on && !partial && epi.fm.eshift >= 2 && epi.fm.eshift <= 5;
+  const bool fm_fast = PRE && epi.fm.on && !partial && epi.fm.eshift >= 2 && epi.fm.eshift <= 5;
+  // a lane's four bias values depend on its column tile only: fetched once, not once per row group
+  float bias4[TN][4];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (32 * TN) + j * 32 + sc4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bias4[j][u] = (epi.bias && !partial && n + u < N) ? epi.bias[n + u] : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     float4 fz[TN][4], fs[4];
@@ -167,6 +177,22 @@ __device__ static inline void tile_epilogue(f32x16 (&acc)[TM][TN], float* smem, 
             if (epi.fm.g2) fz[j][it] = *reinterpret_cast<const float4*>(epi.fm.z + (int64_t)m * epi.fm.z_ld + n);
             if (epi.fm.g1) fg1[j][it] = epi.fm.g1[(int64_t)m * epi.fm.g1_ld + (n >> epi.fm.eshift)];
           }
+        }
+      }
+    }
+    // relu / dropout-backward masks of the whole row of wave tiles, requested together (one round trip instead of
+    // one per row group of every tile)
+    float4 mkv[TN][4];
+    const bool mk_pre = PRE && epi.mask_src && !partial && vec_mask;
+    if (mk_pre) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int m = m0 + wm * (32 * TM) + i * 32 + it * 8 + srow;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * (32 * TN) + j * 32 + sc4;
+          mkv[j][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (m < M && n + 3 < N) mkv[j][it] = *reinterpret_cast<const float4*>(epi.mask_src + (int64_t)m * epi.mask_ld + n);
         }
       }
     }
@@ -199,7 +225,7 @@ __device__ static inline void tile_epilogue(f32x16 (&acc)[TM][TN], float* smem, 
           if (epi.mask_src) {
             const float* mp = epi.mask_src + (int64_t)m * epi.mask_ld + n;
             if (full && vec_mask) {
-              const float4 m4 = *reinterpret_cast<const float4*>(mp);
+              const float4 m4 = PRE ? mkv[j][it] : *reinterpret_cast<const float4*>(mp);
               mk[0] = m4.x; mk[1] = m4.y; mk[2] = m4.z; mk[3] = m4.w;
             } else {
 #pragma unroll
@@ -211,7 +237,7 @@ __device__ static inline void tile_epilogue(f32x16 (&acc)[TM][TN], float* smem, 
           for (int u = 0; u < 4; ++u) {
             if (n + u >= N) break;
             float x = v[u];
-            if (epi.bias) x += epi.bias[n + u];
+            if (epi.bias) x += bias4[j][u];
             if (epi.accumulate) x += cold[u];
             if (epi.relu == 1) x = fmaxf(x, 0.f);
             else if (epi.relu == 2) x = 1.f / (1.f + expf(-x));
@@ -361,7 +387,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(int M, int N, int K, c
     }
   }
 
-  tile_epilogue<TM, TN>(acc, smem, M, N, m0, n0, wm, wn, C, ldc, epi, partial);
+  tile_epilogue<TM, TN, false>(acc, smem, M, N, m0, n0, wm, wn, C, ldc, epi, partial);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -621,7 +647,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_split_kernel(int M, int N, in
   } else {
     multiply(S0, no{}, S1, xa, xb);
   }
-  tile_epilogue<TM, TN>(acc, reinterpret_cast<float*>(smem_raw), M, N, m0, n0, wm, wn, C, ldc, epi, partial);
+  tile_epilogue<TM, TN, true>(acc, reinterpret_cast<float*>(smem_raw), M, N, m0, n0, wm, wn, C, ldc, epi, partial);
 }
 
 // ---------------------------------------------------------------------------------------

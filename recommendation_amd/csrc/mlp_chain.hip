@@ -13,11 +13,12 @@ namespace ctr {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-__device__ static inline f32x4 act4(f32x4 v, const float* __restrict__ bias, int n, const Drop& d, int64_t m, int N) {
+// bias: the lane's four bias values (columns n .. n + 3), fetched once per kernel
+__device__ static inline f32x4 act4(f32x4 v, f32x4 bias, int n, const Drop& d, int64_t m, int N) {
   f32x4 o;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    float x = fmaxf(v[r] + bias[n + r], 0.f);
+    float x = fmaxf(v[r] + bias[r], 0.f);
     if (d.on) x *= drop_mul(d, (uint64_t)m * (uint64_t)N + (uint64_t)(n + r));
     o[r] = x;
   }
@@ -52,6 +53,13 @@ __global__ __launch_bounds__(512) void mlp_chain_fwd_kernel(int M, int K0, const
   __syncthreads();
   const int strips = (M + 15) / 16;
   const int ksteps = K0 / 16;
+  f32x4 b1v[NT1], b2v[NT2], b3v[NT3 > 0 ? NT3 : 1];
+#pragma unroll
+  for (int t = 0; t < NT1; ++t) b1v[t] = f32x4{b1[16 * t + 4 * kq], b1[16 * t + 4 * kq + 1], b1[16 * t + 4 * kq + 2], b1[16 * t + 4 * kq + 3]};
+#pragma unroll
+  for (int t = 0; t < NT2; ++t) b2v[t] = f32x4{b2[16 * t + 4 * kq], b2[16 * t + 4 * kq + 1], b2[16 * t + 4 * kq + 2], b2[16 * t + 4 * kq + 3]};
+#pragma unroll
+  for (int t = 0; t < NT3; ++t) b3v[t] = f32x4{b3[16 * t + 4 * kq], b3[16 * t + 4 * kq + 1], b3[16 * t + 4 * kq + 2], b3[16 * t + 4 * kq + 3]};
   for (int strip = blockIdx.x * 8 + wave; strip < strips; strip += gridDim.x * 8) {
     const int r0 = strip * 16;
     const int64_t m = r0 + l16;
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(512) void mlp_chain_fwd_kernel(int M, int K0, const
 #pragma unroll
     for (int t = 0; t < NT1; ++t) {
       const int n = 16 * t + 4 * kq;
-      acc1[t] = act4(acc1[t], b1, n, d1, m, N1);
+      acc1[t] = act4(acc1[t], b1v[t], n, d1, m, N1);
       if (live) *reinterpret_cast<f32x4*>(H1 + m * ld1 + n) = acc1[t];
     }
     // ---- layer 2: input = acc1 (k-step t of this layer is accumulator tile t of the last), W2 from L2
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(512) void mlp_chain_fwd_kernel(int M, int K0, const
 #pragma unroll
     for (int t = 0; t < NT2; ++t) {
       const int n = 16 * t + 4 * kq;
-      acc2[t] = act4(acc2[t], b2, n, d2, m, N2);
+      acc2[t] = act4(acc2[t], b2v[t], n, d2, m, N2);
       if (live) store4(H2 + m * ld2 + n, acc2[t], NT3 == 0 && last_scalar);
     }
     // ---- layer 3
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(512) void mlp_chain_fwd_kernel(int M, int K0, const
 #pragma unroll
       for (int t = 0; t < NT3; ++t) {
         const int n = 16 * t + 4 * kq;
-        const f32x4 o = act4(acc3[t], b3, n, d3, m, N3);
+        const f32x4 o = act4(acc3[t], b3v[t], n, d3, m, N3);
         if (live) store4(H3 + m * ld3 + n, o, last_scalar);
       }
     }
