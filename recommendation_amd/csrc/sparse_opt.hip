@@ -13,6 +13,14 @@ struct Opt {
   __device__ float LR() const { return lr_dev ? *lr_dev : lr; }
 };
 
+// The descriptor with the device step size already read.  A kernel calls this once on its by-value copy: inside the
+// update formulas the word is a load the compiler must repeat after every store that might alias it.
+__device__ static inline Opt resolve_opt(Opt o) {
+  o.lr = o.LR();
+  o.lr_dev = nullptr;
+  return o;
+}
+
 __device__ static inline void ftrl1(const Opt& o, float g, float& w, float& n, float& z) {
   const float nn = n + g * g;
   z += g - (sqrtf(nn) - sqrtf(n)) / o.LR() * w;
@@ -79,6 +87,7 @@ __global__ __launch_bounds__(256) void sparse_apply_kernel(
     int64_t total_rows, const float* __restrict__ dz, int64_t dz_ld, const float* __restrict__ src_scale,
     float* __restrict__ tables, float* __restrict__ slot0, float* __restrict__ slot1, Opt opt,
     float* __restrict__ part, float* __restrict__ part_head, uint32_t* __restrict__ head_key) {
+  opt = resolve_opt(opt);
   constexpr int R = 64 / G;        // pairs per round
   constexpr int ROUNDS = SEG / R;  // = G
   constexpr int BATCH = ROUNDS < 4 ? ROUNDS : 4;
@@ -206,6 +215,7 @@ __global__ __launch_bounds__(256) void sparse_apply_lean_kernel(
     int64_t total_rows, const float* __restrict__ dz, int64_t dz_ld, const float* __restrict__ src_scale,
     float* __restrict__ tables, float* __restrict__ slot0, float* __restrict__ slot1, Opt opt,
     float* __restrict__ part, float* __restrict__ part_head, uint32_t* __restrict__ head_key) {
+  opt = resolve_opt(opt);
   constexpr int R = 64 / G, IPG = G, E = 4 * G;
   const int lane = threadIdx.x & 63;
   const int g = lane % G, q = lane / G;
@@ -324,6 +334,7 @@ __global__ __launch_bounds__(256) void sparse_apply_tail_kernel(
     float* __restrict__ tables, float* __restrict__ slot0, float* __restrict__ slot1, Opt opt,
     const float* __restrict__ part, const float* __restrict__ part_head,
     const uint32_t* __restrict__ head_key) {
+  opt = resolve_opt(opt);
   constexpr int R = 64 / G;
   constexpr int TU = 8;
   const int lane = threadIdx.x & 63;
@@ -379,6 +390,7 @@ __global__ __launch_bounds__(256) void sparse_apply_tail_kernel(
 __global__ __launch_bounds__(256) void dense_update_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                           float* __restrict__ s0, float* __restrict__ s1,
                                                           int64_t n, Opt o) {
+  o = resolve_opt(o);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i];
