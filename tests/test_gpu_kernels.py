@@ -701,6 +701,25 @@ def test_fused_output_unit_backward(ops_ws, B, K, mask_from):
     assert abs(float(db.item()) - float(dl.astype(np.float64).sum())) < 1e-6
 
 
+@pytest.mark.parametrize('rows,ca,cb,extra', [(777, 26, 16, 5), (50, 200, 100, 0), (300, 1, 3, 2), (64, 0, 40, 1)])
+def test_dropout_apply2_matches_two_single_block_passes(ops_ws, rows, ca, cb, extra):
+    """Two neighbouring column blocks under their own dropouts in one launch (wide blocks: one launch each) against
+    ctr_dropout_apply per block; columns past the blocks untouched; a missing descriptor leaves its block alone."""
+    ops, ws = ops_ws
+    g = torch.Generator(device=DEV); g.manual_seed(rows + ca)
+    x = torch.randn(rows, ca + cb + extra, device=DEV, generator=g)
+    da, db = ops.make_dropout(0.4, seed=11, stream_id=3), ops.make_dropout(0.25, seed=11, stream_id=4)
+    for a, b in ((da, db), (None, db), (da, None)):
+        ref = x.clone()
+        if a is not None and ca:
+            ops.dropout_apply(ref[:, :ca], a)
+        if b is not None:
+            ops.dropout_apply(ref[:, ca:ca + cb], b)
+        out = x.clone()
+        ops.dropout_apply2(out[:, :ca + cb], ca, a, cb, b)
+        assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize('B,K,ca,cb', [(3000, 74, 26, 16), (257, 40, 0, 8), (1000, 600, 26, 16)])
 def test_output_unit_backward_with_keep_masks(ops_ws, B, K, ca, cb):
     """ctr_unit_bwd_keep == ctr_unit_bwd followed by ctr_dropout_apply2 on dX's leading column blocks, bit for bit
