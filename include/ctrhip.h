@@ -514,12 +514,15 @@ int ctr_auc(const float* score, const float* label, int64_t n, float* auc_out, f
  * hottest row of every field, often the same small id, from landing on one rank).
  *   ctr_shard_route   per lookup p = b*F + f: dest[p] = owner rank, lkey[p] = row inside the owner's
  *                     concatenated shard (local_offset[W,F] int32 = first local row of each field on
- *                     each rank); an id outside [0, V_f) gets key -1 (zero row) on rank f mod W.
+ *                     each rank); an id outside [0, V_f) gets key -1 (zero row) on rank f mod W and is
+ *                     added to oor_count (optional device int32) on the rank whose batch holds it.
  *   ctr_shard_bucket  fixed-capacity send buckets from the lookups stably sorted by destination
  *                     (dest_sorted, perm): lookup number r of destination d fills slot d*cap + r with
  *                     slot_key = lkey[perm] and slot_perm = perm; unfilled slots hold -1 / 0xFFFFFFFF;
  *                     lookups beyond a bucket's capacity are dropped and counted in overflow_count
- *                     (a device int32 the caller zeroes and checks).  Every split of the exchange is
+ *                     (a device int32 the caller zeroes and checks); with z_zero (optional, the [B, z_ld]
+ *                     activation buffer the rows will be scattered into, F rows of E floats per sample)
+ *                     the row of a dropped lookup is zeroed there.  Every split of the exchange is
  *                     then `cap` entries: no count exchange and no host synchronisation.  W <= 64.
  *   ctr_rows_gather   out[s, 0:E] = src[b, f*E:(f+1)*E], (b, f) = divmod(perm[s], F): packs rows of the
  *                     strided [B, ld] layout in send order (32-bit words of any type; E = 1 packs ids);
@@ -527,9 +530,10 @@ int ctr_auc(const float* score, const float* label, int64_t n, float* auc_out, f
  *   ctr_rows_scatter  the inverse: dst[b, f*E:(f+1)*E] = rows[s, 0:E]; empty slots are skipped.
  * ---------------------------------------------------------------------------------- */
 int ctr_shard_route(const int32_t* idx, const int64_t* row_offset, const int32_t* local_offset, int B, int F,
-                    int W, uint32_t* dest_out, int32_t* lkey_out, void* stream);
+                    int W, uint32_t* dest_out, int32_t* lkey_out, int32_t* oor_count, void* stream);
 int ctr_shard_bucket(const uint32_t* dest_sorted, const uint32_t* perm, const int32_t* lkey, int64_t n, int W,
-                     int64_t cap, int32_t* slot_key_out, uint32_t* slot_perm_out, int32_t* overflow_count, void* stream);
+                     int64_t cap, int32_t* slot_key_out, uint32_t* slot_perm_out, int32_t* overflow_count,
+                     float* z_zero, int64_t z_ld, int F, int E, void* stream);
 int ctr_rows_gather(const void* src, int64_t ld, const uint32_t* perm, int64_t n, int F, int E, void* out,
                     void* stream);
 int ctr_rows_scatter(const void* rows, const uint32_t* perm, int64_t n, int F, int E, void* dst, int64_t ld,

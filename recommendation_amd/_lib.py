@@ -113,8 +113,8 @@ SIGNATURES = {
     'ctr_mlp_chain_bwd': (i, [i, i, vp, i64, i, vp, vp, i64, f, vp, i64, i, vp, vp, i64, f, vp, i64, vp]),
     'ctr_auc_workspace_bytes': (sz, [i64]),
     'ctr_auc': (i, [vp, vp, i64, vp, vp, vp, sz, vp]),
-    'ctr_shard_route': (i, [vp, vp, vp, i, i, i, vp, vp, vp]),
-    'ctr_shard_bucket': (i, [vp, vp, vp, i64, i, i64, vp, vp, vp, vp]),
+    'ctr_shard_route': (i, [vp, vp, vp, i, i, i, vp, vp, vp, vp]),
+    'ctr_shard_bucket': (i, [vp, vp, vp, i64, i, i64, vp, vp, vp, vp, i64, i, i, vp]),
     'ctr_rows_gather': (i, [vp, i64, vp, i64, i, i, vp, vp]),
     'ctr_rows_scatter': (i, [vp, vp, i64, i, i, vp, i64, vp]),
     'ctr_afm_attn_fwd': (i, [vp, i64, i, i, i, i, vp, vp, vp, DP, vp, vp]),

@@ -123,6 +123,7 @@ class ShardedFront:
         own = [int(cate_list[f]) for f in self.own_fields] or [1]   # a rank without fields keeps a 1-row dummy
         self.t = EmbeddingTables(own, E, device)
         self.device = device
+        self.oor_count = None     # optional device int32[1]: out-of-range ids are counted here, on the OWNER's rank
         self._buf = {}
 
     def owner_of(self, f):
@@ -179,7 +180,7 @@ class ShardedFront:
         self.comm.all_to_all(bf['recv_idx'][:W * B * self.nf_own], bf['send_idx'][:B * F], bf['idx_out'], bf['idx_in'])
         if self.nf_own:
             ops.embed_fwd(self.t.weight, self.t.row_offset, bf['recv_idx'][:W * B * self.nf_own].view(W * B, self.nf_own),
-                          E=E, z_out=bf['rows'], oor_count=oor_count)
+                          E=E, z_out=bf['rows'], oor_count=oor_count if oor_count is not None else self.oor_count)
         self.comm.all_to_all(bf['blocks'][:B * F * E], bf['rows'].view(-1)[:W * B * self.nf_own * E], bf['row_out'],
                              bf['row_in'])
         # one pass: owner blocks -> Z rows, continuous rows / tail, FM sums, dropout
@@ -280,6 +281,7 @@ class RowShardedFront:
         self.device = device
         self.key_bits = max(1, int(self.W - 1).bit_length())
         self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
+        self.oor_count = None     # optional device int32[1]: out-of-range ids of this rank's batch are counted here
         self._buf = {}
         self._own_ws = None
 
@@ -313,9 +315,12 @@ class RowShardedFront:
         bf = self._buffers(B)
         cap = bf['cap']
         ws = ws if ws is not None else self._ws()
-        ops.shard_route(idx, self.full_offset, self.local_offset, W, bf['dest'], bf['lkey'])
+        ops.shard_route(idx, self.full_offset, self.local_offset, W, bf['dest'], bf['lkey'],
+                        oor_count=oor_count if oor_count is not None else self.oor_count)
         sdest, perm = ops.sort_pairs(bf['dest'][:n], bf['arange'][:n], self.key_bits, ws)
-        ops.shard_bucket(sdest, perm, bf['lkey'], n, W, cap, bf['send_keys'], bf['slot_perm'], self.overflow)
+        # a lookup that does not fit its bucket is counted, and its row of Z is zeroed (nothing will be scattered there)
+        ops.shard_bucket(sdest, perm, bf['lkey'], n, W, cap, bf['send_keys'], bf['slot_perm'], self.overflow,
+                         z_zero=z_out, F=F, E=E)
         self.comm.all_to_all(bf['recv_keys'][:W * cap], bf['send_keys'][:W * cap])
         # empty slots carry key -1: zero rows (they are not out-of-range ids, so they are not counted)
         ops.embed_fwd(self.t.weight, self.shard_offset, bf['recv_keys'][:W * cap].view(W * cap, 1), E=E,
@@ -337,12 +342,17 @@ class RowShardedFront:
         return self._own_ws
 
     def check_overflow(self):
-        """Raises when a send bucket overflowed since the last check (synchronises the host)."""
-        n = int(self.overflow.item())
+        """Raises when a send bucket overflowed on ANY rank since the last check.  Collective: every rank calls it at
+        the same point of its program (the counters are summed over the ranks first, so that all of them raise
+        together instead of one raising while the others wait in the next exchange).  Synchronises the host."""
+        total = self.overflow.clone()
+        if self.W > 1:
+            self.comm.all_reduce_sum(total)
+        n = int(total.item())
         if n:
             self.overflow.zero_()
             raise RuntimeError('%d lookup(s) did not fit the fixed-capacity send buckets of the row-sharded tables '
-                               '(slack %.2f); raise args.shard_slack' % (n, self.slack))
+                               '(slack %.2f, all ranks together); raise args.shard_slack' % (n, self.slack))
 
     def backward_tables(self, idx, dz, keys, src, ws, opt, lazy):
         ops, E, F, W = self.ops, self.E, self.F, self.W

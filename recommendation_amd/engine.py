@@ -34,21 +34,34 @@ def truncated_normal(rng, shape, std=0.01):
 
 
 class BufferCache(OrderedDict):
-    """Per-shape scratch buffers of a model, least recently used first, at most `maxsize` shapes: a caller whose
-    batch size (or DIN history length) changes all the time re-allocates instead of accumulating device memory."""
+    """Per-shape scratch buffers of a model, least recently used first, at most `maxsize` unpinned shapes: a caller
+    whose batch size (or DIN history length) changes all the time re-allocates instead of accumulating device memory.
+    A shape that a captured graph points at is pinned (`pin`) and never evicted while the graph lives: a replay
+    reads and writes those buffers without ever coming through lookup()."""
 
     def __init__(self, maxsize=8):
         super().__init__()
         self.maxsize = maxsize
+        self.pinned = set()
 
     def lookup(self, key, make):
         if key in self:
             self.move_to_end(key)
             return self[key]
-        while len(self) >= self.maxsize:
-            self.popitem(last=False)
+        free = [k for k in self if k not in self.pinned]
+        while len(free) >= self.maxsize:
+            del self[free.pop(0)]
         self[key] = make()
         return self[key]
+
+    def pin(self, key):
+        if key not in self:
+            raise KeyError(key)
+        self.pinned.add(key)
+
+    def clear(self):
+        super().clear()
+        self.pinned.clear()
 
 
 class DenseParams:

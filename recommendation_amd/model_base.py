@@ -141,22 +141,23 @@ def get_checkpoint_state(directory):
     return full if os.path.exists(full + '.safetensors') or os.path.exists(full + '.manifest.json') else None
 
 
-# Captured graphs are kept until the process ends.  What is known: a graph owns no memory here (_capture asserts that
-# nothing is allocated while capturing; every buffer it points at belongs to its model or the session), and a
-# torch-free HIP program with the same fork/join capture survives capture -> destroy -> launch in every order
-# (tools/repro/graph_lifetime.cpp).  Still, with the graphs of collected models destroyed, 1 run in 11 of the GPU test
-# suite died inside hipGraphLaunch at the first replay of a newly captured graph; with the graphs kept, none did.
-# So graph executables are not destroyed, and their number is bounded instead: a model captures at most
-# GRAPH_SIZES_PER_MODEL batch sizes per direction and runs other sizes eagerly.
-_LIVE_GRAPHS = []
+# Lifetime of captured graphs.  A graph owns no memory here (_capture asserts that nothing is allocated while
+# capturing; every buffer it points at belongs to its model or the session).  A graph executable is never destroyed
+# by the garbage collector: a model that is closed or collected hands its graphs - together with the static input
+# buffers, the private side stream and the events their nodes refer to - to its Session, which destroys them at a
+# quiescent point only (Session.drain_graphs: device idle before and after; called before every new capture and when
+# the session closes).  So the number of live graph executables is bounded by the live models (GRAPH_SIZES_PER_MODEL
+# batch sizes per model and direction; other sizes run eagerly), and none outlives its session.
 GRAPH_SIZES_PER_MODEL = 4
 BUFFER_SIZES_PER_MODEL = 8      # per-batch-size activation buffers kept besides the captured sizes (LRU)
 
 
-def _capture(graph, fn):
-    """Record fn's launches into graph.  The cyclic garbage collector is held off meanwhile: were it to run inside
-    the capture and free an older model's graph, the runtime call that destroys it would be illegal there and the
-    process would abort (torch collects once on entering the capture, before it starts)."""
+def _capture(graph, fn, session=None):
+    """Record fn's launches into graph.  The cyclic garbage collector is held off meanwhile: a collection inside
+    the capture must not run finalizers that touch the device (torch collects once on entering the capture, before
+    it starts).  Graphs of models that are gone are destroyed first, while the device is idle."""
+    if session is not None:
+        session.drain_graphs()
     was_on = gc.isenabled()
     gc.disable()
     try:
@@ -170,18 +171,50 @@ def _capture(graph, fn):
             grew = torch.cuda.memory_stats()['allocation.all.allocated'] - allocs0
         if grew:
             raise RuntimeError('%d device allocation(s) happened inside a graph capture' % grew)
-        if os.environ.get('CTR_GRAPH_KEEP', '1') != '0':     # '0': experiments on graph destruction only
-            _LIVE_GRAPHS.append(graph)
         return out
     finally:
         if was_on:
             gc.enable()
 
 
+class GraphOwner:
+    """Release protocol for a model's captured graphs.  `_graph_tables()` returns the dicts whose values are graph
+    entries (sequences that start with the torch.cuda.CUDAGraph and hold everything its nodes point at)."""
+
+    session = None
+
+    def _graph_tables(self):
+        return ()
+
+    def _retire_graphs(self):
+        """Hands every captured graph to the session (no device call: safe inside the garbage collector)."""
+        entries = []
+        for table in self._graph_tables():
+            entries.extend(table.values())
+            table.clear()
+        sess = getattr(self, 'session', None)
+        if entries and sess is not None:
+            sess.retire_graphs(entries)
+
+    def close(self):
+        """Waits for the device, then destroys this model's captured graphs.  The model stays usable (the next
+        graphed step captures again)."""
+        self._retire_graphs()
+        sess = getattr(self, 'session', None)
+        if sess is not None:
+            sess.drain_graphs()
+
+    def __del__(self):
+        try:
+            self._retire_graphs()
+        except Exception:        # interpreter shutdown: the process is about to release everything
+            pass
+
+
 GRAPH_MAX_BATCH = 16384     # above this a step is GPU-bound and a captured graph gains nothing
 
 
-class CTRModel:
+class CTRModel(GraphOwner):
     MODEL = None
     OPTIMIZER = 'adam'
     CONT_EMBED = False        # AFM / PNN append value-scaled continuous rows to Z
@@ -259,8 +292,10 @@ class CTRModel:
         if not self._built:
             raise RuntimeError('call build() first')
         dev = session.device
+        if getattr(self, 'session', None) is not None:
+            self.close()                                # captured graphs point at the storage re-allocated below
         self.session = session
-        self._graphs, self._train_graphs = {}, {}      # captured graphs point at the storage allocated below
+        self._bufs.clear()
         self.dense = DenseParams(self.dense_shapes, dev)
         if self.world > 1:
             from .distributed import RowShardedFront, ShardedFront, TorchComm
@@ -285,7 +320,9 @@ class CTRModel:
         self._scalars = torch.zeros(2, dtype=torch.float32, device=dev)
         self._loss_dev = self._scalars[:1]
         self._oor = self._scalars[1:].view(torch.int32)
-        if self.mode == 'S' and self.world == 1:
+        if self.mode == 'S':
+            # one process: the gather counts; row-sharded: the router counts on the rank whose batch holds the id;
+            # table-sharded: the owner's gather counts (out_of_range_lookups sums over the ranks)
             self.front.oor_count = self._oor
         rng = np.random.Generator(np.random.PCG64(seed))
         init = OrderedDict()
@@ -319,6 +356,9 @@ class CTRModel:
 
     def _post_init(self):
         pass
+
+    def _graph_tables(self):
+        return (self._graphs, self._train_graphs)
 
     def _ensure_initialized(self, session):
         if not self._ready:
@@ -531,7 +571,7 @@ class CTRModel:
             self._indirect = (step_w, lr_w)
             try:
                 with self.session.private_side() as side_objs:
-                    _capture(graph, lambda: self.train_step(s_idx, s_xc, s_yy))
+                    _capture(graph, lambda: self.train_step(s_idx, s_xc, s_yy), self.session)
             finally:
                 self._indirect = None
                 self.global_step = step0           # the capture ran no kernel and does not count as a step
@@ -572,7 +612,7 @@ class CTRModel:
                 self.predict_step(s_idx, s_xc)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            out = _capture(graph, lambda: self.predict_step(s_idx, s_xc))
+            out = _capture(graph, lambda: self.predict_step(s_idx, s_xc), self.session)
             entry = (graph, s_idx, s_xc, out)
             self._graphs[B] = entry
         graph, s_idx, s_xc, out = entry
@@ -595,25 +635,34 @@ class CTRModel:
             host = self._scalars.cpu()                  # loss + out-of-range counter in one copy
             self.check_overflow()
             if self.strict_ids:
-                self._raise_on_bad_ids(int(host[1:].view(torch.int32)[0]))
+                self._raise_on_bad_ids(int(host[1:].view(torch.int32)[0]) if self.world == 1
+                                       else self.out_of_range_lookups(reset=False))
             return np.float32(host[0].item())
         # evaluation batches are small: graph replay, not ~15 launches
         y_out = self.predict_step(idx, xc) if isinstance(idx, Bags) else self.predict_step_graphed(idx, xc)
         # tf.round is round-half-to-even; torch.round too
         pred = torch.round(y_out).cpu().numpy()
+        self.check_overflow()
         if self.strict_ids:
-            self._raise_on_bad_ids(int(self._oor.item()))
+            self._raise_on_bad_ids(self.out_of_range_lookups(reset=False))
         return np.asarray(yy.cpu().numpy(), dtype=np.float32), pred
 
     def check_overflow(self):
-        """Row-sharded tables send fixed-capacity buckets; raises if one overflowed since the last check (host sync)."""
+        """Row-sharded tables send fixed-capacity buckets; raises - on every rank - if one overflowed on any rank
+        since the last check.  Host sync; with more than one rank a collective, so every rank must call it at the
+        same point (run() and predict_proba() do; callers of train_step()/predict_step() call it themselves)."""
         if hasattr(self.front, 'check_overflow'):
             self.front.check_overflow()
 
     def out_of_range_lookups(self, reset=True):
         """How many lookups since the last reset carried an id outside [0, V_f) (standard lookup only; they read a
-        zero row and update nothing).  Synchronises the host."""
-        n = int(self._oor.item())
+        zero row and update nothing).  Synchronises the host; with more than one rank the count is summed over the
+        ranks (a collective: every rank calls it at the same point)."""
+        total = self._oor
+        if self.world > 1:
+            total = self._oor.clone()
+            self.comm.all_reduce_sum(total)
+        n = int(total.item())
         if reset and n:
             self._oor.zero_()
         return n
@@ -628,7 +677,11 @@ class CTRModel:
         self._ensure_initialized(session)
         idx, xc, _ = self._upload(X_cate, X_cont, np.zeros(len(X_cont), dtype=np.float32))
         step = self.predict_step if isinstance(idx, Bags) else self.predict_step_graphed
-        return step(idx, xc).cpu().numpy()
+        out = step(idx, xc).cpu().numpy()
+        self.check_overflow()
+        if self.strict_ids:
+            self._raise_on_bad_ids(self.out_of_range_lookups(reset=False))
+        return out
 
     # hooks
     LOSS_KIND = 0

@@ -456,25 +456,30 @@ def auc_logloss(score, label, ws):
 
 
 @_timed
-def shard_route(idx, row_offset, local_offset, W, dest_out, lkey_out):
+def shard_route(idx, row_offset, local_offset, W, dest_out, lkey_out, oor_count=None):
+    """oor_count (optional device int32[1]): ids outside their table are added to it."""
     B, F = idx.shape
     if idx.dtype != torch.int32 or local_offset.dtype != torch.int32 or tuple(local_offset.shape) != (W, F):
         raise TypeError('shard_route wants int32 idx [B,F] and int32 local_offset [W,F]')
     if dest_out.numel() < B * F or lkey_out.numel() < B * F or dest_out.dtype != torch.int32 or lkey_out.dtype != torch.int32:
         raise ValueError('shard_route outputs must be int32 with B*F elements')
     check(lib().ctr_shard_route(_ptr(idx), _ptr(row_offset, torch.int64), _ptr(local_offset), B, F, int(W),
-                                _ptr(dest_out), _ptr(lkey_out), _stream()), 'ctr_shard_route')
+                                _ptr(dest_out), _ptr(lkey_out), _ptr(oor_count), _stream()), 'ctr_shard_route')
 
 
-def shard_bucket(dest_sorted, perm, lkey, n, W, cap, slot_key, slot_perm, overflow):
-    """Fixed-capacity send buckets (cap slots per destination rank) from lookups sorted by destination."""
+def shard_bucket(dest_sorted, perm, lkey, n, W, cap, slot_key, slot_perm, overflow, z_zero=None, F=1, E=1):
+    """Fixed-capacity send buckets (cap slots per destination rank) from lookups sorted by destination.
+    z_zero (optional): the [B, >= F*E] activation buffer the rows are scattered into later; the row of a lookup that
+    does not fit its bucket is zeroed there."""
     for t in (dest_sorted, perm, lkey, slot_key, slot_perm, overflow):
         if t.dtype != torch.int32:
             raise TypeError('shard_bucket moves int32 words')
     if slot_key.numel() < W * cap or slot_perm.numel() < W * cap or dest_sorted.numel() < n or perm.numel() < n:
         raise ValueError('shard_bucket: buffers too small')
+    zp, zld = (None, 0) if z_zero is None else _rows(z_zero, 'z_zero')
     check(lib().ctr_shard_bucket(_ptr(dest_sorted), _ptr(perm), _ptr(lkey), int(n), int(W), int(cap), _ptr(slot_key),
-                                 _ptr(slot_perm), _ptr(overflow), _stream()), 'ctr_shard_bucket')
+                                 _ptr(slot_perm), _ptr(overflow), zp, zld, int(F), int(E), _stream()),
+          'ctr_shard_bucket')
 
 
 def _words(t):

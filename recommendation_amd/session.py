@@ -31,13 +31,38 @@ class Session:
         self._join_ev = None
         self._side_open = False
         self.side_enabled = True     # False: side_stream() is a no-op context (per-kernel timing passes)
+        # captured graphs (with the static buffers, streams and events they refer to) whose model was closed or
+        # collected: destroyed only at a quiescent point (drain_graphs), never from the garbage collector
+        self._retired = []
 
     def __enter__(self):
         return self
 
     def __exit__(self, *exc):
-        torch.cuda.synchronize(self.device)
+        self.close()
         return False
+
+    def close(self):
+        """Waits for the device and destroys the graphs of models that are gone."""
+        torch.cuda.synchronize(self.device)
+        self.drain_graphs()
+
+    def retire_graphs(self, entries):
+        """Takes over captured-graph entries (sequences whose first item is the torch.cuda.CUDAGraph) from a model
+        that no longer needs them.  Nothing is destroyed here: this may run inside the garbage collector."""
+        self._retired.extend(entries)
+
+    def drain_graphs(self):
+        """Destroys retired graphs.  Graph executables are released only here, with the device idle before and
+        after: first the graph, then the buffers, streams and events its nodes point at."""
+        if not self._retired:
+            return
+        torch.cuda.synchronize(self.device)
+        while self._retired:
+            items = list(self._retired.pop())
+            while items:
+                items.pop(0)                 # the graph goes first; its last reference dies here
+        torch.cuda.synchronize(self.device)
 
     def side_stream(self):
         """Context manager: the enclosed launches go to the side stream, ordered after everything issued so far

@@ -72,6 +72,52 @@ def _checkpoint_round_trip(cls, cfg, dcfg, m, single, sess, Xc, Xf, y, lo, hi, r
             assert np.array_equal(m3.tables.table(fl, m3.tables.slot0).cpu().numpy(), want), (rank, f)
 
 
+def _bad_ids_and_overflow(cls, dcfg, cfg, P, sess, Xc, Xf, y, lo, hi, rank, world, shard):
+    """An id outside its table in ONE rank's batch is counted once over the ranks and, with strict_ids, raises on
+    every rank; a send bucket that overflows on one rank raises on every rank (the ranks stay in step)."""
+    import copy
+    F, C = cfg.cate_num, cfg.cont_num
+    bad = Xc[lo:hi].copy()
+    if rank == 0:
+        bad[1, 3] = 10 ** 6
+    m = cls(copy.copy(dcfg), F, C, cfg.cate_list)
+    m.build()
+    m.initialize(sess, params=P)
+    m.run(sess, bad, Xf[lo:hi], y[lo:hi], True)
+    assert m.out_of_range_lookups() == 1 and m.out_of_range_lookups() == 0, rank
+    scfg = copy.copy(dcfg)
+    scfg.strict_ids = True
+    ms = cls(scfg, F, C, cfg.cate_list)
+    ms.build()
+    ms.initialize(sess, params=P)
+    try:
+        ms.run(sess, bad, Xf[lo:hi], y[lo:hi], True)
+        raise AssertionError('strict_ids did not raise on rank %d' % rank)
+    except IndexError:
+        pass
+    if shard == 'row':
+        tcfg = copy.copy(dcfg)
+        tcfg.shard_slack = 1.0                    # 120 lookups per rank, 64 slots per destination
+        mt = cls(tcfg, F, C, cfg.cate_list)
+        mt.build()
+        mt.initialize(sess, params=P)
+        nb = 24
+        fcol = np.arange(F)[None, :]
+        # rank 0: every id 0, so three of the five fields go to one rank (72 lookups > 64 slots);
+        # rank 1: destinations alternate with the sample (60 + 60): nothing overflows there
+        hot = np.zeros((nb, F), dtype=np.int64) if rank == 0 else (np.arange(nb)[:, None] + fcol) % 2
+        xf, yy = np.zeros((nb, C)), np.zeros(nb)
+        mt.train_step(*mt._upload(hot, xf, yy))
+        own = int(mt.front.overflow.item())
+        assert (own == 0) == (rank == 1), (rank, own)          # only rank 0 dropped lookups ...
+        try:
+            mt.check_overflow()
+            raise AssertionError('bucket overflow did not raise on rank %d' % rank)
+        except RuntimeError as e:                              # ... and both ranks raise
+            assert 'send buckets' in str(e), e
+    dist.barrier()
+
+
 def main(model_name, shard='table', arch='tiny'):
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -139,6 +185,7 @@ def main(model_name, shard='table', arch='tiny'):
     dist.barrier()
     if arch == 'tiny':
         _checkpoint_round_trip(cls, cfg, dcfg, m, single, sess, Xc, Xf, y, lo, hi, rank, world, shard)
+        _bad_ids_and_overflow(cls, dcfg, cfg, P, sess, Xc, Xf, y, lo, hi, rank, world, shard)
     dist.barrier()
     if rank == 0:
         print('DIST_OK %s %s' % (model_name, shard))

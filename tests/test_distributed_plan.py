@@ -39,7 +39,7 @@ class TorchBackend:
         def __init__(self, device):
             self.device = device
 
-    def shard_route(self, idx, row_offset, local_offset, W, dest_out, lkey_out):
+    def shard_route(self, idx, row_offset, local_offset, W, dest_out, lkey_out, oor_count=None):
         B, F = idx.shape
         x = idx.long()
         V = (row_offset[1:] - row_offset[:-1]).view(1, F)
@@ -50,6 +50,8 @@ class TorchBackend:
                           torch.full_like(x, -1))
         dest_out[:B * F] = d.reshape(-1).int()
         lkey_out[:B * F] = key.reshape(-1).int()
+        if oor_count is not None:
+            oor_count += int((~ok).sum())
 
     def sort_pairs(self, keys, vals, key_bits, ws):
         order = torch.sort(keys.long(), stable=True).indices
@@ -72,7 +74,7 @@ class TorchBackend:
         for e in range(E):
             dst[p // F, (p % F) * E + e] = r[:, e]
 
-    def shard_bucket(self, dest_sorted, perm, lkey, n, W, cap, slot_key, slot_perm, overflow):
+    def shard_bucket(self, dest_sorted, perm, lkey, n, W, cap, slot_key, slot_perm, overflow, z_zero=None, F=1, E=1):
         slot_key[:W * cap] = -1
         slot_perm[:W * cap] = -1
         d = dest_sorted[:n].long()
@@ -83,6 +85,9 @@ class TorchBackend:
         slot_key[slot] = lkey[perm[:n].long()[ok]]
         slot_perm[slot] = perm[:n][ok]
         overflow += int((~ok).sum())
+        if z_zero is not None:
+            for p in perm[:n].long()[~ok].tolist():
+                z_zero[p // F, (p % F) * E:(p % F + 1) * E] = 0
 
     def copy2d(self, src, dst, accumulate=False):
         dst[:, :src.shape[1]] = src
@@ -187,6 +192,9 @@ def _row_worker(rank, world, port, ret):
             in_splits = in_splits or [inp.shape[0] // world] * world
             p2p_all_to_all(out, inp, out_splits, in_splits, rank, world)
 
+        def all_reduce_sum(self, t):
+            dist.all_reduce(t)
+
     cards, E, C, B = [5, 9, 1, 7, 3], 4, 2, 6               # field 2 has one row: rank 1 owns none of it
     rng = np.random.default_rng(0)
     full = [torch.tensor(rng.standard_normal((v, E)), dtype=torch.float32) for v in cards]
@@ -201,7 +209,9 @@ def _row_worker(rank, world, port, ret):
     idx[0, 1] = 99                                           # out of range: zero row, no update
     xc = torch.tensor(r2.standard_normal((B, C)), dtype=torch.float32)
     z = torch.zeros(B, len(cards) * E + C)
+    front.oor_count = torch.zeros(1, dtype=torch.int32)
     front.forward(idx, xc, z_out=z, cont_tail=True)
+    assert int(front.oor_count) == 1                         # counted on the rank whose batch holds the id
     safe = idx.clone()
     safe[0, 1] = 0
     ref = torch.cat([full[f][safe[:, f].long()] for f in range(5)] + [xc], dim=1)
@@ -224,9 +234,15 @@ def _row_worker(rank, world, port, ret):
     tight = RowShardedFront(cards, E, C, False, Comm(), torch.device('cpu'), backend=TorchBackend(), slack=0.1)
     tight.capacity = lambda B: 1
     hot = torch.zeros(B, len(cards), dtype=torch.int32)     # every lookup of a field goes to one rank
-    tight.forward(hot, xc, z_out=torch.zeros_like(z), cont_tail=True)
-    assert int(tight.overflow) > 0
-    with pytest.raises(RuntimeError):
+    if rank == 1:
+        hot = idx.clone()                                    # rank 1's own buckets may or may not overflow ...
+    stale = torch.full_like(z, 7.0)                          # ... and a dropped lookup must not keep a stale row
+    tight.forward(hot, xc, z_out=stale, cont_tail=True)
+    if rank == 0:
+        assert int(tight.overflow) > 0
+        rows = stale[:, :len(cards) * E].reshape(B, len(cards), E)
+        assert bool(((rows == 0).all(-1) | (rows != 7.0).all(-1)).all())     # every row was written or zeroed
+    with pytest.raises(RuntimeError):                        # ... yet both ranks raise, together
         tight.check_overflow()
     dist.barrier()
     dist.destroy_process_group()

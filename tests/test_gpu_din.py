@@ -105,3 +105,52 @@ def test_din_graph_replay_matches_eager_steps(sess):
     p1, p2 = m1.get_params(), m2.get_params()
     for k in p1:
         assert np.array_equal(p1[k], p2[k]), k
+
+
+@pytest.mark.gpu
+def test_din_captured_shape_survives_buffer_cache_pressure(sess):
+    """A captured (B, T) step keeps its buffers while nine other shapes pass through eval() and train_step() - more
+    than the per-shape buffer cache holds - and its next replay still leaves the bits of an eager model that saw
+    the same steps.  initialize() on a captured model releases its graphs and buffers."""
+    B, T, H = 32, 20, 32
+    m1, _, _, _ = _setup(sess, H, seed=3, B=B, T=T, item_count=300, cate_count=12)
+    m2, _, _, _ = _setup(sess, H, seed=3, B=B, T=T, item_count=300, cate_count=12)
+    rng = np.random.default_rng(9)
+    dev = sess.device
+
+    def batch(b, t):
+        sl = rng.integers(1, t + 1, b)
+        hist = rng.integers(0, 300, (b, t))
+        hist[np.arange(t)[None, :] >= sl[:, None]] = 0
+        return (torch.as_tensor(rng.integers(0, 300, b).astype(np.int32)).to(dev),
+                torch.as_tensor(rng.integers(0, 2, b).astype(np.float32)).to(dev),
+                torch.as_tensor(hist.astype(np.int32)).to(dev), torch.as_tensor(sl.astype(np.int32)).to(dev))
+
+    for _ in range(2):                                   # eager step + capture, then one replay
+        args = batch(B, T)
+        m1.train_step(*args, 0.1)
+        m2.train_step_graphed(*args, 0.1)
+    assert list(m2._train_graphs) == [(B, T)] and (B, T) in m2._bufs.pinned
+    for k in range(9):                                   # nine other shapes, alternately evaluated and trained
+        b, t = 8 + k, 5 + 2 * k
+        i, y, hist, sl = batch(b, t)
+        if k % 2:
+            for m in (m1, m2):
+                m.train_step(i, y, hist, sl, 0.05)
+        else:
+            j = torch.as_tensor(rng.integers(0, 300, b).astype(np.int32)).to(dev)
+            for m in (m1, m2):
+                m.eval(sess, (None, i, j, hist, sl))
+    assert (B, T) in m2._bufs and len(m2._bufs) <= m2._bufs.maxsize + 1
+    for _ in range(2):                                   # replays against the buffers captured above
+        args = batch(B, T)
+        l1 = m1.train_step(*args, 0.1)
+        l2 = m2.train_step_graphed(*args, 0.1)
+        assert float(l1.item()) == float(l2.item())
+    p1, p2 = m1.get_params(), m2.get_params()
+    for k in p1:
+        assert np.array_equal(p1[k], p2[k]), k
+    m2.initialize(sess, params=p1)
+    assert not m2._train_graphs and not m2._bufs and not m2._bufs.pinned and not sess._retired
+    args = batch(B, T)
+    assert float(m1.train_step(*args, 0.1).item()) == float(m2.train_step_graphed(*args, 0.1).item())
