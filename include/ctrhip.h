@@ -77,6 +77,18 @@ int ctr_embed_fwd(const float* tables, const int64_t* row_offset, const int32_t*
                   float* second_out, int64_t second_ld,
                   const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second,
                   int32_t* oor_count, void* stream);
+/* ctr_embed_fwd that also raises the record amax_out (optional, CTR_AMAX_FLOATS floats zeroed by the caller) to the largest magnitude
+ * it writes to z_out, continuous tail included: the a_amax word of the product that consumes z_out
+ * (ctr_epilogue_t). */
+int ctr_embed_fwd_amax(const float* tables, const int64_t* row_offset, const int32_t* idx,
+                  const float* x_cont, const float* cont_w,
+                  int B, int F, int C, int E,
+                  float* z_out, int64_t z_ld, int cont_tail,
+                  float* first_out, int64_t first_ld,
+                  float* s_out,
+                  float* second_out, int64_t second_ld,
+                  const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second,
+                  int32_t* oor_count, float* amax_out, void* stream);
 
 /* Multi-hot fields ("gather and pool"; the sum combiner of tf.nn.embedding_lookup_sparse, which the reference's
  * one-id-per-field models are the one-member case of: DeepFM/DeepFM.py:43-53).  idx is a flat list of nnz ids and
@@ -263,6 +275,22 @@ typedef struct {
   int64_t mask_ld;
   float mask_scale;
   const ctr_fm_bwd_t* fm_bwd;
+  /* Largest magnitudes (all optional).  Each is a device record of CTR_AMAX_FLOATS floats whose value is the
+   * largest of its words 0, 32, 64, ... (concurrent raises are spread over 32 cache lines); zero the whole record to
+   * reset it.
+   *   a_amax / b_amax   max |A|, max |B| (or any upper bound within a factor of 2^8), written before this call by
+   *                     whatever produced the operands (c_amax_out of an earlier product, ctr_embed_fwd's amax_out,
+   *                     ctr_absmax).  With both present - and the split arithmetic selected - the product runs as
+   *                     the two-term fp16 split (see ctr_set_gemm_f16_split): ~3e-7 relative instead of ~1e-7, at
+   *                     half the matrix-core work.  *_floor: a lower bound the kernel applies to the word (an
+   *                     operand view that includes a column of ones its producer did not write).
+   *   c_amax_out        raised (integer atomic max on the floats' bits, never lowered: zero it first) to max |C|
+   *                     over the elements this call stores. */
+  const float* a_amax;
+  const float* b_amax;
+  float a_amax_floor;
+  float b_amax_floor;
+  float* c_amax_out;
 } ctr_epilogue_t;
 
 /* Arithmetic of the tiled GEMM (process-wide; default CTR_GEMM_SPLIT_BF16):
@@ -278,6 +306,22 @@ typedef struct {
 #define CTR_GEMM_BF16 2
 int ctr_set_gemm_mode(int mode);
 int ctr_get_gemm_mode(void);
+/* In CTR_GEMM_SPLIT_BF16 mode a product whose epilogue brings a_amax and b_amax runs as a two-term fp16 split
+ * instead: each operand times a power of two that puts its largest magnitude just under 2^15 (exact), then
+ * x = hi + lo in fp16 (22 significant bits) and three fp16 MFMAs (lo*hi + hi*lo + hi*hi) accumulated in fp32, the
+ * powers of two taken out again in the epilogue.  on = 0 keeps every product on the bf16 split.  Returns the
+ * previous setting (default 1). */
+int ctr_set_gemm_f16_split(int on);
+/* Raises the record `out` (CTR_AMAX_FLOATS floats, see ctr_epilogue_t) to max |X[r, c]| over a [rows, cols] view:
+ * the a_amax / b_amax record of an operand whose producer does not raise it.  Zero the record first (it is only
+ * ever raised). */
+#define CTR_AMAX_FLOATS 1024
+int ctr_absmax(const float* X, int64_t ld, int64_t rows, int cols, float* out, void* stream);
+/* The same over n_tensors slices of one flat buffer: record i (at out + i * CTR_AMAX_FLOATS) is raised to
+ * max |flat[offset[i] .. offset[i] + count[i])| (the weight matrices of a tower in the flat variable buffer).
+ * offsets / counts: device int64[n_tensors]. */
+int ctr_absmax_tensors(const float* flat, const int64_t* offsets, const int64_t* counts, int n_tensors,
+                       float* out, void* stream);
 /* Diagnostic: resident blocks per CU the runtime grants the 128x128 split tile kernel (designed for 2); < 0 on error. */
 int ctr_gemm_split_blocks_per_cu(void);
 size_t ctr_gemm_f32_workspace_bytes(int M, int N, int K);
@@ -294,6 +338,12 @@ int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K,
 size_t ctr_dense_wgrad_workspace_bytes(int M, int N, int K);
 int ctr_dense_wgrad(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
                     float* dW, float* db, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the operands' largest magnitudes (ctr_epilogue_t.a_amax / b_amax; a_amax_floor as there): the
+ * products that go through ctr_gemm_f32 then run as the two-term fp16 split; the streamed small-output kernel is
+ * plain fp32 either way. */
+int ctr_dense_wgrad_scaled(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                           float* dW, float* db, const float* a_amax, float a_amax_floor, const float* b_amax,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* out[j] = sum_b X[b*ld + j] * (w ? w[b*w_ld + j / w_group] : 1),  j in [0, K).
  * Two fixed-order passes (bitwise reproducible).  Serves bias gradients (w == NULL),

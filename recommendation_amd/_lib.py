@@ -39,7 +39,9 @@ class FmBwd(C.Structure):
 class Epilogue(C.Structure):
     _fields_ = [('bias', C.c_void_p), ('relu', C.c_int), ('accumulate', C.c_int),
                 ('dropout', C.POINTER(Dropout)), ('mask_src', C.c_void_p),
-                ('mask_ld', C.c_int64), ('mask_scale', C.c_float), ('fm_bwd', C.POINTER(FmBwd))]
+                ('mask_ld', C.c_int64), ('mask_scale', C.c_float), ('fm_bwd', C.POINTER(FmBwd)),
+                ('a_amax', C.c_void_p), ('b_amax', C.c_void_p), ('a_amax_floor', C.c_float),
+                ('b_amax_floor', C.c_float), ('c_amax_out', C.c_void_p)]
 
 
 OPT_GRAD_ONLY, OPT_ADAM, OPT_ADAGRAD, OPT_SGD, OPT_FTRL = 0, 1, 2, 3, 4
@@ -54,6 +56,7 @@ SIGNATURES = {
     'ctr_version': (i, []),
     'ctr_keep_hash24': (C.c_uint32, [C.c_uint64, C.c_uint64, C.c_uint64]),
     'ctr_embed_fwd': (i, [vp, vp, vp, vp, vp, i, i, i, i, vp, i64, i, vp, i64, vp, vp, i64, DP, DP, vp, vp]),
+    'ctr_embed_fwd_amax': (i, [vp, vp, vp, vp, vp, i, i, i, i, vp, i64, i, vp, i64, vp, vp, i64, DP, DP, vp, vp, vp]),
     'ctr_fm_fwd': (i, [vp, i64, i, i, i, vp, i64, vp, vp, i64, DP, DP, vp]),
     'ctr_relu_mask_apply': (i, [vp, i64, vp, i64, i, i, f, vp]),
     'ctr_embed_onehot_fwd': (i, [vp, vp, vp, vp, i, i, i, i, vp, i64, i, vp, vp]),
@@ -72,6 +75,10 @@ SIGNATURES = {
     'ctr_gemm_f32': (i, [i, i, i, i, i, vp, i64, vp, i64, vp, i64, C.POINTER(Epilogue), vp, sz, vp]),
     'ctr_dense_wgrad_workspace_bytes': (sz, [i, i, i]),
     'ctr_dense_wgrad': (i, [i, i, i, vp, i64, vp, i64, vp, vp, vp, sz, vp]),
+    'ctr_dense_wgrad_scaled': (i, [i, i, i, vp, i64, vp, i64, vp, vp, vp, f, vp, vp, sz, vp]),
+    'ctr_set_gemm_f16_split': (i, [i]),
+    'ctr_absmax': (i, [vp, i64, i64, i, vp, vp]),
+    'ctr_absmax_tensors': (i, [vp, vp, vp, i, vp, vp]),
     'ctr_colsum_workspace_bytes': (sz, [i, i]),
     'ctr_colsum': (i, [vp, i64, vp, i64, i, i, i, vp, i, vp, sz, vp]),
     'ctr_rowdot_fwd': (i, [vp, i64, vp, vp, i, i, vp, vp]),

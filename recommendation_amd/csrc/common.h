@@ -145,4 +145,34 @@ __device__ static inline int buf_ld1i(__amdgpu_buffer_rsrc_t r, unsigned off) {
 }
 static inline bool fits_buffer(int64_t bytes) { return bytes >= 0 && bytes < ((int64_t)1 << 31); }
 
+// A "largest magnitude" record is CTR_AMAX_FLOATS floats: the maximum is kept in AMAX_WORDS words that lie
+// AMAX_STRIDE floats (128 bytes) apart, and its value is the largest of them.  Thousands of waves raise a record as
+// they finish; atomics on one word are served one after the other (about 3.5 ns each: a 16 K-wave kernel would end
+// with 50 us of queued atomics), spread over 32 lines they cost nothing measurable, and no wave has to read the
+// record back first.
+constexpr int AMAX_WORDS = 32, AMAX_STRIDE = 32;
+static_assert(AMAX_WORDS * AMAX_STRIDE == CTR_AMAX_FLOATS, "record size");
+
+// Raises the record to the largest of the wave's non-negative values: one integer atomic per wave.
+__device__ static inline void raise_amax(float* rec, float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  if ((threadIdx.x & 63) == 0 && v > 0.f) {
+    const unsigned word = (blockIdx.x + 13u * blockIdx.y + (threadIdx.x >> 6)) & (AMAX_WORDS - 1);
+    atomicMax(reinterpret_cast<unsigned int*>(rec) + word * AMAX_STRIDE, __float_as_uint(v));
+  }
+}
+
+// The record's value, the same in every lane (a kernel reads records that earlier launches wrote).
+__device__ static inline float read_amax(const float* rec) {
+  const int lane = threadIdx.x & 63;
+  float v = lane < AMAX_WORDS ? rec[lane * AMAX_STRIDE] : 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// *out = max(*out, max |X|) over a [rows, cols] view (gemm.hip): for producers that do not track it themselves
+void launch_absmax(const float* X, int64_t ld, int64_t rows, int cols, float* out, hipStream_t st);
+
 }  // namespace ctr

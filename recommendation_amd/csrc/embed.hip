@@ -149,9 +149,10 @@ __global__ __launch_bounds__(256) void embed_fwd_lean_kernel(
     float* __restrict__ z_out, int64_t z_ld, int cont_tail,
     float* __restrict__ first_out, int64_t first_ld, float* __restrict__ s_out,
     float* __restrict__ second_out, int64_t second_ld, Drop d_first, Drop d_second,
-    int32_t* __restrict__ oor_count) {
+    int32_t* __restrict__ oor_count, float* __restrict__ amax_out) {
   d_first = resolve_drop(d_first); d_second = resolve_drop(d_second);
   constexpr int SLOTS = 16 / G, CH = 4, E = 4 * G;
+  float amx = 0.f;                                          // largest magnitude this lane writes to z_out
   extern __shared__ int64_t offs_lds[];                     // [F + 1] first row of every field
   for (int f = threadIdx.x; f <= F; f += 256) offs_lds[f] = row_offset[f];
   __syncthreads();
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(256) void embed_fwd_lean_kernel(
   float4 s = f4_zero(), q = f4_zero();
   auto take = [&](float4 zz, int n, bool active) {          // one row of Z: store, sums, first-order term
     buf_st4(rz, active ? zbase + (unsigned)n * (E * 4) - (unsigned)slot * (E * 4) : OOB, zz);
+    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(zz.x), fabsf(zz.y))), fmaxf(fabsf(zz.z), fabsf(zz.w)));   // inactive rows are zero
     s.x += zz.x; s.y += zz.y; s.z += zz.z; s.w += zz.w;
     q.x += zz.x * zz.x; q.y += zz.y * zz.y; q.z += zz.z * zz.z; q.w += zz.w * zz.w;
     if (first_out) {
@@ -243,8 +245,13 @@ __global__ __launch_bounds__(256) void embed_fwd_lean_kernel(
     }
   }
   if (cont_tail && z_out && live) {
-    for (int c = l16; c < C; c += 16) z_out[b * z_ld + (int64_t)N * E + c] = x_cont[b * C + c];
+    for (int c = l16; c < C; c += 16) {
+      const float v = x_cont[b * C + c];
+      z_out[b * z_ld + (int64_t)N * E + c] = v;
+      amx = fmaxf(amx, fabsf(v));
+    }
   }
+  if (amax_out) raise_amax(amax_out, amx);
 }
 
 // Same front end for E = 128 and 256 (G = 32, 64 lanes per row): one wave per sample.
@@ -501,8 +508,9 @@ static int embed_fwd_impl(const float* tables, const int64_t* row_offset, const 
                           int64_t first_ld, float* s_out, float* second_out, int64_t second_ld,
                           const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second,
                           int32_t* oor_count, const float* blk, const int64_t* fbase, const int64_t* fstride,
-                          void* stream) {
+                          void* stream, float* amax_out = nullptr) {
   CTR_REQUIRE(B >= 0 && F >= 0 && C >= 0, "ctr_embed_fwd: negative size");
+  CTR_REQUIRE(!amax_out || z_out, "ctr_embed_fwd: amax_out is the largest magnitude written to z_out, which is null");
   CTR_REQUIRE(pow2(E) && E >= 4 && E <= 256, "ctr_embed_fwd: E=%d must be a power of two in [4,256]", E);
   CTR_REQUIRE(F == 0 || (tables && row_offset && idx) || (blk && fbase && fstride),
               "ctr_embed_fwd: null table/index pointer");
@@ -534,6 +542,7 @@ static int embed_fwd_impl(const float* tables, const int64_t* row_offset, const 
       case 64: GATHER(64); break;
     }
 #undef GATHER
+    if (amax_out) launch_absmax(z_out, z_ld, B, F * E, amax_out, st);
     CTR_LAUNCH_CHECK();
     return CTR_OK;
   }
@@ -541,7 +550,8 @@ static int embed_fwd_impl(const float* tables, const int64_t* row_offset, const 
       fits_buffer((int64_t)B * z_ld * 4) && fits_buffer((int64_t)B * first_ld * 4)) {
 #define LEAN(GG)                                                                                           \
   hipLaunchKernelGGL((embed_fwd_lean_kernel<GG>), grid, block, lds, st, tables, row_offset, idx, x_cont, cont_w, B, F, C, \
-                     z_out, z_ld, cont_tail, first_out, first_ld, s_out, second_out, second_ld, d1, d2, oor_count)
+                     z_out, z_ld, cont_tail, first_out, first_ld, s_out, second_out, second_ld, d1, d2, oor_count, \
+                     z_out ? amax_out : nullptr)
     switch (E / 4) {
       case 1: LEAN(1); break;
       case 2: LEAN(2); break;
@@ -572,8 +582,20 @@ static int embed_fwd_impl(const float* tables, const int64_t* row_offset, const 
   }
 #undef LAUNCH
 #undef LAUNCHW
+  if (amax_out) launch_absmax(z_out, z_ld, B, N * E + (cont_tail ? C : 0), amax_out, st);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
+}
+
+extern "C" int ctr_embed_fwd_amax(const float* tables, const int64_t* row_offset, const int32_t* idx,
+                                  const float* x_cont, const float* cont_w, int B, int F, int C, int E,
+                                  float* z_out, int64_t z_ld, int cont_tail, float* first_out,
+                                  int64_t first_ld, float* s_out, float* second_out, int64_t second_ld,
+                                  const ctr_dropout_t* drop_first, const ctr_dropout_t* drop_second,
+                                  int32_t* oor_count, float* amax_out, void* stream) {
+  return embed_fwd_impl(tables, row_offset, idx, x_cont, cont_w, B, F, C, E, z_out, z_ld, cont_tail, first_out,
+                        first_ld, s_out, second_out, second_ld, drop_first, drop_second, oor_count, nullptr, nullptr,
+                        nullptr, stream, amax_out);
 }
 
 extern "C" int ctr_embed_fwd(const float* tables, const int64_t* row_offset, const int32_t* idx,

@@ -31,6 +31,7 @@ struct Epi {
   int64_t mask_ld;
   float mask_scale;
   FmBwd fm;
+  float* amax_out;   // optional: max |C| over the stored elements is raised here (bits of a non-negative float, atomicMax)
 };
 
 __device__ static inline float epilogue(const Epi& e, float v, int m, int n, int N, const float* cptr) {
@@ -149,6 +150,7 @@ __device__ static inline void tile_epilogue(f32x16 (&acc)[TM][TN], float* smem, 
 #pragma unroll
     for (int u = 0; u < 4; ++u) bias4[j][u] = (epi.bias && !partial && n + u < N) ? epi.bias[n + u] : 0.f;
   }
+  float amx = 0.f;   // max |value stored| of this lane (epi.amax_out)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     float4 fz[TN][4], fs[4];
@@ -278,14 +280,16 @@ __device__ static inline void tile_epilogue(f32x16 (&acc)[TM][TN], float* smem, 
         }
         if (full && vec_out) {
           *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+          amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         } else {
 #pragma unroll
           for (int u = 0; u < 4; ++u)
-            if (n + u < N) cp[u] = v[u];
+            if (n + u < N) { cp[u] = v[u]; amx = fmaxf(amx, fabsf(v[u])); }
         }
       }
     }
   }
+  if (epi.amax_out && !partial) raise_amax(epi.amax_out, amx);
 }
 
 // A_K: A stored [M,K] (k contiguous).  B_K: B stored [N,K] (k contiguous).
@@ -435,6 +439,43 @@ __device__ static inline void split_load8(const float* __restrict__ P, int64_t l
     if (k0 + j < kend) v[j] = KCONTIG ? p[j] : p[(int64_t)j * ld];
 }
 
+// Two-term fp16 split (PL = 2): x * scale = hi + lo with hi = fp16(x * scale), lo = fp16(x * scale - hi), both rounded
+// to nearest: 22 significant bits where lo is a normal fp16 number.  `scale` is a power of two that brings the
+// matrix's largest magnitude just under 2^15 (see scale_for), so x * scale is exact, nothing overflows, and the part
+// of an element that falls below fp16's smallest subnormal is at most 2^-40 of the matrix maximum.  The product is
+// accumulated from three fp16 MFMAs, lo*hi + hi*lo + hi*hi (the dropped lo*lo is <= 2^-22 relative): ~3e-7
+// relative, against ~1e-7 for the three-term bf16 split, at half the matrix-core work and two thirds of the LDS
+// traffic.  It needs the two operands' largest magnitudes before the launch (ctr_epilogue_t.a_amax / b_amax).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int F16_TARGET_EXP = 15;   // the largest magnitude lands in [2^14, 2^15)
+
+// 2^k with amax * 2^k in [2^(F16_TARGET_EXP-1), 2^F16_TARGET_EXP); 1 for amax = 0, inf or NaN.  k is returned too.
+__device__ static inline float scale_for(float amax, int& k) {
+  const unsigned bits = __float_as_uint(amax);
+  const int e = (int)((bits >> 23) & 0xFFu);          // biased exponent: amax in [2^(e-127), 2^(e-126))
+  k = 0;
+  if (e == 0 || e == 255) return 1.f;                 // zero / subnormal maximum, or non-finite: leave the values alone
+  k = F16_TARGET_EXP - 1 - (e - 127);
+  if (k > 100) k = 100;
+  if (k < -100) k = -100;
+  return __uint_as_float((unsigned)(127 + k) << 23);
+}
+
+__device__ static inline void split_store8_f16(_Float16* __restrict__ S, int R, int row, int kg, const float (&v)[8],
+                                               float scale) {
+  f16x8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = v[j] * scale;
+    const _Float16 h = (_Float16)x;
+    hi[j] = h;
+    lo[j] = (_Float16)(x - (float)h);
+  }
+  _Float16* p = S + row * SROW + kg * 8;
+  *reinterpret_cast<f16x8*>(p) = hi;
+  *reinterpret_cast<f16x8*>(p + R * SROW) = lo;
+}
+
 // S: PL planes [PL][R][SROW] of bf16; writes the hi / mid / lo terms of v at (row, 8*kg .. 8*kg+7).  PL = 1 keeps
 // only the leading term: v rounded to bf16 (round to nearest even), the plain bf16-in / fp32-accumulate product.
 template <int PL>
@@ -464,13 +505,28 @@ __device__ static inline void split_store8(__bf16* __restrict__ S, int R, int ro
 // writes them to buffer (s+1)%2 - the split's VALU and LDS writes fill the issue slots between MFMAs - and
 // (3) meets the block at ONE barrier.  The loop is unrolled by two so the register sets alternate without
 // moves.
+// PL = 3: the three-term bf16 split; PL = 1: operands rounded to bf16; PL = 2: the two-term fp16 split, whose
+// scales come from the operands' largest magnitudes (sc.a_amax / sc.b_amax, device words written before the launch).
+struct Scales {
+  const float *a_amax, *b_amax;
+  float a_floor, b_floor;     // lower bounds of the two maxima (a column of ones the producer did not see)
+};
+
 template <bool A_K, bool B_K, int TBM, int TBN, int WGM, int NW = 4, int PL = 3>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_split_kernel(int M, int N, int K, const float* __restrict__ A,
                                                            int64_t lda, bool vecA, const float* __restrict__ Bm,
                                                            int64_t ldb, bool vecB, float* __restrict__ C,
                                                            int64_t ldc, Epi epi, int k_chunk,
-                                                           float* __restrict__ partial) {
+                                                           float* __restrict__ partial, Scales sc) {
   epi.drop = resolve_drop(epi.drop);
+  float scale_a = 1.f, scale_b = 1.f, unscale_a = 1.f, unscale_b = 1.f;
+  if (PL == 2) {
+    int ka, kb;
+    scale_a = scale_for(fmaxf(read_amax(sc.a_amax), sc.a_floor), ka);
+    scale_b = scale_for(fmaxf(read_amax(sc.b_amax), sc.b_floor), kb);
+    unscale_a = __uint_as_float((unsigned)(127 - ka) << 23);    // |k| <= 100: both factors are normal numbers
+    unscale_b = __uint_as_float((unsigned)(127 - kb) << 23);
+  }
   constexpr int NT = 64 * NW;                            // threads: NW waves, each a 64 x 64 output tile
   constexpr int WGN = NW / WGM;
   constexpr int TM = TBM / WGM / 32, TN = TBN / WGN / 32;
@@ -544,13 +600,24 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_split_kernel(int M, int N, in
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
       const int g = t + NT * q;
-      if (GA % NT == 0 || g < GA) split_store8<PL>(S, TBM, A_K ? g / SKG : g % TBM, A_K ? g % SKG : g / TBM, va[q]);
+      if (GA % NT == 0 || g < GA) {
+        if (PL == 2)
+          split_store8_f16(reinterpret_cast<_Float16*>(S), TBM, A_K ? g / SKG : g % TBM, A_K ? g % SKG : g / TBM, va[q],
+                           scale_a);
+        else
+          split_store8<PL == 2 ? 1 : PL>(S, TBM, A_K ? g / SKG : g % TBM, A_K ? g % SKG : g / TBM, va[q]);
+      }
     }
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
       const int g = t + NT * q;
-      if (GB % NT == 0 || g < GB)
-        split_store8<PL>(S + PL * TBM * SROW, TBN, B_K ? g / SKG : g % TBN, B_K ? g % SKG : g / TBN, vb[q]);
+      if (GB % NT == 0 || g < GB) {
+        if (PL == 2)
+          split_store8_f16(reinterpret_cast<_Float16*>(S + PL * TBM * SROW), TBN, B_K ? g / SKG : g % TBN,
+                           B_K ? g % SKG : g / TBN, vb[q], scale_b);
+        else
+          split_store8<PL == 2 ? 1 : PL>(S + PL * TBM * SROW, TBN, B_K ? g / SKG : g % TBN, B_K ? g % SKG : g / TBN, vb[q]);
+      }
     }
   };
   const int lr = lane & 31, lk = lane >> 5;
@@ -578,6 +645,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_split_kernel(int M, int N, in
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         f32x16 c = acc[i][j];
+        if (PL == 2) {                              // fp16 planes: lo*hi, hi*lo, hi*hi
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][1]), __builtin_bit_cast(f16x8, b[j][0]), c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][0]), __builtin_bit_cast(f16x8, b[j][1]), c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][0]), __builtin_bit_cast(f16x8, b[j][0]), c, 0, 0, 0);
+          acc[i][j] = c;
+          continue;
+        }
         if (PL == 3) {                              // small terms first
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PL - 1], b[j][0], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][PL - 1], c, 0, 0, 0);
@@ -590,6 +664,16 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_split_kernel(int M, int N, in
       }
     if (STORE) {
       store_stage(Snext, va, vb);
+      if (PL == 2) {
+        constexpr int NMFMA = TM * TN * 3;
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);   // the fragment reads first
+#pragma unroll
+        for (int q = 0; q < NMFMA; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);             // six VALU of the split
+          if (q % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // an LDS write now and then
+        }
+      }
       if (PL == 3) {
         constexpr int NMFMA = TM * TN * 6;
         __builtin_amdgcn_sched_group_barrier(0x100, 3 * (TM + TN), 0);   // the fragment reads first
@@ -646,6 +730,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_split_kernel(int M, int N, in
     multiply(S1, no{}, S0, xa, xb);
   } else {
     multiply(S0, no{}, S1, xa, xb);
+  }
+  if (PL == 2) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] * unscale_a) * unscale_b;
   }
   tile_epilogue<TM, TN, true>(acc, reinterpret_cast<float*>(smem_raw), M, N, m0, n0, wm, wn, C, ldc, epi, partial);
 }
@@ -986,6 +1078,7 @@ struct Plan {
 };
 
 static int g_gemm_mode = CTR_GEMM_SPLIT_BF16;
+static int g_f16_split = 1;   // calls that bring both operands' maxima take the two-term fp16 split (split mode only)
 
 static Plan make_plan(int M, int N, int K, bool wide_ok) {
   Plan p;
@@ -1033,6 +1126,12 @@ extern "C" int ctr_set_gemm_mode(int mode) {
 
 extern "C" int ctr_get_gemm_mode(void) { return g_gemm_mode; }
 
+extern "C" int ctr_set_gemm_f16_split(int on) {
+  const int prev = g_f16_split;
+  g_f16_split = on ? 1 : 0;
+  return prev;
+}
+
 // Diagnostic: resident blocks per CU the runtime grants the 128x128 split-bf16 tile kernel (it is written
 // for two; one means its two-blocks-per-CU overlap of split work and matrix-core work is not happening).
 extern "C" int ctr_gemm_split_blocks_per_cu(void) {
@@ -1045,6 +1144,37 @@ extern "C" int ctr_gemm_split_blocks_per_cu(void) {
 }
 
 namespace ctr {
+// *out = max(*out, max |X[r, c]|) over a [rows, cols] view (leading dimension ld): the largest magnitude of a GEMM
+// operand, for producers that do not raise it themselves.  V4: 16 bytes per lane.
+template <bool V4>
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ X, int64_t ld, int64_t rows, int cols,
+                                                    float* __restrict__ out) {
+  constexpr int W = V4 ? 4 : 1;
+  const int cw = (cols + W - 1) / W;
+  const int64_t total = rows * cw;
+  float m = 0.f;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = q / cw;
+    const int c = (int)(q - r * cw) * W;
+    if (V4) {
+      const float4 v = *reinterpret_cast<const float4*>(X + r * ld + c);
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    } else {
+      m = fmaxf(m, fabsf(X[r * ld + c]));
+    }
+  }
+  raise_amax(out, m);
+}
+
+void launch_absmax(const float* X, int64_t ld, int64_t rows, int cols, float* out, hipStream_t st) {
+  const bool v4 = cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)X % 16) == 0;
+  const int64_t total = rows * (v4 ? cols / 4 : cols);
+  const int64_t b = cdiv(total, 256 * 4);
+  const unsigned blocks = (unsigned)(b < 1 ? 1 : b > 2048 ? 2048 : b);
+  if (v4) hipLaunchKernelGGL(absmax_kernel<true>, dim3(blocks), dim3(256), 0, st, X, ld, rows, cols, out);
+  else hipLaunchKernelGGL(absmax_kernel<false>, dim3(blocks), dim3(256), 0, st, X, ld, rows, cols, out);
+}
+
 // out[k][n] = in[n][k]: a weight matrix stored k-contiguous becomes n-contiguous (32x32 tiles through LDS)
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int64_t ldi, int N, int K,
                                                        float* __restrict__ out, int64_t ldo) {
@@ -1094,7 +1224,14 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
   e.mask_src = nullptr; e.mask_ld = 0; e.mask_scale = 1.f;
   e.fm.on = 0; e.fm.E = e.fm.cols = 0; e.fm.eshift = -1;
   e.fm.g1 = e.fm.g2 = e.fm.s = e.fm.z = nullptr; e.fm.g1_ld = e.fm.g2_ld = e.fm.z_ld = 0;
+  e.amax_out = nullptr;
+  Scales sc;
+  sc.a_amax = sc.b_amax = nullptr; sc.a_floor = sc.b_floor = 0.f;
   if (epi) {
+    e.amax_out = epi->c_amax_out;
+    sc.a_amax = epi->a_amax; sc.b_amax = epi->b_amax;
+    sc.a_floor = epi->a_amax_floor > 0.f ? epi->a_amax_floor : 0.f;
+    sc.b_floor = epi->b_amax_floor > 0.f ? epi->b_amax_floor : 0.f;
     e.bias = epi->bias; e.relu = epi->relu; e.accumulate = epi->accumulate;
     e.drop = make_drop(epi->dropout);
     e.mask_src = epi->mask_src; e.mask_ld = epi->mask_ld; e.mask_scale = epi->mask_scale;
@@ -1141,6 +1278,7 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
       if (trans_b) { if (nc == 32) SK(2, true); else if (nc == 64) SK(4, true); else SK(8, true); }
       else { if (nc == 32) SK(2, false); else if (nc == 64) SK(4, false); else SK(8, false); }
 #undef SK
+      if (e.amax_out) launch_absmax(C, ldc, M, N, e.amax_out, st);   // this kernel does not track its output's maximum
       CTR_LAUNCH_CHECK();
       return CTR_OK;
     }
@@ -1170,6 +1308,8 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
   const bool vecA = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0);
   const bool vecB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
   const dim3 grid(p.tiles_n, p.tiles_m, p.splits), block(256);
+  // both operands' largest magnitudes are known: the two-term fp16 split (half the matrix-core work of the bf16 one)
+  const bool use_f16 = g_gemm_mode == CTR_GEMM_SPLIT_BF16 && g_f16_split && sc.a_amax && sc.b_amax;
 #define LAUNCH_SPLIT(AK, BK_, TBM, TBN, WGM, NW_, PL_)                                                      \
   do {                                                                                                      \
     const size_t lds_ = split_lds_bytes(TBM, TBN, PL_);                                                     \
@@ -1177,11 +1317,12 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
       CTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<AK, BK_, TBM, TBN, WGM, NW_, PL_>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));                  \
     hipLaunchKernelGGL((gemm_split_kernel<AK, BK_, TBM, TBN, WGM, NW_, PL_>), grid, dim3(64 * NW_), lds_, st, M, N, K, \
-                       A, lda, vecA, B, ldb, vecB, C, ldc, e, p.k_chunk, partial);                          \
+                       A, lda, vecA, B, ldb, vecB, C, ldc, e, p.k_chunk, partial, sc);                      \
   } while (0)
 #define LAUNCH3(AK, BK_, TBM, TBN, WGM)                                                                     \
   do {                                                                                                      \
-    if (g_gemm_mode == CTR_GEMM_SPLIT_BF16) LAUNCH_SPLIT(AK, BK_, TBM, TBN, WGM, 4, 3);                     \
+    if (use_f16) LAUNCH_SPLIT(AK, BK_, TBM, TBN, WGM, 4, 2);                                                \
+    else if (g_gemm_mode == CTR_GEMM_SPLIT_BF16) LAUNCH_SPLIT(AK, BK_, TBM, TBN, WGM, 4, 3);                \
     else if (g_gemm_mode == CTR_GEMM_BF16) LAUNCH_SPLIT(AK, BK_, TBM, TBN, WGM, 4, 1);                      \
     else                                                                                                    \
       hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, TBM, TBN, WGM>), grid, block, 0, st, M, N, K, A, lda, vecA, B,  \
@@ -1189,7 +1330,8 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
   } while (0)
 #define LAUNCH_WIDE(AK, BK_)                                                                                 \
   do {                                                                                                      \
-    if (g_gemm_mode == CTR_GEMM_BF16) LAUNCH_SPLIT(AK, BK_, 128, 256, 2, 8, 1);                             \
+    if (use_f16) LAUNCH_SPLIT(AK, BK_, 128, 256, 2, 8, 2);                                                  \
+    else if (g_gemm_mode == CTR_GEMM_BF16) LAUNCH_SPLIT(AK, BK_, 128, 256, 2, 8, 1);                        \
     else LAUNCH_SPLIT(AK, BK_, 128, 256, 2, 8, 3);                                                          \
   } while (0)
 #define LAUNCH(AK, BK_)                                    \
@@ -1212,7 +1354,40 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
     const int64_t blocks = cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, partial, p.splits, M, N,
                        C, ldc, e);
+    if (e.amax_out) launch_absmax(C, ldc, M, N, e.amax_out, st);
   }
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_absmax(const float* X, int64_t ld, int64_t rows, int cols, float* out, void* stream) {
+  CTR_REQUIRE(rows >= 0 && cols >= 0 && ld >= cols, "ctr_absmax: bad size");
+  if (rows == 0 || cols == 0) return CTR_OK;
+  CTR_REQUIRE(X && out, "ctr_absmax: null pointer");
+  launch_absmax(X, ld, rows, cols, out, (hipStream_t)stream);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+namespace ctr {
+// a block walks slices of 4096 floats of tensor blockIdx.y
+__global__ __launch_bounds__(256) void absmax_tensors_kernel(const float* __restrict__ flat,
+                                                            const int64_t* __restrict__ offsets,
+                                                            const int64_t* __restrict__ counts, float* __restrict__ out) {
+  const int64_t off = offsets[blockIdx.y], n = counts[blockIdx.y];
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(flat[off + i]));
+  raise_amax(out + (int64_t)blockIdx.y * CTR_AMAX_FLOATS, m);
+}
+}  // namespace ctr
+
+extern "C" int ctr_absmax_tensors(const float* flat, const int64_t* offsets, const int64_t* counts, int n_tensors,
+                                  float* out, void* stream) {
+  CTR_REQUIRE(n_tensors >= 0 && n_tensors <= 65535, "ctr_absmax_tensors: bad tensor count");
+  if (n_tensors == 0) return CTR_OK;
+  CTR_REQUIRE(flat && offsets && counts && out, "ctr_absmax_tensors: null pointer");
+  hipLaunchKernelGGL(absmax_tensors_kernel, dim3(64, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, flat,
+                     offsets, counts, out);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
@@ -1294,6 +1469,13 @@ __global__ __launch_bounds__(256) void wgrad_colsum_partial(const float* __restr
 
 extern "C" int ctr_dense_wgrad(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
                                float* dW, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+  return ctr_dense_wgrad_scaled(M, N, K, A, lda, B, ldb, dW, db, nullptr, 0.f, nullptr, workspace, workspace_bytes,
+                                stream);
+}
+
+extern "C" int ctr_dense_wgrad_scaled(int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                                      float* dW, float* db, const float* a_amax, float a_amax_floor,
+                                      const float* b_amax, void* workspace, size_t workspace_bytes, void* stream) {
   CTR_REQUIRE(M > 0 && N > 0 && K > 0, "ctr_dense_wgrad: sizes must be positive");
   CTR_REQUIRE(A && B && dW, "ctr_dense_wgrad: null pointer");
   CTR_REQUIRE(lda >= M && ldb >= N, "ctr_dense_wgrad: leading dimension too small");
@@ -1304,7 +1486,10 @@ extern "C" int ctr_dense_wgrad(int M, int N, int K, const float* A, int64_t lda,
   }
   hipStream_t st = (hipStream_t)stream;
   if (!wgrad_streams(M, N, K)) {
-    const int rc = ctr_gemm_f32(1, 0, M, N, K, A, lda, B, ldb, dW, N, nullptr, workspace, workspace_bytes, stream);
+    ctr_epilogue_t ep = {};
+    ep.mask_scale = 1.f;
+    ep.a_amax = a_amax; ep.a_amax_floor = a_amax_floor; ep.b_amax = b_amax;
+    const int rc = ctr_gemm_f32(1, 0, M, N, K, A, lda, B, ldb, dW, N, &ep, workspace, workspace_bytes, stream);
     if (rc != CTR_OK || !db) return rc;
     // bias gradient: fixed-order column sums of B (the slab region is free again: same stream)
     const int nchunks = wgrad_colsum_chunks(K);

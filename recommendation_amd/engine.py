@@ -217,9 +217,17 @@ class EmbedFront:
         self.oor_count = None     # optional device int32[1]: the standard lookup counts out-of-range ids here
 
     def forward(self, idx, x_cont, *, z_out, cont_tail=False, cont_w=None, first_out=None, s_out=None,
-                second_out=None, drop_first=None, drop_second=None, oor_count=None):
+                second_out=None, drop_first=None, drop_second=None, oor_count=None, amax_out=None):
+        """amax_out (optional largest-magnitude record the caller zeroed): raised to the largest magnitude of what
+        this call writes to z_out (the standard lookup does it inside the gather; the other forms pay one pass)."""
         t, E = self.t, self.E
         want_fm = first_out is not None or s_out is not None or second_out is not None
+        if amax_out is not None and (self.mode != 'S' or isinstance(idx, Bags)):
+            self.forward(idx, x_cont, z_out=z_out, cont_tail=cont_tail, cont_w=cont_w, first_out=first_out, s_out=s_out,
+                         second_out=second_out, drop_first=drop_first, drop_second=drop_second, oor_count=oor_count)
+            width = self.N * E + (self.C if cont_tail else 0)
+            ops.absmax(z_out[:, :width], amax_out)
+            return
         if isinstance(idx, Bags):
             if self.mode != 'S':
                 raise ValueError('multi-hot bags are defined for the standard lookup (mode S)')
@@ -235,7 +243,7 @@ class EmbedFront:
             ops.embed_fwd(t.weight, t.row_offset, idx, x_cont, cont_w if self.cont_embed else None, E=E,
                           z_out=z_out, cont_tail=cont_tail, first_out=first_out, s_out=s_out,
                           second_out=second_out, drop_first=drop_first, drop_second=drop_second,
-                          oor_count=oor_count if oor_count is not None else self.oor_count)
+                          oor_count=oor_count if oor_count is not None else self.oor_count, amax_out=amax_out)
             return
         if z_out is None:
             raise ValueError('R-mode needs the dense Z buffer')
@@ -306,18 +314,62 @@ class Tower:
         self._chain = None
         self._bwd_chain = None
         self._tail_wgrad = None
+        self.am = None          # largest magnitudes of the products' operands (enable_amax)
+        self._x_amax = None
         # chain backward + its two weight gradients in one launch (ops.tail_bwd_fused): 15 us less kernel time at
         # B = 65536 but 3 % more step time, because the weight-gradient half then sits on the main stream ahead of the
         # activation-gradient GEMMs instead of beside the embedding backward on the side stream - off by default
         self.fuse_tail = os.environ.get('CTR_FUSE_TAIL', '0') == '1'
 
-    def forward(self, x, acts, drops, ws):
-        """x: [B, >= d_in]; acts[i]: output buffer of layer i ([B, L_i] views)."""
+    def enable_amax(self, device):
+        """Keeps the largest magnitude of every operand of the tower's wide products in one device word each, so that
+        those products can run as the two-term fp16 split (ops.gemm, a_amax / b_amax): the weights' records are
+        refreshed by begin_step(), a layer's output and gradient words by the product that writes them, the input's
+        word by whoever fills the input (x_amax of forward()).  Words: [0, n) weights, [n, 2n) layer outputs,
+        [2n, 3n) gradients with respect to the layer outputs, 3n the tower's input."""
+        n = len(self.names)
+        self.am = torch.zeros((3 * n + 1) * ops.AMAX_FLOATS, dtype=torch.float32, device=device)
+        offs = [self.dense.offsets[w] for w, _ in self.names]
+        cnts = [int(np.prod(self.dense.shapes[w])) for w, _ in self.names]
+        self._am_offs = torch.tensor(offs, dtype=torch.int64, device=device)
+        self._am_cnts = torch.tensor(cnts, dtype=torch.int64, device=device)
+        self._have_g = set()
+
+    @property
+    def x_amax(self):
+        """The input's word, for the producer of x to raise (None while enable_amax() has not been called)."""
+        n = len(self.names)
+        return None if self.am is None else self.am[3 * n * ops.AMAX_FLOATS:(3 * n + 1) * ops.AMAX_FLOATS]
+
+    def begin_step(self):
+        """Start of a forward pass: every word back to zero, the weights' words recomputed (one small launch)."""
+        if self.am is None:
+            return
+        self.am.zero_()
+        ops.absmax_tensors(self.dense.flat, self._am_offs, self._am_cnts, self.am)
+        self._have_g = set()
+
+    def _slot(self, kind, i):
+        n = len(self.names)
+        k = (dict(w=0, a=n, g=2 * n)[kind] + i) * ops.AMAX_FLOATS
+        return self.am[k:k + ops.AMAX_FLOATS]
+
+    def forward(self, x, acts, drops, ws, x_amax=None):
+        """x: [B, >= d_in]; acts[i]: output buffer of layer i ([B, L_i] views).  x_amax: the word holding max |x|
+        (self.x_amax, raised by the producer of x after begin_step()), or None."""
         h = x[:, :self.d_in]
         n = len(self.names)
         chain = self._chain_len(acts)
+        am = self.am is not None
+        self._x_amax = x_amax if am else None
         for i, (wn, bn) in enumerate(self.names[:n - chain]):
-            ops.gemm(h, self.dense.p(wn), acts[i], bias=self.dense.p(bn), relu=True, dropout=drops[i], ws=ws)
+            kw = {}
+            if am:
+                kw['amax_out'] = self._slot('a', i)
+                a_in = x_amax if i == 0 else self._slot('a', i - 1)
+                if a_in is not None:
+                    kw.update(a_amax=a_in, b_amax=self._slot('w', i))
+            ops.gemm(h, self.dense.p(wn), acts[i], bias=self.dense.p(bn), relu=True, dropout=drops[i], ws=ws, **kw)
             h = acts[i]
         if chain:
             k = n - chain
@@ -351,6 +403,13 @@ class Tower:
         if not g_last_masked:
             ops.relu_mask_apply(g_last, acts[n - 1], scale[n - 1])
         g = g_last
+        am = self.am is not None
+        n_fwd_gemm = n - self._chain_len(acts)          # layers whose output word the forward pass raised
+
+        def in_amax(i):                                  # word of layer i's input, or None
+            if not am:
+                return None
+            return self._x_amax if i == 0 else (self._slot('a', i - 1) if i - 1 < n_fwd_gemm else None)
         # the last two activation gradients in one chained launch when the widths are covered
         chained = 0
         tail_done = False
@@ -369,18 +428,30 @@ class Tower:
         # activation gradients first (they are what the rest of the step waits for) ...
         gs = [None] * n
         gs[n - 1] = g_last
+        if am:
+            # the gradient that enters the first wide product comes from a kernel that does not track its maximum
+            # (output unit, chained tail): one pass over it
+            top = n - 1 - chained
+            ops.absmax(g_last if top == n - 1 else gbufs[top], self._slot('g', top))
+            self._have_g.add(top)
         for i in range(n - 1, -1, -1):
             wn = self.names[i][0]
+            kw = {}
+            if am and i in self._have_g:
+                kw.update(a_amax=self._slot('g', i), b_amax=self._slot('w', i))
             if i > 0:
                 if chained:
                     chained -= 1
                 else:
+                    if am:
+                        kw['amax_out'] = self._slot('g', i - 1)
+                        self._have_g.add(i - 1)
                     ops.gemm(gs[i], self.dense.p(wn), gbufs[i - 1], trans_b=True, mask_src=acts[i - 1],
-                             mask_scale=scale[i - 1], ws=ws)
+                             mask_scale=scale[i - 1], ws=ws, **kw)
                 gs[i - 1] = gbufs[i - 1]
             elif dx is not None:
                 ops.gemm(gs[0], self.dense.p(wn), dx[:, :self.d_in], trans_b=True, accumulate=accumulate_dx,
-                         fm_bwd=dx_fm, ws=ws)
+                         fm_bwd=dx_fm, ws=ws, **kw)
         # ... then the weight gradients: dW = h_in^T g, db.  With `side` (a Session) they go to its side stream
         # and overlap whatever the caller launches next; the caller joins before the dense optimizer.
         ctx = side.side_stream() if side is not None else contextlib.nullcontext()
@@ -399,12 +470,17 @@ class Tower:
                 wn, bn = self.names[i]
                 gext = self.dense.g_with_bias_row(wn, bn) if ext is not None and ext[i] is not None else None
                 K = self.dense.shapes[wn][0]
+                kw = {}
+                if am and i in self._have_g and in_amax(i) is not None:
+                    kw = dict(x_amax=in_amax(i), g_amax=self._slot('g', i))
                 if gext is not None and (K + 128) // 128 == (K + 127) // 128:
                     # db falls out of the product as its last row (only where that row fits the last 128-row tile)
-                    ops.dense_wgrad(ext[i], gs[i], gext, None, ws=wws)
+                    if kw:
+                        kw['x_amax_floor'] = 1.0                   # the column of ones
+                    ops.dense_wgrad(ext[i], gs[i], gext, None, ws=wws, **kw)
                     continue
                 h_in = x[:, :self.d_in] if i == 0 else acts[i - 1]
-                ops.dense_wgrad(h_in, gs[i], self.dense.g(wn), self.dense.g(bn).reshape(-1), ws=wws)
+                ops.dense_wgrad(h_in, gs[i], self.dense.g(wn), self.dense.g(bn).reshape(-1), ws=wws, **kw)
 
     def _tail_wgrad_ok(self, acts, gs):
         if self._tail_wgrad is None:

@@ -141,7 +141,17 @@ def get_checkpoint_state(directory):
     return full if os.path.exists(full + '.safetensors') or os.path.exists(full + '.manifest.json') else None
 
 
-# Lifetime of captured graphs.  A graph owns no memory here (_capture asserts that nothing is allocated while
+# Lifetime of captured graphs.
+# What went wrong before: a process that captured many models in turn died with SIGSEGV inside hipGraphLaunch at a
+# replay of a freshly captured graph, whenever executables of earlier models had been destroyed - also when they were
+# destroyed with the device idle before and after.  The native stack (tools/repro/segv_trace.c) ends four frames below
+# at::cuda::CUDAGraph::replay inside libamdhip64, in a loop that walks an array of stream objects by an index with no
+# bound and dereferences the element (mov 0x1a8(%rax),%rdi with %rax = array[i]): the launch of an executable with
+# parallel branches picks its extra streams from a runtime-wide pool, and destroying another executable with
+# branches leaves that pool shorter than the survivor needs.  A graph with a single chain of nodes needs no extra
+# stream and never enters that loop.  So captured steps are single-chain graphs (the side stream is switched off
+# while capturing), and their executables can be destroyed.
+# A graph owns no memory here (_capture asserts that nothing is allocated while
 # capturing; every buffer it points at belongs to its model or the session).  A graph executable is never destroyed
 # by the garbage collector: a model that is closed or collected hands its graphs - together with the static input
 # buffers, the private side stream and the events their nodes refer to - to its Session, which destroys them at a
@@ -569,15 +579,20 @@ class CTRModel(GraphOwner):
             graph = torch.cuda.CUDAGraph()
             step0 = self.global_step
             self._indirect = (step_w, lr_w)
+            # The captured step is one chain of launches: no second stream inside a graph.  An executable with
+            # parallel branches takes streams from a pool inside the HIP runtime when it is launched, and destroying
+            # another such executable shrinks that pool under it (see the note above _capture).
+            side_was = self.session.side_enabled
+            self.session.side_enabled = False
             try:
-                with self.session.private_side() as side_objs:
-                    _capture(graph, lambda: self.train_step(s_idx, s_xc, s_yy), self.session)
+                _capture(graph, lambda: self.train_step(s_idx, s_xc, s_yy), self.session)
             finally:
+                self.session.side_enabled = side_was
                 self._indirect = None
                 self.global_step = step0           # the capture ran no kernel and does not count as a step
-            self._train_graphs[B] = (graph, s_idx, s_xc, s_yy, step_w, lr_w, side_objs)
+            self._train_graphs[B] = (graph, s_idx, s_xc, s_yy, step_w, lr_w)
             return loss
-        graph, s_idx, s_xc, s_yy, step_w, lr_w, _ = entry
+        graph, s_idx, s_xc, s_yy, step_w, lr_w = entry
         s_idx.copy_(idx)
         s_xc.copy_(xc)
         s_yy.copy_(yy)
@@ -698,6 +713,23 @@ class CTRModel(GraphOwner):
 
     def _backward(self, idx, xc, bufs):
         raise NotImplementedError
+
+    def _x_amax_kw(self, x0):
+        """Keyword arguments for front.forward(): the tower's input word, raised by the front end where it can
+        (engine.EmbedFront); the sharded front ends do not take it, the word is then raised by _x_amax_after()."""
+        t = getattr(self, 'tower', None)
+        if t is None or t.x_amax is None:
+            return {}
+        if isinstance(self.front, EmbedFront):
+            return dict(amax_out=t.x_amax)
+        return {}
+
+    def _x_amax_after(self, x0, width):
+        """After front.forward(): raises the tower's input word by one pass over x0[:, :width] when the front end did
+        not do it itself (sharded tables)."""
+        t = getattr(self, 'tower', None)
+        if t is not None and t.x_amax is not None and not isinstance(self.front, EmbedFront):
+            ops.absmax(x0[:, :width], t.x_amax)
 
     def _dz_route(self, B):
         """Extra keyword arguments for ops.embed_bwd_dz when the front end wants dZ in its exchange layout."""

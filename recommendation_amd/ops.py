@@ -147,7 +147,9 @@ class Workspace:
 @_timed
 def embed_fwd(tables, row_offset, idx, x_cont=None, cont_w=None, *, E, z_out=None, cont_tail=False,
               first_out=None, s_out=None, second_out=None, drop_first=None, drop_second=None,
-              oor_count=None):
+              oor_count=None, amax_out=None):
+    """amax_out (optional largest-magnitude record, AMAX_FLOATS floats zeroed by the caller): raised to the largest
+    magnitude written to z_out."""
     B, F = idx.shape
     C_ = 0 if x_cont is None else x_cont.shape[1]
     if idx.dtype != torch.int32 or not idx.is_contiguous():
@@ -174,11 +176,12 @@ def embed_fwd(tables, row_offset, idx, x_cont=None, cont_w=None, *, E, z_out=Non
         raise ValueError('second_out too small')
     if s_out is not None and (tuple(s_out.shape) != (B, E) or not s_out.is_contiguous()):
         raise ValueError('s_out must be contiguous [B,E]')
-    check(lib().ctr_embed_fwd(_ptr(tables, torch.float32, 'tables'), _ptr(row_offset), _ptr(idx),
-                              _ptr(x_cont, torch.float32, 'x_cont'), _ptr(cont_w, torch.float32, 'cont_w'),
-                              B, F, C_, E, zp, zld, int(bool(cont_tail)), fp, fld,
-                              _ptr(s_out, torch.float32, 's_out'), sp, sld, _dp(drop_first), _dp(drop_second),
-                              _ptr(oor_count, torch.int32, 'oor_count'), _stream()), 'ctr_embed_fwd')
+    check(lib().ctr_embed_fwd_amax(_ptr(tables, torch.float32, 'tables'), _ptr(row_offset), _ptr(idx),
+                                   _ptr(x_cont, torch.float32, 'x_cont'), _ptr(cont_w, torch.float32, 'cont_w'),
+                                   B, F, C_, E, zp, zld, int(bool(cont_tail)), fp, fld,
+                                   _ptr(s_out, torch.float32, 's_out'), sp, sld, _dp(drop_first), _dp(drop_second),
+                                   _ptr(oor_count, torch.int32, 'oor_count'), _amax_rec(amax_out, 'amax_out'),
+                                   _stream()), 'ctr_embed_fwd')
 
 
 @_timed
@@ -557,10 +560,13 @@ def get_gemm_mode():
 
 @_timed
 def gemm(A, B_, Cout, *, trans_a=False, trans_b=False, bias=None, relu=False, sigmoid=False, accumulate=False,
-         dropout=None, mask_src=None, mask_scale=1.0, fm_bwd=None, ws=None):
+         dropout=None, mask_src=None, mask_scale=1.0, fm_bwd=None, ws=None, a_amax=None, b_amax=None,
+         a_amax_floor=0.0, b_amax_floor=0.0, amax_out=None):
     """Cout[M,N] = epilogue(op(A) @ op(B_)); all three are 2-D views with contiguous last dim.
     fm_bwd (optional): dict(N, E, g_first, g_second, s, z) - the FM terms of embed_bwd_dz are added to the first N*E
-    columns of the product on its way out (ctr_fm_bwd_t; g_first / g_second already carry their keep masks)."""
+    columns of the product on its way out (ctr_fm_bwd_t; g_first / g_second already carry their keep masks).
+    a_amax / b_amax (optional largest-magnitude records of A and B, AMAX_FLOATS floats each): with both, the product runs as
+    the two-term fp16 split; amax_out: raised to max |Cout| (zero it first)."""
     M, N = Cout.shape
     ap, lda = _rows(A, 'A')
     bp, ldb = _rows(B_, 'B')
@@ -580,7 +586,11 @@ def gemm(A, B_, Cout, *, trans_a=False, trans_b=False, bias=None, relu=False, si
     epi = Epilogue(bias=None if bias is None else bias.data_ptr(), relu=2 if sigmoid else int(relu), accumulate=int(accumulate),
                    dropout=C.pointer(dropout) if dropout is not None else None,
                    mask_src=None if mask_src is None else mask_src.data_ptr(), mask_ld=mld,
-                   mask_scale=float(mask_scale))
+                   mask_scale=float(mask_scale),
+                   a_amax=None if a_amax is None else _amax_rec(a_amax, 'a_amax').value,
+                   b_amax=None if b_amax is None else _amax_rec(b_amax, 'b_amax').value,
+                   a_amax_floor=float(a_amax_floor), b_amax_floor=float(b_amax_floor),
+                   c_amax_out=None if amax_out is None else _amax_rec(amax_out, 'amax_out').value)
     if fm_bwd is not None:
         g1, g2 = fm_bwd.get('g_first'), fm_bwd.get('g_second')
         g1p, g1ld = _rows(g1, 'g_first') if g1 is not None else (None, 0)
@@ -599,8 +609,9 @@ def gemm(A, B_, Cout, *, trans_a=False, trans_b=False, bias=None, relu=False, si
 
 
 @_timed
-def dense_wgrad(x, g, dW, db=None, *, ws):
-    """dW[M,N] = x^T g (x: [K,M] view, g: [K,N] view), db[N] = column sums of g."""
+def dense_wgrad(x, g, dW, db=None, *, ws, x_amax=None, g_amax=None, x_amax_floor=0.0):
+    """dW[M,N] = x^T g (x: [K,M] view, g: [K,N] view), db[N] = column sums of g.  x_amax / g_amax: as a_amax / b_amax
+    of gemm()."""
     K, M = x.shape
     N = g.shape[1]
     xp, lda = _rows(x, 'x')
@@ -608,8 +619,42 @@ def dense_wgrad(x, g, dW, db=None, *, ws):
     if g.shape[0] != K or dW.numel() != M * N or not dW.is_contiguous() or (db is not None and db.numel() != N):
         raise ValueError('dense_wgrad shape mismatch')
     wp, wn = ws.get(lib().ctr_dense_wgrad_workspace_bytes(M, N, K))
-    check(lib().ctr_dense_wgrad(M, N, K, xp, lda, gp, ldb, _ptr(dW, torch.float32), _ptr(db, torch.float32), wp, wn,
-                                _stream()), 'ctr_dense_wgrad')
+    check(lib().ctr_dense_wgrad_scaled(M, N, K, xp, lda, gp, ldb, _ptr(dW, torch.float32), _ptr(db, torch.float32),
+                                       _amax_rec(x_amax, 'x_amax'), float(x_amax_floor), _amax_rec(g_amax, 'g_amax'),
+                                       wp, wn, _stream()), 'ctr_dense_wgrad')
+
+
+AMAX_FLOATS = 1024      # a largest-magnitude record (CTR_AMAX_FLOATS): its value is record.max()
+
+
+def _amax_rec(t, name='amax'):
+    if t is None:
+        return None
+    if t.numel() < AMAX_FLOATS or not t.is_contiguous():
+        raise ValueError('%s must be a contiguous record of %d floats' % (name, AMAX_FLOATS))
+    return _ptr(t, torch.float32, name)
+
+
+def absmax(x, out):
+    """Raises the record `out` to max |x| over a 2-D view (zero `out` first: it is only ever raised)."""
+    xp, ld = _rows(x, 'x')
+    _amax_rec(out)
+    check(lib().ctr_absmax(xp, ld, x.shape[0], x.shape[1], _ptr(out, torch.float32), _stream()), 'ctr_absmax')
+
+
+def absmax_tensors(flat, offsets, counts, out):
+    """Record i of `out` (AMAX_FLOATS floats each) is raised to max |flat[offsets[i] : offsets[i] + counts[i]]|;
+    offsets / counts: device int64."""
+    n = offsets.numel()
+    if counts.numel() != n or out.numel() < n * AMAX_FLOATS:
+        raise ValueError('absmax_tensors: offsets, counts and out disagree')
+    check(lib().ctr_absmax_tensors(_ptr(flat, torch.float32), _ptr(offsets, torch.int64), _ptr(counts, torch.int64), n,
+                                   _ptr(out, torch.float32), _stream()), 'ctr_absmax_tensors')
+
+
+def set_gemm_f16_split(on):
+    """Two-term fp16 split for products that bring both operands' maxima (default on); returns the previous setting."""
+    return bool(lib().ctr_set_gemm_f16_split(int(bool(on))))
 
 
 def tail_wgrad2_supported(ka, na, kb, nb):

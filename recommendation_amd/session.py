@@ -7,6 +7,7 @@ the GPU device, the RNG seed of the dropout streams and the scratch workspace.
 from __future__ import annotations
 
 import contextlib
+import os
 
 import torch
 
@@ -30,7 +31,8 @@ class Session:
         self._fork_ev = None
         self._join_ev = None
         self._side_open = False
-        self.side_enabled = True     # False: side_stream() is a no-op context (per-kernel timing passes)
+        # False: side_stream() is a no-op context (per-kernel timing passes, graph captures; CTR_NO_SIDE=1: experiments)
+        self.side_enabled = os.environ.get('CTR_NO_SIDE', '0') != '1'
         # captured graphs (with the static buffers, streams and events they refer to) whose model was closed or
         # collected: destroyed only at a quiescent point (drain_graphs), never from the garbage collector
         self._retired = []
@@ -77,19 +79,6 @@ class Session:
         self._side.wait_event(self._fork_ev)
         self._side_open = True
         return torch.cuda.stream(self._side)
-
-    @contextlib.contextmanager
-    def private_side(self):
-        """For a graph capture: a side stream and events of its own, so that nothing recorded into the graph is
-        ever recorded again eagerly or by another capture.  Yields the objects; the graph's owner keeps them alive."""
-        saved = (self._side, self._fork_ev, self._join_ev, self._side_open)
-        self._side = torch.cuda.Stream(self.device)
-        self._fork_ev, self._join_ev = torch.cuda.Event(), torch.cuda.Event()
-        self._side_open = False
-        try:
-            yield (self._side, self._fork_ev, self._join_ev)
-        finally:
-            self._side, self._fork_ev, self._join_ev, self._side_open = saved
 
     def side_join(self):
         """The current stream waits for everything issued to the side stream."""

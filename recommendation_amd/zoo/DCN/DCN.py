@@ -1,4 +1,6 @@
 """Deep & Cross on the HIP hot path; same class surface as the reference's DCN/DCN.py:5-132."""
+import os
+
 import torch
 
 from recommendation_amd import ops
@@ -36,6 +38,9 @@ class DCN(CTRModel):
 
     def _post_init(self):
         self.tower = Tower(self.dense, 'deep_part/deep', len(self.deep_layers))
+        if os.environ.get('CTR_GEMM_F16', '1') != '0':
+            # the tower's wide products as two-term fp16 splits: every operand's largest magnitude is tracked
+            self.tower.enable_amax(self.session.device)
         self._wn = ['cross_part/cross_w_%d' % l for l in range(self.cross_layer_num)]
         self._bn = ['cross_part/cross_b_%d' % l for l in range(self.cross_layer_num)]
 
@@ -56,11 +61,13 @@ class DCN(CTRModel):
 
     def _forward(self, idx, xc, bufs, train):
         D, n, ws = self.total_size, len(self.deep_layers), self.session.ws
-        self.front.forward(idx, xc, z_out=bufs['x0'], cont_tail=True)
+        self.tower.begin_step()
+        self.front.forward(idx, xc, z_out=bufs['x0'], cont_tail=True, **self._x_amax_kw(bufs['x0']))
+        self._x_amax_after(bufs['x0'], D)
         ops.cross_fwd(bufs['x0'], self.dense.stacked(self._wn), self.dense.stacked(self._bn),
                       bufs['stack'][:, :D], bufs['aux'], ws)
         drops = [self._drop(self.dropout, 10 + i, train) for i in range(n)]
-        self.tower.forward(bufs['x0'], bufs['acts'], drops, ws)
+        self.tower.forward(bufs['x0'], bufs['acts'], drops, ws, x_amax=self.tower.x_amax)
         ops.rowdot_fwd(bufs['stack'], self.dense.p('stack_layer/stack_w_%d' % (n - 1)).reshape(-1),
                        self.dense.p('stack_layer/stack_b_%d' % (n - 1)), bufs['logit'])
 

@@ -37,6 +37,9 @@ class DeepFM(CTRModel):
 
     def _post_init(self):
         self.tower = Tower(self.dense, 'deep_part/deep', len(self.deep_layers))
+        if os.environ.get('CTR_GEMM_F16', '1') != '0':
+            # the tower's wide products as two-term fp16 splits: every operand's largest magnitude is tracked
+            self.tower.enable_amax(self.session.device)
 
     def _alloc(self, B, bufs, dev):
         N, E, Ls = self.N, self.embed_size, self.deep_layers
@@ -56,11 +59,13 @@ class DeepFM(CTRModel):
     def _forward(self, idx, xc, bufs, train):
         N, E, n = self.N, self.embed_size, len(self.deep_layers)
         concat = bufs['concat']
+        self.tower.begin_step()
         self.front.forward(idx, xc, z_out=bufs['x0'], cont_tail=True, first_out=concat[:, :N], s_out=bufs['s'],
                            second_out=concat[:, N:N + E], drop_first=self._drop(self.dropout_fm, 1, train),
-                           drop_second=self._drop(self.dropout_fm, 2, train))
+                           drop_second=self._drop(self.dropout_fm, 2, train), **self._x_amax_kw(bufs['x0']))
+        self._x_amax_after(bufs['x0'], self.total_size)
         drops = [self._drop(self.dropout_deep, 10 + i, train) for i in range(n)]
-        self.tower.forward(bufs['x0'], bufs['acts'], drops, self.session.ws)
+        self.tower.forward(bufs['x0'], bufs['acts'], drops, self.session.ws, x_amax=self.tower.x_amax)
         ops.rowdot_fwd(concat, self.dense.p('output_unit/output_w_%d' % (n - 1)).reshape(-1),
                        self.dense.p('output_unit/output_b_%d' % (n - 1)), bufs['logit'])
 

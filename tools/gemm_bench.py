@@ -41,6 +41,10 @@ for name, M, N, K, ta, tb in shapes:
     kw = {}
     if name.endswith('m'):                      # with the relu/dropout-backward mask epilogue
         kw = dict(mask_src=mk(M, N), mask_scale=1.25)
+    if os.environ.get('F16'):                   # both operands' maxima known: the two-term fp16 split
+        am = torch.zeros(3, ops.AMAX_FLOATS, device='cuda')
+        ops.absmax(A, am[0]); ops.absmax(Bm, am[1])
+        kw.update(a_amax=am[0], b_amax=am[1], amax_out=am[2])
     for _ in range(3):
         ops.gemm(A, Bm, C, trans_a=bool(ta), trans_b=bool(tb), ws=ws, **kw)
     torch.cuda.synchronize()
@@ -52,7 +56,13 @@ for name, M, N, K, ta, tb in shapes:
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
-    print('%-6s M=%6d N=%5d K=%6d  %8.1f us  %6.1f TF' % (name, M, N, K, us, 2.0 * M * N * K / us / 1e6))
+    err = ''
+    if M * N * K <= 2 ** 33:
+        ref = (A.double().t() if ta else A.double()) @ (Bm.double().t() if tb else Bm.double())
+        if 'mask_src' in kw:
+            ref = ref * torch.where(kw['mask_src'] > 0, 1.25, 0.0)
+        err = '  relerr %.2e' % ((C.double() - ref).abs().max() / ref.abs().max()).item()
+    print('%-6s M=%6d N=%5d K=%6d  %8.1f us  %6.1f TF%s' % (name, M, N, K, us, 2.0 * M * N * K / us / 1e6, err))
 if len(sys.argv) > 1 and sys.argv[1] != 'wgrad':
     sys.exit(0)
 print('--- dense_wgrad')
