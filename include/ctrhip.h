@@ -543,7 +543,8 @@ int ctr_mlp_chain_bwd_supported(int in, int mid, int out);
 int ctr_mlp_chain_bwd(int M, int in, const float* Gin, int64_t ldgi, int mid, const float* Wb,
                       const float* Hmid, int64_t ldhm, float scale_mid, float* Gmid, int64_t ldgm, int out,
                       const float* Wa, const float* Hout, int64_t ldho, float scale_out, float* Gout,
-                      int64_t ldgo, void* stream);
+                      int64_t ldgo, float* gout_amax /* optional largest-magnitude record of Gout (ctr_epilogue_t) */,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Evaluation metrics on the device (the reference round-trips predictions to the host:

@@ -117,7 +117,7 @@ SIGNATURES = {
     'ctr_tail_bwd_fused': (i, [i, i, vp, i64, i, vp, vp, i64, f, i, vp, vp, i64, f, vp, i64, vp, vp, vp, vp, vp, sz, vp]),
     'ctr_tail_wgrad2_workspace_bytes': (sz, [i, i, i, i, i]),
     'ctr_tail_wgrad2': (i, [i, i, vp, i64, i, vp, i64, vp, vp, i, vp, i64, i, vp, i64, vp, vp, vp, sz, vp]),
-    'ctr_mlp_chain_bwd': (i, [i, i, vp, i64, i, vp, vp, i64, f, vp, i64, i, vp, vp, i64, f, vp, i64, vp]),
+    'ctr_mlp_chain_bwd': (i, [i, i, vp, i64, i, vp, vp, i64, f, vp, i64, i, vp, vp, i64, f, vp, i64, vp, vp]),
     'ctr_auc_workspace_bytes': (sz, [i64]),
     'ctr_auc': (i, [vp, vp, i64, vp, vp, vp, sz, vp]),
     'ctr_shard_route': (i, [vp, vp, vp, i, i, i, vp, vp, vp, vp]),

@@ -162,9 +162,11 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(int M, const float* 
                                                            float* __restrict__ Gm, int64_t ldgm,
                                                            const float* __restrict__ Wa,
                                                            const float* __restrict__ Ho, int64_t ldho, float scale_o,
-                                                           float* __restrict__ Go, int64_t ldgo) {
+                                                           float* __restrict__ Go, int64_t ldgo,
+                                                           float* __restrict__ go_amax) {
   extern __shared__ float Ws[];
   constexpr int IN = 16 * NTI, MID = 16 * NTM, OUT = 16 * NTO, SB = MID + 4, SA = OUT + 4;
+  float amx = 0.f;                 // largest magnitude this lane writes to Go
   float* Wbt = Ws;                 // [IN][SB]:  Wbt[k][n] = Wb[n][k]
   float* Wat = Ws + IN * SB;       // [MID][SA]: Wat[k][n] = Wa[n][k]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -222,9 +224,13 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(int M, const float* 
     for (int t = 0; t < NTO; ++t) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) go[t][r] = ho[t][r] > 0.f ? go[t][r] * scale_o : 0.f;
-      if (live) *reinterpret_cast<f32x4*>(Go + m * ldgo + 16 * t + 4 * kq) = go[t];
+      if (live) {
+        *reinterpret_cast<f32x4*>(Go + m * ldgo + 16 * t + 4 * kq) = go[t];
+        amx = fmaxf(fmaxf(amx, fmaxf(fabsf(go[t][0]), fabsf(go[t][1]))), fmaxf(fabsf(go[t][2]), fabsf(go[t][3])));
+      }
     }
   }
+  if (go_amax) raise_amax(go_amax, amx);
 }
 
 
@@ -721,7 +727,7 @@ extern "C" int ctr_mlp_chain_bwd_supported(int in, int mid, int out) {
 extern "C" int ctr_mlp_chain_bwd(int M, int in, const float* Gin, int64_t ldgi, int mid, const float* Wb,
                                  const float* Hmid, int64_t ldhm, float scale_mid, float* Gmid, int64_t ldgm, int out,
                                  const float* Wa, const float* Hout, int64_t ldho, float scale_out, float* Gout,
-                                 int64_t ldgo, void* stream) {
+                                 int64_t ldgo, float* gout_amax, void* stream) {
   CTR_REQUIRE(M >= 0, "ctr_mlp_chain_bwd: negative M");
   CTR_REQUIRE(ctr_mlp_chain_bwd_supported(in, mid, out), "ctr_mlp_chain_bwd: widths %d -> %d -> %d not covered", in, mid,
               out);
@@ -739,7 +745,7 @@ extern "C" int ctr_mlp_chain_bwd(int M, int in, const float* Gin, int64_t ldgi, 
   hipStream_t st = (hipStream_t)stream;
 #define CB(A_, B_, C_)                                                                                         \
   hipLaunchKernelGGL((mlp_chain_bwd_kernel<A_, B_, C_>), dim3(blocks), dim3(256), lds, st, M, Gin, ldgi, in_scalar, Wb, \
-                     Hmid, ldhm, scale_mid, Gmid, ldgm, Wa, Hout, ldho, scale_out, Gout, ldgo)
+                     Hmid, ldhm, scale_mid, Gmid, ldgm, Wa, Hout, ldho, scale_out, Gout, ldgo, gout_amax)
   if (in == 32) CB(2, 4, 8);
   else CB(1, 2, 4);
 #undef CB

@@ -423,15 +423,18 @@ class Tower:
                 tail_done = True
             else:
                 ops.mlp_chain_bwd(g_last, self.dense.p(self.names[n - 1][0]), acts[n - 2], scale[n - 2], gbufs[n - 2],
-                                  self.dense.p(self.names[n - 2][0]), acts[n - 3], scale[n - 3], gbufs[n - 3])
+                                  self.dense.p(self.names[n - 2][0]), acts[n - 3], scale[n - 3], gbufs[n - 3],
+                                  g_out_amax=self._slot('g', n - 3) if am else None)
+                if am:
+                    self._have_g.add(n - 3)
             chained = 2
         # activation gradients first (they are what the rest of the step waits for) ...
         gs = [None] * n
         gs[n - 1] = g_last
-        if am:
+        top = n - 1 - chained
+        if am and top not in self._have_g:
             # the gradient that enters the first wide product comes from a kernel that does not track its maximum
-            # (output unit, chained tail): one pass over it
-            top = n - 1 - chained
+            # (output unit, fused tail): one pass over it
             ops.absmax(g_last if top == n - 1 else gbufs[top], self._slot('g', top))
             self._have_g.add(top)
         for i in range(n - 1, -1, -1):

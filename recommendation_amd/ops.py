@@ -401,8 +401,9 @@ def mlp_chain_bwd_supported(w_in, w_mid, w_out):
 
 
 @_timed
-def mlp_chain_bwd(g_in, Wb, h_mid, scale_mid, g_mid, Wa, h_out, scale_out, g_out):
-    """g_mid = (g_in Wb^T) masked by h_mid, g_out = (g_mid Wa^T) masked by h_out (relu/dropout masks)."""
+def mlp_chain_bwd(g_in, Wb, h_mid, scale_mid, g_mid, Wa, h_out, scale_out, g_out, g_out_amax=None):
+    """g_mid = (g_in Wb^T) masked by h_mid, g_out = (g_mid Wa^T) masked by h_out (relu/dropout masks).
+    g_out_amax: optional largest-magnitude record of g_out (zeroed by the caller)."""
     M, n_in = g_in.shape
     mid, out = Wb.shape[0], Wa.shape[0]
     if Wb.shape[1] != n_in or Wa.shape[1] != mid or not Wb.is_contiguous() or not Wa.is_contiguous():
@@ -416,8 +417,8 @@ def mlp_chain_bwd(g_in, Wb, h_mid, scale_mid, g_mid, Wa, h_out, scale_out, g_out
     ho, ldho = _rows(h_out, 'h_out')
     go, ldgo = _rows(g_out, 'g_out')
     check(lib().ctr_mlp_chain_bwd(M, n_in, gp, ldgi, mid, _ptr(Wb, torch.float32), hm, ldhm, float(scale_mid), gm, ldgm,
-                                  out, _ptr(Wa, torch.float32), ho, ldho, float(scale_out), go, ldgo, _stream()),
-          'ctr_mlp_chain_bwd')
+                                  out, _ptr(Wa, torch.float32), ho, ldho, float(scale_out), go, ldgo,
+                                  _amax_rec(g_out_amax, 'g_out_amax'), _stream()), 'ctr_mlp_chain_bwd')
 
 
 @_timed
