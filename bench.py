@@ -1,13 +1,18 @@
 #!/usr/bin/env python
-"""Headline benchmark: DeepFM training step on Criteo-Kaggle-shape synthetic data (and, at N = 1, the DCN step at
-the Criteo-1TB per-GPU share beside it).
+"""Headline benchmark: DeepFM training step on Criteo-Kaggle-shape synthetic data.  At N = 1 the same line also
+carries, under `legs`, the other workloads of the measurement plan, each with its own `config.workload`: the DCN step
+at the Criteo-1TB per-GPU share, DeepFM with uniform ids and at batch 4096 / 16384, PNN (inner, outer) and AFM
+(reference attention, attention over the pairs) over 39 fields at batch 65536, DIN at history length 200 (H = 32, 128)
+and ESMM.
 
   python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N ...          (starts N ranks under torch.distributed.run itself when WORLD_SIZE is unset)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path (embedding gather + FM + tower forward, loss, backward,
-sorted segment-reduce + sparse Adam, dense Adam) over one batch that already sits in HBM.
-Rank 0 prints ONE JSON line.
+sorted segment-reduce + sparse Adam, dense Adam) over one batch that already sits in HBM.  After W warm-up steps the
+block of K steps is timed REPEATS times (barrier + device synchronisation on both sides of every block); `value` comes
+from the median block, every block's time is listed under `timing`.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -15,6 +20,7 @@ import argparse
 import glob
 import json
 import os
+import subprocess
 import sys
 import time
 from types import SimpleNamespace
@@ -51,6 +57,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timers', action='store_true')
     ap.add_argument('--no-dcn', action='store_true', help='N = 1, DeepFM: skip the DCN leg reported under "dcn"')
+    ap.add_argument('--no-legs', action='store_true', help='N = 1, DeepFM: skip the other workloads reported under "legs"')
+    ap.add_argument('--repeats', type=int, default=10, help='how many times the block of --steps steps is timed')
+    ap.add_argument('--master-port', type=int, default=29511, help='rendezvous port when this script starts the ranks')
     return ap.parse_args()
 
 
@@ -166,9 +175,42 @@ def load_traffic(model):
     return out
 
 
-def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embed, shard):
-    """Builds the model, warms up, profiles per operator (untimed), then times `steps` steps.  Returns the result dict
-    (rank 0) or None."""
+def time_blocks(run_step, steps, repeats, barrier):
+    """Seconds of `repeats` blocks of `steps` steps, each between barrier()s (which synchronise the device)."""
+    out = []
+    for _ in range(max(repeats, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            run_step(i)
+        barrier()
+        out.append(time.perf_counter() - t0)
+    return out
+
+
+def timing_of(blocks, steps):
+    ms = sorted(1e3 * t / steps for t in blocks)
+    return dict(blocks=len(ms), ms_per_step_median=float(np.median(ms)), ms_per_step_min=ms[0], ms_per_step_max=ms[-1],
+                ms_per_step_all=[round(1e3 * t / steps, 4) for t in blocks])
+
+
+# flops per SAMPLE of the interaction operators that are not plain products (N rows of Z, E floats each, P product
+# units, A attention units, T history positions, H hidden width), for their fraction of the fp32 MFMA peak
+def interaction_flops(name, N, E, P=50, A=10, T=200, H=32):
+    pairs = N * (N - 1) // 2
+    table = {'pnn_inner_fwd': 2 * P * N * E, 'pnn_inner_bwd': 4 * P * N * E,
+             'afm_pair_fwd': 2 * N * N * E, 'afm_pair_bwd': 2 * N * N * E,
+             'afm_attn_fwd': pairs * (E + 2 * E * A + 2 * A + 2 * E), 'afm_attn_bwd': 3 * pairs * (E + 2 * E * A + 2 * A + 2 * E),
+             'din_attn_mlp_fwd': T * 2 * (4 * H * 80 + 80 * 40 + 40), 'din_attn_mlp_bwd': 2 * T * 2 * (4 * H * 80 + 80 * 40 + 40),
+             'din_attn_mlp_wgrad': T * 2 * (4 * H * 80 + 80 * 40 + 40)}
+    return table.get(name)
+
+
+def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embed, shard, alpha=None, light=False):
+    """Builds the model, warms up, profiles per operator (untimed), then times `steps` steps args.repeats times.
+    Returns the result dict (rank 0) or None.  light: a leg of the measurement plan - no reduced-precision timing, no
+    cold-copy yardsticks."""
+    alpha = args.alpha if alpha is None else alpha
     from recommendation_amd import ops
     from recommendation_amd.synthetic import CRITEO_1TB, CRITEO_KAGGLE, make_batches, scaled
     dev = sess.device
@@ -181,7 +223,7 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
         print('[bench] building %s: %d table rows on %d rank(s)' % (variant, sum(cards), world), file=sys.stderr, flush=True)
     model = build_model(variant, embed, shard, args.comm, sess, cards, rank, world)
     B = batch
-    batches = make_batches(cards, 13, B, 8, args.alpha, 20240601 + rank, dev)
+    batches = make_batches(cards, 13, B, 8, alpha, 20240601 + rank, dev)
     if variant.startswith('AFM'):
         batches = [(i, x.abs_().mul_(0.1), y) for i, x, y in batches]
 
@@ -212,21 +254,25 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
         ops.set_timer(None)
         profile = prof.summary()
         dom_name = max(profile, key=lambda n: profile[n]['total_ms'])
-        timer = ops.KernelTimer(only=watched | {dom_name}, pool=steps * 12)
+        timer = ops.KernelTimer(only=watched | {dom_name}, pool=steps * 12 * max(args.repeats, 1))
         ops.set_timer(timer)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        model.train_step(*batches[i % len(batches)])
-    barrier()
-    dt = time.perf_counter() - t0
+    blocks = time_blocks(lambda i: model.train_step(*batches[i % len(batches)]), steps, args.repeats, barrier)
     ops.set_timer(None)
+    eager_blocks = None
+    from recommendation_amd.model_base import GRAPH_MAX_BATCH
+    if world == 1 and B <= GRAPH_MAX_BATCH:
+        # small batches are launch-bound: run() replays the step from a captured graph there, and that is the figure
+        # of this workload (the eager time is kept beside it)
+        for i in range(2):
+            model.train_step_graphed(*batches[0])          # eager step + capture, one replay
+        eager_blocks = blocks
+        blocks = time_blocks(lambda i: model.train_step_graphed(*batches[i % len(batches)]), steps, args.repeats, barrier)
     loss = float(model._loss_dev.item())
     model.check_overflow()      # row-sharded tables: a fixed-capacity send bucket that overflowed is an error
     # the same steps once more with the tile GEMM in its opt-in reduced-precision mode (bf16 operands, one MFMA per
     # product): reported beside the headline, never as it
     bf16 = None
-    if world == 1 and not args.no_bf16_leg:
+    if world == 1 and not args.no_bf16_leg and not light:
         prev = ops.set_gemm_mode('bf16')
         try:
             for i in range(3):
@@ -243,20 +289,25 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
                              'continuing from the fp32-accurate steps above; not the headline figure')
         finally:
             ops.set_gemm_mode(prev)
-    if world > 1:
-        t = torch.tensor([dt], device='cpu' if args.comm == 'host-staged' else dev, dtype=torch.float64)
+    if world > 1:                       # every block: the slowest rank's time
+        t = torch.tensor(blocks, device='cpu' if args.comm == 'host-staged' else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        blocks = [float(v) for v in t.tolist()]
     if rank != 0:
         return None
+    dt = float(np.median(blocks))
     out = dict(value=world * B * steps / dt, unit='samples/s', steps=steps, warmup=warmup, ms_per_step=1e3 * dt / steps,
+               timing=timing_of(blocks, steps),
                config=dict(workload='%s %s shape: 13 dense + 26 sparse fields, sum(V)=%d rows, '
-                                    'embed dim %d, per-GPU batch %d, Zipf(%.2f) ids, fwd+bwd+Adam (sparse rows: '
-                                    'row-wise Adam on touched rows), dropout at the reference rates'
-                                    % (variant, shape_name, int(np.sum(cards)), embed, B, args.alpha),
+                                    'embed dim %d, per-GPU batch %d, Zipf(%.2f) ids (0 = uniform), fwd+bwd+%s (sparse rows: '
+                                    'row-wise update of touched rows), dropout at the reference rates'
+                                    % (variant, shape_name, int(np.sum(cards)), embed, B, alpha, model.OPTIMIZER),
                            global_batch=world * B,
                            parallelism='dp%d + %s-sharded tables' % (world, shard) if world > 1 else 'single'),
                final_loss=loss if np.isfinite(loss) else None)
+    if eager_blocks is not None:
+        out['step_runs_as'] = 'captured graph replay (batch <= %d, as run() does)' % GRAPH_MAX_BATCH
+        out['eager'] = dict(value=B * steps / float(np.median(eager_blocks)), timing=timing_of(eager_blocks, steps))
     if bf16 is not None:
         out['bf16_tower_mode'] = bf16
     if timer is None:
@@ -286,9 +337,12 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
     def hbm_roof(name, avg_us):
         nbytes = algo[name]
         ach = nbytes / (avg_us * 1e-6) / 1e9
-        return dict(kernel=label.get(name, name), bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=ach / HBM_PEAK_GBS, frac_of_measured_copy_peak=ach / HBM_COPY_GBS,
-                    traffic=traffic.get(sym.get(name)), avg_us=avg_us, bytes_per_launch=nbytes)
+        r = dict(kernel=label.get(name, name), bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
+                 frac=ach / HBM_PEAK_GBS, frac_of_measured_copy_peak=ach / HBM_COPY_GBS,
+                 traffic=traffic.get(sym.get(name)), avg_us=avg_us, bytes_per_launch=nbytes)
+        if r['traffic'] is not None:     # not measured in this run: read from the committed counter pass
+            r['traffic_source'] = 'committed profile profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)' % traffic['_file']
+        return r
 
     def mfma_roof(name, M, N, K, avg_us):
         # fp32-equivalent flops against the dense fp32 MFMA peak (the path's dtype).  In split mode the
@@ -296,12 +350,17 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
         # 6 * achieved / bf16 peak, reported beside it.
         ach = 2.0 * M * N * K / (avg_us * 1e-6) / 1e12
         split = gemm_mode == 1
-        r = dict(kernel=name + (' (fp32 via 3-way bf16 split, 6 bf16 MFMAs per product)' if split else ' (fp32 MFMA)'),
+        f16 = split and getattr(getattr(model, 'tower', None), 'am', None) is not None
+        per = 3.0 if f16 else 6.0
+        r = dict(kernel=name + (' (fp32 via 2-term fp16 split, 3 fp16 MFMAs per product)' if f16 else
+                                ' (fp32 via 3-way bf16 split, 6 bf16 MFMAs per product)' if split else ' (fp32 MFMA)'),
                  bound='mfma', achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
                  frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=None, avg_us=avg_us)
         if split:
-            r['bf16_pipe_frac'] = 6.0 * ach / MFMA_BF16_PEAK_TFLOPS
+            r['matrix_pipe_frac'] = per * ach / MFMA_BF16_PEAK_TFLOPS    # of the 16-bit dense MFMA peak
         return r
+
+    Nrows = F + (13 if getattr(model, 'CONT_EMBED', False) else 0)
 
     def roof_of(name):
         k = ks[name]
@@ -310,11 +369,17 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
         if name.startswith('gemm_') or name.startswith('wgrad_'):
             M, N, K = [int(v) for v in name.split('_')[1].split('x')]
             return mfma_roof(name, M, N, K, k['avg_us'])
+        fl = interaction_flops(name, Nrows, E, P=int(MODEL_ARGS[variant].get('product_size', 50)),
+                               A=int(MODEL_ARGS[variant].get('attention_size', 10)))
+        if fl:          # interaction layers formed on chip: compute-bound, against the fp32 MFMA peak
+            ach = fl * B / (k['avg_us'] * 1e-6) / 1e12
+            return dict(kernel=name, bound='mfma', achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=None, avg_us=k['avg_us'], flops_per_sample=fl)
         return dict(kernel=name, bound='hbm', achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None,
                     traffic=None, avg_us=k['avg_us'])
 
     out['roofline'] = roof_of(dom_name)
-    if variant == 'DeepFM' and world == 1 and getattr(model, 'fuse_dz', False) and dom_name.startswith('gemm_%dx%dx' % (B, D)):
+    if variant == 'DeepFM' and world == 1 and not light and getattr(model, 'fuse_dz', False) and dom_name.startswith('gemm_%dx%dx' % (B, D)):
         # the dominant launch is the dx0 product WITH dZ's FM terms in its epilogue (the 65 us dZ pass it replaced has
         # no launch any more): its duration covers both, its flops only the product.  The same product without the
         # epilogue, on the same buffers, timed here for the matrix-core fraction of the product by itself.
@@ -322,9 +387,11 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
         g0, w0 = bufs['gbufs'][0], model.dense.p('deep_part/deep_w_0')
         scratch = torch.empty_like(bufs['dx0'])
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(42)]
+        t = model.tower
+        kw = dict(a_amax=t._slot('g', 0), b_amax=t._slot('w', 0)) if t.am is not None else {}   # the step's arithmetic
         for i in range(21):
             evs[2 * i].record()
-            ops.gemm(g0, w0, scratch[:, :D], trans_b=True, ws=sess.ws)
+            ops.gemm(g0, w0, scratch[:, :D], trans_b=True, ws=sess.ws, **kw)
             evs[2 * i + 1].record()
         torch.cuda.synchronize()
         plain_us = 1e3 * float(np.mean([evs[2 * i].elapsed_time(evs[2 * i + 1]) for i in range(1, 21)]))
@@ -362,13 +429,14 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
         ach = tot_b / (tot_us * 1e-6) / 1e9
         # the same bytes as cold streaming copies, one per kernel: the time a launch of that size needs at the least
         # when it starts with the caches full of the rest of the step
-        cold = {n: cold_copy_us(algo[n], dev) for n in path}
         out['roofline_emb_path'] = dict(kernels=path, bound='hbm', bytes_per_step=tot_b, us_per_step=tot_us, achieved=ach,
                                         peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
                                         frac_of_measured_copy_peak=ach / HBM_COPY_GBS,
-                                        us={n: round(v, 2) for n, v in us.items()},
-                                        cold_copy_us={n: round(v, 2) for n, v in cold.items()},
-                                        frac_of_cold_copy=sum(cold.values()) / tot_us)
+                                        us={n: round(v, 2) for n, v in us.items()})
+        if not light:
+            cold = {n: cold_copy_us(algo[n], dev) for n in path}
+            out['roofline_emb_path'].update(cold_copy_us={n: round(v, 2) for n, v in cold.items()},
+                                            frac_of_cold_copy=sum(cold.values()) / tot_us)
         if 'embed_bwd_dz' not in path and variant == 'DeepFM':
             out['roofline_emb_path']['note'] = ('dZ (FM terms added to the tower gradient) has no launch of its own: it rides '
                                                 'the epilogue of the dx0 product (gemm_%dx%dx%d_NT)' % (B, D, 256))
@@ -402,6 +470,78 @@ def cold_copy_us(nbytes, dev, reps=5):
     return float(np.mean(ts))
 
 
+def run_din(sess, args, H, steps, warmup, B=2048, T=200):
+    """DIN training step at the Amazon-Books shape (367 982 items, 1 600 categories, history length T with lengths
+    ~U[20, T], Zipf-distributed history ids) on one GPU: eager and replayed from a captured graph."""
+    import recommendation_amd as ra
+    from recommendation_amd import ops
+    ra.enable_zoo_imports()
+    from DIN import DIN
+    items, cates, users = 367982, 1600, 603668
+    rng = np.random.default_rng(0)
+    cate_list = rng.integers(0, cates, items).astype(np.int32)
+    margs = SimpleNamespace(hidden_units=H, train_batch_size=B, test_batch_size=B, learning_rate=0.1, epoch=1)
+    m = DIN.DIN(margs, users, items, cates, cate_list)
+    m.initialize(sess, seed=1)
+    dev = sess.device
+    batches = []
+    for _ in range(4):
+        sl = rng.integers(20, T + 1, B)
+        hist = rng.zipf(1.2, (B, T)) % items
+        hist[np.arange(T)[None, :] >= sl[:, None]] = 0
+        batches.append((torch.as_tensor(rng.integers(0, items, B).astype(np.int32)).to(dev),
+                        torch.as_tensor((rng.random(B) < 0.5).astype(np.float32)).to(dev),
+                        torch.as_tensor(hist.astype(np.int32)).to(dev), torch.as_tensor(sl.astype(np.int32)).to(dev)))
+    sync = lambda: torch.cuda.synchronize()
+    for k in range(max(warmup, 2)):
+        m.train_step(*batches[k % 4], 0.1)
+    prof = ops.KernelTimer(pool=PROFILE_STEPS * 200)
+    ops.set_timer(prof)
+    for k in range(PROFILE_STEPS):
+        m.train_step(*batches[k % 4], 0.1)
+    ops.set_timer(None)
+    profile = prof.summary()
+    blocks = time_blocks(lambda i: m.train_step(*batches[i % 4], 0.1), steps, args.repeats, sync)
+    for k in range(2):
+        m.train_step_graphed(*batches[0], 0.1)          # eager step + capture, one replay
+    gblocks = time_blocks(lambda i: m.train_step_graphed(*batches[0], 0.1), steps, args.repeats, sync)
+    dt, gdt = float(np.median(blocks)), float(np.median(gblocks))
+    dom = max(profile, key=lambda n: profile[n]['total_ms'])
+    out = dict(value=B * steps / dt, unit='samples/s', ms_per_step=1e3 * dt / steps, timing=timing_of(blocks, steps),
+               graph_replay=dict(value=B * steps / gdt, ms_per_step=1e3 * gdt / steps,
+                                 note='the same step replayed from a captured graph (one batch; bit-identical arithmetic)'),
+               config=dict(workload='DIN Amazon-Books shape: %d items, %d categories, B=%d, T=%d (lengths U[20,%d]), '
+                                    'hidden_units=%d, fwd+bwd+SGD, %s attention scoring network'
+                                    % (items, cates, B, T, T, H, 'fused' if m.fused_attention else 'layer-by-layer')),
+               final_loss=float(m._loss_dev.item()),
+               kernel_ms_per_step={n: round(v['total_ms'] / PROFILE_STEPS, 4) for n, v in
+                                   sorted(profile.items(), key=lambda kv: -kv[1]['total_ms'])[:12]})
+    us = 1e3 * profile[dom]['total_ms'] / max(profile[dom]['calls'], 1)
+    fl = interaction_flops(dom, 0, 0, T=T, H=H)
+    if fl:
+        ach = fl * B / (us * 1e-6) / 1e12
+        out['roofline'] = dict(kernel=dom, bound='mfma', achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
+                               frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=None, avg_us=us, flops_per_sample=fl)
+    else:
+        out['roofline'] = dict(kernel=dom, bound='hbm', achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None,
+                               traffic=None, avg_us=us)
+    m.close()
+    return out
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks as children under torch.distributed.run (a fresh process tree,
+    started before this process touches the GPU) and relay rank 0's JSON line."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{')]
+    if lines:
+        print(lines[-1])
+    raise SystemExit(proc.returncode if proc.returncode or lines else 1)
+
+
 def main():
     args = parse()
     if not args.batch:
@@ -410,14 +550,12 @@ def main():
         args.embed = 64 if args.model == 'DCN' else 16
     if args.shard is None:
         args.shard = 'row' if args.model == 'DCN' else 'table'
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
-                             '--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...'
-                             % (args.gpus, args.gpus))
         raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
     import recommendation_amd as ra
 
@@ -434,14 +572,34 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device(dev))
     sess = ra.Session(dev, seed=11 + rank)
     res = run_model(args.model, args, sess, rank, world, dist, args.steps, args.warmup, args.batch, args.embed, args.shard)
-    dcn = None
-    if world == 1 and args.model == 'DeepFM' and not args.no_dcn:
-        # the metric names DeepFM and DCN: the DCN step at BASELINE configs[2]'s per-GPU share rides along (its own
-        # tables, its own timed region after the headline's), reported under "dcn"
-        import gc
+    import gc
+
+    def leg(fn, *a, **k):
+        """One more workload; a failure is reported in place of its numbers, never in place of the line."""
         gc.collect()
         torch.cuda.empty_cache()
-        dcn = run_model('DCN', args, sess, rank, world, dist, max(args.steps, 20), max(args.warmup, 3), 8192, 64, 'row')
+        try:
+            return fn(*a, **k)
+        except Exception as e:                       # noqa: BLE001
+            return dict(error='%s: %s' % (type(e).__name__, e))
+
+    dcn, legs = None, {}
+    full = world == 1 and args.model == 'DeepFM'
+    if full and not args.no_dcn:
+        # the metric names DeepFM and DCN: the DCN step at BASELINE configs[2]'s per-GPU share rides along (its own
+        # tables, its own timed region after the headline's), reported under "dcn"
+        dcn = leg(run_model, 'DCN', args, sess, rank, world, dist, max(args.steps, 20), max(args.warmup, 3), 8192, 64, 'row')
+    if full and not args.no_legs:
+        st, wu = max(min(args.steps, 20), 5), max(min(args.warmup, 3), 2)
+        legs['deepfm_uniform_ids'] = leg(run_model, 'DeepFM', args, sess, rank, world, dist, st, wu, args.batch, args.embed,
+                                         args.shard, alpha=0.0, light=True)
+        for b in (4096, 16384):
+            legs['deepfm_B%d' % b] = leg(run_model, 'DeepFM', args, sess, rank, world, dist, st, wu, b, args.embed,
+                                         args.shard, light=True)
+        for v in ('PNN', 'PNN_outer', 'AFM', 'AFM_pairs', 'ESMM', 'NFM'):      # BASELINE configs[3] (+ ESMM of configs[4])
+            legs[v] = leg(run_model, v, args, sess, rank, world, dist, st, wu, 65536, 16, 'table', light=True)
+        for h in (32, 128):                                                    # BASELINE configs[4]
+            legs['DIN_H%d' % h] = leg(run_din, sess, args, h, st, wu)
         gc.collect()
         torch.cuda.empty_cache()
     if rank != 0:
@@ -452,11 +610,15 @@ def main():
                value=res['value'], unit='samples/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=res['ms_per_step'], higher_is_better=True, scaling='weak', vs_baseline=None,
                dtype='f32', data='synthetic',
-               gemm_arithmetic='fp32 result from 6 bf16 MFMAs per product (exact 3-way split, fp32 accumulate; '
-                               '~1e-7 relative)')
+               gemm_arithmetic='fp32 result from 16-bit MFMAs: the tower products whose operands\' largest magnitudes '
+                               'are tracked run as a two-term fp16 split (power-of-two scaling per matrix, 3 MFMAs per '
+                               'product, ~3e-7 relative), the others as a three-term bf16 split (6 MFMAs, ~1e-7); fp32 '
+                               'accumulate')
     out.update({k: v for k, v in res.items() if k not in ('value', 'unit', 'steps', 'warmup', 'ms_per_step')})
     if dcn is not None:
         out['dcn'] = dcn
+    if legs:
+        out['legs'] = legs
     if not args.no_cpu_baseline and world == 1:
         from recommendation_amd.synthetic import CRITEO_KAGGLE
         out['cpu_baseline'] = cpu_baseline(args, CRITEO_KAGGLE)
