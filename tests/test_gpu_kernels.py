@@ -607,6 +607,72 @@ def test_afm_attention_over_pairs_fwd_bwd(ops_ws, B, N, E, A, keep):
     assert_close(dh.cpu().numpy(), th.grad.numpy(), 1e-5, 'dh')
 
 
+def test_afm_attention_over_pairs_at_the_benchmark_shape(ops_ws):
+    """B = 65536, N = 39, E = 16, A = 10 (741 pairs): forward, dZ and the parameter gradients of the rows of a
+    2048-sample slice against float64 autograd (the whole batch does not fit a float64 graph in seconds), the slice's
+    rows taken from a run over the whole batch, so that grid caps and the per-wave partial sums are exercised; the
+    parameter gradients of the whole batch against the sum of eight such slices' worth is replaced by linearity: the
+    gradients of two half-batches add up to the gradient of the batch."""
+    ops, ws = ops_ws
+    B, N, E, A = 65536, 39, 16, 10
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(39)
+    Z = torch.randn(B, N * E, generator=gen, device=DEV) * 0.5
+    W = torch.randn(E, A, generator=gen, device=DEV) * 0.4
+    b = torch.randn(A, generator=gen, device=DEV) * 0.2
+    h = torch.randn(A, generator=gen, device=DEV)
+    g = torch.randn(B, E, generator=gen, device=DEV)
+    x = torch.zeros(B, E, device=DEV)
+    ops.afm_attn_fwd(Z, W, b, h, x, N=N, E=E)
+    dz = torch.zeros(B, N * E, device=DEV)
+    dW, db, dh = torch.zeros(E, A, device=DEV), torch.zeros(A, device=DEV), torch.zeros(A, device=DEV)
+    ops.afm_attn_bwd(Z, g, W, b, h, dz, dW, db, dh, N=N, E=E, ws=ws)
+    sl = slice(30000, 32048)
+    tz = Z[sl].double().reshape(-1, N, E).cpu().requires_grad_(True)
+    tW, tb, th = [t.double().cpu().requires_grad_(True) for t in (W, b, h)]
+    ii, jj = torch.triu_indices(N, N, offset=1)
+    pw = tz[:, ii, :] * tz[:, jj, :]
+    a = torch.softmax((torch.relu(pw @ tW + tb) * th).sum(2, keepdim=True), dim=1)
+    x_ref = (a * pw).sum(1)
+    x_ref.backward(g[sl].double().cpu())
+    assert rel_err(x[sl].cpu().numpy(), x_ref.detach().numpy()) < 1e-5
+    assert_close(dz[sl].cpu().numpy(), tz.grad.numpy().reshape(-1, N * E), 1e-5, 'dz')
+    # parameter gradients: the slice alone against autograd, then additivity over the two halves of the batch
+    dWs, dbs, dhs = torch.zeros(E, A, device=DEV), torch.zeros(A, device=DEV), torch.zeros(A, device=DEV)
+    dzs = torch.zeros(2048, N * E, device=DEV)
+    ops.afm_attn_bwd(Z[sl].contiguous(), g[sl].contiguous(), W, b, h, dzs, dWs, dbs, dhs, N=N, E=E, ws=ws)
+    assert_close(dWs.cpu().numpy(), tW.grad.numpy(), 1e-5, 'dW')
+    assert_close(dbs.cpu().numpy(), tb.grad.numpy(), 1e-5, 'db')
+    assert_close(dhs.cpu().numpy(), th.grad.numpy(), 1e-5, 'dh')
+    assert torch.equal(dzs, dz[sl])
+    halves = []
+    for lo in (0, B // 2):
+        o = [torch.zeros(E, A, device=DEV), torch.zeros(A, device=DEV), torch.zeros(A, device=DEV)]
+        ops.afm_attn_bwd(Z[lo:lo + B // 2], g[lo:lo + B // 2], W, b, h, torch.zeros(B // 2, N * E, device=DEV), *o, N=N,
+                         E=E, ws=ws)
+        halves.append(o)
+    for whole, p0, p1, nm in zip((dW, db, dh), halves[0], halves[1], ('dW', 'db', 'dh')):
+        assert_close(whole.cpu().numpy(), (p0.double() + p1.double()).cpu().numpy(), 1e-5, nm)
+
+
+@pytest.mark.parametrize('B,E', [(7, 4), (300, 16), (65536, 16)])
+def test_outer_product_fwd_bwd(ops_ws, B, E):
+    """PNN's outer-product term (PNN/PNN.py:83-84): ss = s (x) s and its gradient, against float64."""
+    ops, _ = ops_ws
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(B + E)
+    s = torch.randn(B, E, generator=gen, device=DEV)
+    ss = torch.zeros(B, E * E, device=DEV)
+    ops.outer_fwd(s, ss)
+    assert torch.equal(ss.view(B, E, E), s[:, :, None] * s[:, None, :])        # one rounding per element either way
+    dss = torch.randn(B, E * E, generator=gen, device=DEV)
+    ds = torch.zeros(B, E, device=DEV)
+    ops.outer_bwd(dss, s, ds)
+    d = dss.double().view(B, E, E)
+    ref = ((d + d.transpose(1, 2)) * s.double()[:, None, :]).sum(2)
+    assert_close(ds.cpu().numpy(), ref.cpu().numpy(), 1e-5, 'ds')
+
+
 def test_bad_arguments_are_rejected(ops_ws):
     ops, ws = ops_ws
     from recommendation_amd._lib import CtrError
