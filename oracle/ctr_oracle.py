@@ -411,6 +411,18 @@ def din_forward(P, cfg, cate_list, i, hist_i, sl, j=None):
     return out
 
 
+def din_logits_all(P, cfg, cate_list, i, hist_i, sl):
+    """logits_all (DIN/DIN.py:73-89): every user row against every item through the FCN with the `_all` Dice
+    alphas -> [B, item_count].  u_emb needs the target items i (the attention query, DIN/DIN.py:44)."""
+    u_emb = din_forward(P, cfg, cate_list, i, hist_i, sl).u_emb
+    B, I = u_emb.shape[0], P['embedding/item_emb_w'].shape[0]
+    all_emb = torch.cat([P['embedding/item_emb_w'], P['embedding/cate_emb_w'][cate_list]], dim=1)
+    u_all = u_emb.unsqueeze(1).expand(B, I, u_emb.shape[1])
+    e_all = all_emb.unsqueeze(0).expand(B, I, all_emb.shape[1])
+    d3 = _din_fcn(P, u_all, e_all, 'all').reshape(B, I)
+    return torch.sigmoid(P['embedding/item_b'] + d3)
+
+
 FORWARD = dict(DeepFM=deepfm_forward, DCN=dcn_forward, NFM=nfm_forward, PNN=pnn_forward,
                AFM=afm_forward, ESMM=esmm_forward)
 # loss kind per model: 'log_loss' on y_out, or sigmoid CE applied to y_out (a probability)
@@ -534,7 +546,7 @@ def din_param_shapes(cfg, user_count, item_count, cate_count):
     for name, (i, o) in (('f1', (2 * H, 80)), ('f2', (80, 40)), ('f3', (40, 1))):
         sh['fcn/%s/kernel' % name] = (i, o)
         sh['fcn/%s/bias' % name] = (o,)
-    for tag in ('i', 'j'):
+    for tag in ('i', 'j', 'all'):
         sh['fcn/alphadice_1_%s' % tag] = (80,)
         sh['fcn/alphadice_2_%s' % tag] = (40,)
     return sh
@@ -964,6 +976,11 @@ class OracleDIN:
                               torch.as_tensor(np.asarray(hist_i)), torch.as_tensor(np.asarray(sl)),
                               j=torch.as_tensor(np.asarray(j)))
         return np.float32(out.mf_auc.item()), out.p_and_n.to(torch.float32).numpy()
+
+    def test(self, i, hist_i, sl):
+        with torch.no_grad():
+            return din_logits_all(self.P, self.cfg, self.cate_list, torch.as_tensor(np.asarray(i)),
+                                  torch.as_tensor(np.asarray(hist_i)), torch.as_tensor(np.asarray(sl))).numpy()
 
 
 def default_cfg(model, **kw):

@@ -1,12 +1,14 @@
-// Stable LSD radix sort of (uint32 key, uint32 value) pairs, 9 bits per pass, and the
-// (key, src) pair builder of the embedding backward.  Each pass is three launches:
-// per-tile digit histogram -> exclusive scan of the [tile][digit] counts -> stable scatter.
-// Stability inside a tile comes from wave-level peer masks (ballots over the digit bits)
-// plus per-wave running digit counters in LDS, so the result is bitwise reproducible.
-// Between passes the pairs travel as one uint2 per pair, and a tile is put into digit order
-// in LDS before it is written, so that neighbouring lanes store to neighbouring addresses
-// (a pass used to end in one 4-byte store per lane and array to ~500 places per tile, which
-// bound it by the number of write requests, not by bytes).
+// Stable LSD radix sort of (uint32 key, uint32 value) pairs, 9 or 10 bits per pass, and the
+// (key, src) pair builder of the embedding backward.  A pass is three launches: per-tile digit
+// histogram -> exclusive scan of the [tile][digit] counts -> stable scatter; the builder leaves
+// the first pass's histogram behind, so that pass starts at its scan.
+// Stability inside a tile: the lanes of a 64-key chunk that carry the same digit find each other
+// through a 64-bit lane mask per digit in LDS (an atomic OR of runs of neighbouring lanes, which
+// commutes), and per-wave running digit counters in LDS order the chunks; the result is bitwise
+// reproducible.  Between passes the pairs travel as one uint2 per pair, and a tile is put into
+// digit order in LDS before it is written, so that neighbouring lanes store to neighbouring
+// addresses (one 4-byte store per lane and array to ~500 places per tile is bound by the number
+// of write requests, not by bytes).
 #include "common.h"
 #include <mutex>
 

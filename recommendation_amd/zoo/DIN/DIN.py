@@ -7,7 +7,7 @@ attention over the padded history (MLP 4H -> 80 -> 40 -> 1 with sigmoids, length
 softmax, weighted sum), inference-mode batch norm, dense H, then the FCN 2H -> 80 -> 40 -> 1 with
 Dice, logits = item_b[i] + d3, sigmoid cross-entropy, plain SGD with the learning rate fed per call.
 `user_emb_w` exists in the reference but is never used (DIN/DIN.py:18,48) and is not allocated here;
-`logits_all` / test() (DIN/DIN.py:73-89,133-138) is outside the training/eval hot path."""
+`logits_all` / test() (DIN/DIN.py:73-89,133-138) runs the same FCN over every item, in item tiles."""
 import os
 from collections import OrderedDict
 
@@ -46,7 +46,7 @@ class DIN(GraphOwner):
         for name, (i, o) in (('f1', (2 * H, 80)), ('f2', (80, 40)), ('f3', (40, 1))):
             sh['fcn/%s/kernel' % name] = (i, o)
             sh['fcn/%s/bias' % name] = (o,)
-        for tag in ('i', 'j'):
+        for tag in ('i', 'j', 'all'):          # one pair of Dice alphas per branch (DIN/DIN.py:55-57,63-65,83-85)
             sh['fcn/alphadice_1_%s' % tag] = (80,)
             sh['fcn/alphadice_2_%s' % tag] = (40,)
         self.dense_shapes = sh
@@ -420,5 +420,64 @@ class DIN(GraphOwner):
         self._raise_on_bad_ids(int(self._oor.item()))
         return np.float32(self._auc_dev.item()), pn_host
 
-    def test(self, sess, uid, hist_i, sl):
-        raise NotImplementedError('logits over all items (DIN/DIN.py:73-89,133-138) is outside the hot path')
+    ITEM_TILE_ROWS = 1 << 17               # rows of [B * items-per-tile, 2H] one pass of test() materialises
+
+    def test(self, sess, uid, hist_i, sl, i=None):
+        """logits_all (DIN/DIN.py:73-89,133-138): sigmoid(item_b[n] + FCN(BN([u_emb[b], all_emb[n]]))) for every
+        user row b and every item n -> float32 [B, item_count], through the FCN's weights with the `_all` Dice alphas.
+
+        The reference's call feeds u, hist_i and sl only, but u_emb comes out of the attention whose query is the
+        target item's embedding (DIN/DIN.py:24-27,44): its session run stops on the unfed placeholder i.  Here the
+        target items are the explicit argument `i`, and leaving it out raises as that run does.  The reference also
+        tiles all_emb 512 times (DIN/DIN.py:79), which fixes its batch at 512; any B works here.  The [B, items, 2H]
+        input is formed ITEM_TILE_ROWS rows at a time."""
+        if i is None:
+            raise ValueError("DIN.test: the user vector depends on the target items (placeholder 'i' of the reference "
+                             "graph, which its own test() leaves unfed); pass i=")
+        self._ensure(sess)
+        i, hist, sl = self._dev_i32(i), self._dev_i32(hist_i), self._dev_i32(sl)
+        B, T = hist.shape
+        if i.numel() != B or sl.numel() != B:
+            raise ValueError('DIN.test: batch sizes disagree')
+        dev, H, d, ws, I = sess.device, self.H, self.dense, sess.ws, self.item_count
+        b = self._buffers(B, T)
+        self._lookup(torch.cat([i.reshape(-1), hist.reshape(-1)]), b)
+        self._user_vector(b, sl, B, T)
+        t = max(1, min(I, self.ITEM_TILE_ROWS // B))
+        R = B * t
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        half, x, xbn, f1, a1, f2, a2 = z(R, H), z(R, 2 * H), z(R, 2 * H), z(R, 80), z(R, 80), z(R, 40), z(R, 40)
+        d3, y, e, ib4, ib = z(R), z(R), z(t, H), z(t, 4), z(R, 4)
+        pair = torch.zeros(t, 2, dtype=torch.int32, device=dev)
+        out = z(B, I)
+        p = 'fcn/b1/'
+        for n0 in range(0, I, t):
+            tt = min(t, I - n0)
+            r = B * tt
+            rows = torch.arange(r, dtype=torch.int32, device=dev)
+            perm_u = torch.div(rows, tt, rounding_mode='floor').to(torch.int32)       # row -> user row b
+            perm_e = (rows - perm_u * tt).to(torch.int32)                             # row -> item n0 + n
+            ids = torch.arange(n0, n0 + tt, dtype=torch.int32, device=dev)
+            # all_emb rows of this tile: [item_emb_w[n], cate_emb_w[cate_list[n]]] (DIN/DIN.py:77)
+            ops.din_build_idx(ids, self.cate_list, I, pair)
+            ops.embed_fwd(self.tables.weight, self.tables.row_offset, pair[:tt], E=H // 2, z_out=e[:tt],
+                          oor_count=self._oor)
+            self._item_bias(ids, ib4[:tt])
+            ops.rows_gather(b['u_emb'], perm_u, r, half, F=1, E=H)
+            ops.copy2d(half[:r], x[:r, :H])
+            ops.rows_gather(e, perm_e, r, half, F=1, E=H)
+            ops.copy2d(half[:r], x[:r, H:])
+            ops.bn_infer(x[:r], xbn[:r], gamma=d.p(p + 'gamma'), beta=d.p(p + 'beta'), mean=d.p(p + 'moving_mean'),
+                         var=d.p(p + 'moving_variance'), eps=BN_EPS)
+            ops.gemm(xbn[:r], d.p('fcn/f1/kernel'), f1[:r], bias=d.p('fcn/f1/bias'), ws=ws)
+            ops.dice_fwd(f1[:r], d.p('fcn/alphadice_1_all'), a1[:r], BN_EPS)
+            ops.gemm(a1[:r], d.p('fcn/f2/kernel'), f2[:r], bias=d.p('fcn/f2/bias'), ws=ws)
+            ops.dice_fwd(f2[:r], d.p('fcn/alphadice_2_all'), a2[:r], BN_EPS)
+            ops.rowdot_fwd(a2[:r], d.p('fcn/f3/kernel').reshape(-1), d.p('fcn/f3/bias'), d3)
+            ops.rows_gather(ib4, perm_e, r, ib, F=1, E=4)
+            ops.copy2d(ib[:r, :1], d3[:r].view(r, 1), accumulate=True)                # item_b + d_layer_3_all
+            ops.loss_head(LOSS_SCE_LOGIT, d3[:r], None, y_out=y[:r])
+            ops.copy2d(y[:r].view(B, tt), out[:, n0:n0 + tt])
+        host = out.cpu().numpy()
+        self._raise_on_bad_ids(int(self._oor.item()))
+        return host

@@ -1,5 +1,6 @@
 """DIN on the HIP path vs the CPU oracle (DIN/DIN.py): train (loss, dense gradients, SGD steps on
-dense variables and on the item/category/bias tables), eval (mf_auc, p_and_n), padding-invariance."""
+dense variables and on the item/category/bias tables), eval (mf_auc, p_and_n), test (logits over all items),
+padding-invariance."""
 import numpy as np
 import pytest
 import torch
@@ -67,6 +68,25 @@ def test_din_train_and_eval_match_oracle(sess, H, B, T):
         assert abs(float(lo) - float(lg)) < 1e-5
     for k, v in m.get_params().items():
         assert rel_err(v, orc.P[k].numpy()) < 1e-5, k          # plain SGD: no amplification of the gradient's rounding
+
+
+@pytest.mark.parametrize('H,tile_rows', [(8, 1 << 17), (32, 64)])
+def test_din_logits_over_all_items_match_oracle(sess, H, tile_rows):
+    """test() (DIN/DIN.py:73-89,133-138): every user row against every item, with the `_all` Dice alphas; the second
+    case forms the [B, items, 2H] input in several item tiles with a ragged last one (40 items, 7 per tile)."""
+    m, orc, uij, _ = _setup(sess, H, seed=5)
+    u, i, _, hist, sl = uij
+    m.ITEM_TILE_ROWS = tile_rows
+    got = m.test(sess, u, hist, sl, i=i)
+    want = orc.test(i, hist, sl)
+    assert got.shape == want.shape == (len(i), 40) and got.dtype == np.float32
+    assert rel_err(got, want) < 1e-5
+    # the branch has alphas of its own: the target item's column differs from the training branch's score
+    _, pn = m.eval(sess, (u, i, i, hist, sl))
+    assert np.max(np.abs(got[np.arange(len(i)), i] - pn[:, 0])) > 1e-4
+    # fed as the reference feeds it (no target items) the call stops, as the reference's session run does
+    with pytest.raises(ValueError, match="placeholder 'i'"):
+        m.test(sess, u, hist, sl)
 
 
 def test_din_padding_positions_do_not_matter(sess):

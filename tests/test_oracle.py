@@ -173,6 +173,30 @@ def test_din_attention_masks_padding_and_auc():
     assert 0.0 <= auc <= 1.0 and pn.shape == (B, 2)
 
 
+def test_din_logits_over_all_items_reduce_to_the_scored_branch():
+    """logits_all (DIN/DIN.py:73-89) runs the FCN of the scored branch over every item with Dice alphas of its own:
+    with those alphas set equal to the `_i` ones, the target item's column is score_i (DIN/DIN.py:93)."""
+    rng = np.random.default_rng(2)
+    cfg = O.default_cfg('DIN')
+    cfg.hidden_units = 8
+    P = O.din_init_params(cfg, 10, 30, 5, seed=1)
+    for k in list(P):
+        if 'alphadice' in k and k.endswith('_i'):
+            P[k] = rng.standard_normal(P[k].shape) * 0.3
+            P[k[:-2] + '_all'] = P[k].copy()
+    P['embedding/item_b'] = rng.standard_normal(30) * 0.2
+    cate_list = rng.integers(0, 5, 30)
+    m = O.OracleDIN(cfg, cate_list, P)
+    B, T = 6, 7
+    hist, sl, i = rng.integers(0, 30, (B, T)), np.array([7, 3, 1, 5, 2, 7]), rng.integers(0, 30, B)
+    la = m.test(i, hist, sl)
+    assert la.shape == (B, 30)
+    _, pn = m.eval((None, i, i, hist, sl))
+    assert np.allclose(la[np.arange(B), i], pn[:, 0], rtol=1e-6, atol=1e-7)
+    P['fcn/alphadice_1_all'] = P['fcn/alphadice_1_all'] + 0.5
+    assert not np.allclose(O.OracleDIN(cfg, cate_list, P).test(i, hist, sl), la)
+
+
 @pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*.npz'))))
 def test_oracle_reproduces_golden(path):
     from tests.golden.make_golden import make

@@ -1,6 +1,7 @@
 """ctr_emb_sort_static (scratch built into the library, no allocation) against ctr_emb_sort (caller workspace),
-through the C ABI: bit-identical sorted pairs on two calls in a row, the second with a smaller input, and the
-size limit is enforced."""
+through the C ABI: bit-identical sorted pairs on two calls in a row, the second with a smaller input; the size
+limit is enforced; a call after the first leaves the device's free memory untouched and can be captured into a HIP
+graph (stream capture refuses an allocation or a synchronisation), whose replay sorts whatever the input holds."""
 import ctypes as C
 
 import numpy as np
@@ -59,6 +60,55 @@ def test_static_scratch_sort_matches_workspace_sort_on_two_calls_in_a_row():
     ro = torch.as_tensor(np.array([0, 3, 6, 9, 12], dtype=np.int64), device=dev)
     (k0, s0), (k1, s1) = _sort_both(lib, idx, ro, 12, 12, 1)
     assert np.array_equal(k0, k1) and np.array_equal(s0, s1)
+
+
+def test_static_scratch_sort_allocates_nothing_and_replays_from_a_captured_graph():
+    from recommendation_amd import _lib
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(9)
+    cards = [50000, 7, 1200, 300000]
+    offs = np.concatenate([[0], np.cumsum(cards)]).astype(np.int64)
+    row_offset = torch.as_tensor(offs, device=dev)
+    total, B, F = int(offs[-1]), 6000, len(cards)
+    n = B * F
+
+    def draw():
+        return np.stack([rng.integers(0, v, B) for v in cards], 1).astype(np.int32)
+
+    idx = torch.as_tensor(draw(), device=dev)
+    keys = torch.zeros(n, dtype=torch.int32, device=dev)
+    src = torch.zeros(n, dtype=torch.int32, device=dev)
+
+    def call(stream):
+        rc = lib.ctr_emb_sort_static(C.c_void_p(idx.data_ptr()), C.c_void_p(row_offset.data_ptr()), B, F, F, total, 0,
+                                     C.c_void_p(keys.data_ptr()), C.c_void_p(src.data_ptr()), C.c_void_p(stream))
+        assert rc == 0, lib.ctr_last_error()
+
+    call(torch.cuda.current_stream().cuda_stream)          # the first call on a device looks the scratch's address up
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    held0 = torch.cuda.memory_reserved(dev)
+    call(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(dev)[0] == free0 and torch.cuda.memory_reserved(dev) == held0
+
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):                                      # new ids into the captured input, replay, compare
+        ids = draw()
+        idx.copy_(torch.as_tensor(ids, device=dev))
+        keys.fill_(-1)
+        src.fill_(-1)
+        graph.replay()
+        torch.cuda.synchronize()
+        key = (offs[:-1] + ids).reshape(-1).astype(np.uint32)
+        order = np.argsort(key, kind='stable')
+        assert np.array_equal(keys.cpu().numpy().view(np.uint32), key[order])
+        assert np.array_equal(src.cpu().numpy().view(np.uint32), order.astype(np.uint32))
+    torch.cuda.synchronize()
+    del graph
 
 
 def test_static_scratch_sort_rejects_inputs_beyond_its_limit():
