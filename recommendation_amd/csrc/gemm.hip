@@ -127,13 +127,13 @@ __device__ static inline void tile_store(float* __restrict__ S, int t, const flo
 template <int TM, int TN, bool PRE>
 __device__ static inline void tile_epilogue(f32x16 (&acc)[TM][TN], float* smem, int M, int N, int m0, int n0, int wm,
                                             int wn, float* __restrict__ C, int64_t ldc, const Epi& epi,
-                                            float* __restrict__ partial) {
+                                            float* __restrict__ partial, int zslice) {
   constexpr int CS = 36;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 31, lk = lane >> 5;
   __syncthreads();  // every wave is done with As / Bs
   float* S = smem + wave * (32 * CS);
-  float* out = partial ? partial + (int64_t)blockIdx.z * M * N : C;
+  float* out = partial ? partial + (int64_t)zslice * M * N : C;
   const int64_t ldo = partial ? N : ldc;
   const bool vec_out = (ldo % 4 == 0) && ((uintptr_t)out % 16 == 0);
   const bool vec_mask = epi.mask_src && (epi.mask_ld % 4 == 0) && ((uintptr_t)epi.mask_src % 16 == 0);
@@ -292,6 +292,27 @@ __device__ static inline void tile_epilogue(f32x16 (&acc)[TM][TN], float* smem, 
   if (epi.amax_out && !partial) raise_amax(epi.amax_out, amx);
 }
 
+// Which tile a workgroup computes.  The hardware hands workgroups to the eight XCDs round-robin in launch order (x
+// fastest), and each XCD has an L2 of its own: in a split-K launch with a handful of tiles per k-slice (the tower's
+// weight gradients: 8 tiles, 64-256 slices) the plain blockIdx mapping spreads the tiles of one slice, which share
+// its rows of both operands, over all XCDs, and each fetches them again from beyond its L2 (measured: 2.4 x the
+// operand bytes).  There XCD x gets a contiguous range of the logical tile order instead, so a slice's tiles run on
+// one XCD within a few dispatches of each other (429 x 256 x 65536: 97.7 -> 86.5 us).  Launches with many tiles per
+// slice keep the plain order, which measured faster for them (4096^3: 548 vs 597 us).  Placement only changes who
+// computes what, never a result; on any other dispatch order the mapping is still a bijection.
+__device__ static inline void xcd_tile(int& bx, int& by, int& bz) {
+  const unsigned nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
+  bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+  if (nz == 1 || nx * ny > 16) return;
+  const unsigned total = nx * ny * nz;
+  const unsigned lin = (blockIdx.z * ny + blockIdx.y) * nx + blockIdx.x;
+  const unsigned per = total / 8u, rem = total % 8u, x = lin % 8u, slot = lin / 8u;
+  const unsigned L = x * per + (x < rem ? x : rem) + slot;
+  bx = (int)(L % nx);
+  by = (int)((L / nx) % ny);
+  bz = (int)(L / (nx * ny));
+}
+
 // A_K: A stored [M,K] (k contiguous).  B_K: B stored [N,K] (k contiguous).
 // Tile TBM x TBN x BK, four waves as WGM x (4/WGM); a wave owns TM x TN MFMA tiles of 32x32.
 template <bool A_K, bool B_K, int TBM, int TBN, int WGM>
@@ -391,7 +412,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(int M, int N, int K, c
     }
   }
 
-  tile_epilogue<TM, TN, false>(acc, smem, M, N, m0, n0, wm, wn, C, ldc, epi, partial);
+  tile_epilogue<TM, TN, false>(acc, smem, M, N, m0, n0, wm, wn, C, ldc, epi, partial, blockIdx.z);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -403,13 +424,21 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(int M, int N, int K, c
 // from an fp32 FMA chain only in rounding order (~1e-7 relative), while six 32x32x16 bf16 MFMAs cost
 // 192 matrix-core cycles per 16 values of k against 512 for eight 32x32x2 fp32 MFMAs.
 // The split happens once, on the way from global memory into LDS; LDS holds three bf16 planes per
-// operand, k-contiguous with a 48-byte row stride (conflict-free 16-byte fragment reads).
+// operand, k-contiguous in 32-byte rows whose halves are swizzled (lds_at: conflict-free 16-byte reads and writes).
 // A non-finite input turns into NaN (inf - inf in the split).
 // ---------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int SK = 16;    // k per stage = one bf16 MFMA step
-constexpr int SROW = SK + 8;  // bf16 elements per LDS row: 48- or 80-byte stride, conflict-free 16-byte reads
+constexpr int SROW = SK;      // 16-bit elements per LDS row: 32 bytes, no padding
 constexpr int SKG = SK / 8;   // groups of 8 k per row
+// Element offset of (row, k group kg) inside a plane.  Rows are 32 bytes apart, so rows 8 apart would meet on the
+// same banks in a 16-byte fragment read (its lane groups span rows 0-3, 12-15, 20-27 / 4-11, 16-19, 28-31) and rows
+// 4 apart in a 16-byte store (8 consecutive rows per group, 32 banks): the two 16-byte halves of a row swap places
+// by the parity of row bits 2 and 3, which makes both conflict-free.  Against a padded 48-byte row this is a third
+// less LDS per stage, so a fourth block fits on a CU.
+__device__ static inline int lds_at(int row, int kg) {
+  return row * SROW + ((kg ^ (((row >> 2) ^ (row >> 3)) & 1)) << 3);
+}
 
 // eight consecutive-k elements (k0 .. k0+7) of row r; KCONTIG: element (r, k) at P[r*ld + k], else P[k*ld + r].
 // FAST (whole stage inside K, vector loads allowed): no bound checks at all; a row past the end is
@@ -471,7 +500,7 @@ __device__ static inline void split_store8_f16(_Float16* __restrict__ S, int R, 
     hi[j] = h;
     lo[j] = (_Float16)(x - (float)h);
   }
-  _Float16* p = S + row * SROW + kg * 8;
+  _Float16* p = S + lds_at(row, kg);
   *reinterpret_cast<f16x8*>(p) = hi;
   *reinterpret_cast<f16x8*>(p + R * SROW) = lo;
 }
@@ -492,7 +521,7 @@ __device__ static inline void split_store8(__bf16* __restrict__ S, int R, int ro
       mid[j] = m; lo[j] = (__bf16)r2;
     }
   }
-  __bf16* p = S + row * SROW + kg * 8;
+  __bf16* p = S + lds_at(row, kg);
   *reinterpret_cast<bf16x8*>(p) = hi;
   if (PL == 3) {
     *reinterpret_cast<bf16x8*>(p + R * SROW) = mid;
@@ -541,8 +570,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_split_kernel(int M, int N, in
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
-  const int kbeg = blockIdx.z * k_chunk;
+  int bx, by, bz;
+  xcd_tile(bx, by, bz);
+  const int m0 = by * TBM, n0 = bx * TBN;
+  const int kbeg = bz * k_chunk;
   const int kend = kbeg + k_chunk < K ? kbeg + k_chunk : K;
   const int nstages = (kend - kbeg + SK - 1) / SK;
 
@@ -634,12 +665,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_split_kernel(int M, int N, in
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int p = 0; p < PL; ++p)
-        a[i][p] = *reinterpret_cast<const bf16x8*>(As + (p * TBM + wm * (32 * TM) + i * 32 + lr) * SROW + lk * 8);
+        a[i][p] = *reinterpret_cast<const bf16x8*>(As + p * TBM * SROW + lds_at(wm * (32 * TM) + i * 32 + lr, lk));
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int p = 0; p < PL; ++p)
-        b[j][p] = *reinterpret_cast<const bf16x8*>(Bs + (p * TBN + wn * (32 * TN) + j * 32 + lr) * SROW + lk * 8);
+        b[j][p] = *reinterpret_cast<const bf16x8*>(Bs + p * TBN * SROW + lds_at(wn * (32 * TN) + j * 32 + lr, lk));
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -739,7 +770,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_split_kernel(int M, int N, in
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] * unscale_a) * unscale_b;
   }
-  tile_epilogue<TM, TN, true>(acc, reinterpret_cast<float*>(smem_raw), M, N, m0, n0, wm, wn, C, ldc, epi, partial);
+  tile_epilogue<TM, TN, true>(acc, reinterpret_cast<float*>(smem_raw), M, N, m0, n0, wm, wn, C, ldc, epi, partial, bz);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -12,12 +12,12 @@ R=$PWD
 OUT=$R/gpurun_out/prof_$MODEL
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-ARGS="--model $MODEL --steps 30 --warmup 3 --no-cpu-baseline --no-dcn"
+ARGS="--model $MODEL --steps 30 --warmup 3 --repeats 1 --no-cpu-baseline --no-dcn --no-legs"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/bench_under_rocprof.json
 echo "stats pass done"
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --model $MODEL --steps 5 --warmup 2 --no-cpu-baseline --no-dcn --no-kernel-timers > /dev/null
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --model $MODEL --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-dcn --no-legs --no-kernel-timers > /dev/null
 echo "fetch pass done"
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --model $MODEL --steps 5 --warmup 2 --no-cpu-baseline --no-dcn --no-kernel-timers > /dev/null
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --model $MODEL --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-dcn --no-legs --no-kernel-timers > /dev/null
 echo "write pass done"
 cd $R
 python3 tools/pmc_summary.py $(find $OUT/fetch -name "*counter_collection.csv" | head -1) $(find $OUT/write -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json
