@@ -21,9 +21,22 @@ constexpr int DT2 = 3;                   // layer 2 padded to 48 columns (the la
 constexpr int DS1 = DN1 + 4;             // LDS row strides: 4 rows apart = 16 banks apart
 constexpr int DS2 = 16 * DT2 + 4;
 
-// 1 / (1 + e^-x) on the hardware exp2 and reciprocal (about 1 ulp each, relative error ~2e-7): 128 sigmoids per
-// row would otherwise cost more vector-instruction time than the row's matrix products
-__device__ static inline float sigm(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+// 1 / (1 + e^-x) on the hardware exp2 and reciprocal: 128 sigmoids per row would otherwise cost more
+// vector-instruction time than the row's matrix products.  Both instructions are good to about 1 ulp, but
+// exp2(-x log2 e) also inherits the rounding of its argument (|x log2 e| * 2^-24, five ulp at |x| = 5), and the
+// weight gradients sum these values over hundreds of thousands of rows with cancellation: the argument's rounding
+// residual (one fma) is put back as a first-order factor, and the reciprocal gets one Newton step.  ~1.5 ulp.
+__device__ static inline float sigm(float x) {
+  const float L2E_HI = 1.44269502f, L2E_LO = 1.92596299e-8f;    // log2(e) = hi + lo
+  const float t = -x * L2E_HI;
+  float r = fmaf(-x, L2E_HI, -t);                               // exact: what the product's rounding dropped
+  r = fmaf(-x, L2E_LO, r);
+  float e = __builtin_amdgcn_exp2f(t);
+  e = fmaf(e, r * 0.693147181f, e);                             // 2^(t + r) = 2^t (1 + r ln 2 + ...)
+  const float d = 1.f + e;
+  float y = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, y, 1.f), y, y);
+}
 
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -60,7 +73,7 @@ __device__ static inline void stage_fwd_weights(float* lds, const float* __restr
 }
 
 template <int HT>
-__global__ __launch_bounds__(256, 2) void din_mlp_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, int B,
+__global__ __launch_bounds__(256, (HT > 4 ? 1 : 2)) void din_mlp_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, int B,
                                                          int T, const float* __restrict__ W1, const float* __restrict__ b1,
                                                          const float* __restrict__ W2, const float* __restrict__ b2,
                                                          const float* __restrict__ w3, const float* __restrict__ b3,
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void din_mlp_fwd_kernel(const float* __rest
 // LDS: W2t [48][DS1] (W2t[n2][n1] = W2[n1][n2], rows >= 40 zero), Wt [80][3H + 4] (Wt[n1][c] = [Wq; Wk; Wd][c][n1]),
 // w3 padded to 48.
 template <int HT>
-__global__ __launch_bounds__(256, 2) void din_mlp_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, int B,
+__global__ __launch_bounds__(256, (HT > 4 ? 1 : 2)) void din_mlp_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, int B,
                                                          int T, const float* __restrict__ W1, const float* __restrict__ W2,
                                                          const float* __restrict__ w3, const float* __restrict__ d1,
                                                          const float* __restrict__ d2, const float* __restrict__ ds,
@@ -310,43 +323,54 @@ __global__ __launch_bounds__(256, 2) void din_mlp_bwd_kernel(const float* __rest
 // launch, the accumulator tiles of  dW2 = d1^T g2 [80 x 40 (48)]  and  dW' = [q, k, q*k]^T g1 [3H x 80], plus
 // per-column running sums for db1 = sum g1, db2 = sum g2, dw3 = sum ds d2, db3 = sum ds.  Both operands of a
 // product are rows^T: lane (l16, kq) needs column 16i + l16 of row 4kq + u, read from a 16-row strip that the
-// wave staged in its own LDS area with whole-row 16-byte loads.  Every wave writes its partial to `part`
-// ([waves][PART]); din_mlp_wgrad_reduce_kernel adds the partials in a fixed order and _final unfolds dW' into dW1:
+// wave staged in its own LDS area with whole-row 16-byte loads.  Every wave writes its partial to `part`;
+// din_mlp_wgrad_reduce_kernel adds the partials in a fixed order and _final unfolds dW' into dW1:
 //   dW1 = [dWq; dWk; dWq - dWk; dWd].
-template <int HT>
+// The 3H/16 x 5 tiles of dW' fit a wave's registers up to H = 32.  Wider rows are cut into XS column slices of 32
+// (blockIdx.y): a slice's waves walk all samples but keep only the tiles of their 32 columns of q, k and q*k (and
+// read only those columns of k); slice 0 also carries dW2 and the column sums.
+template <int HT, int XS>
 struct WgradLayout {
-  static constexpr int H = 16 * HT, XT = 3 * HT;
-  static constexpr int W2 = 0;                              // [80][48]
-  static constexpr int WX = W2 + DN1 * 16 * DT2;            // [3H][80]
-  static constexpr int SB1 = WX + 3 * H * DN1;              // [80]
+  static constexpr int H = 16 * HT, HTS = HT / XS, XT = 3 * HTS;
+  static constexpr int W2 = 0;                              // [80][48]                     (slice 0)
+  static constexpr int WX = W2 + DN1 * 16 * DT2;            // [3][16 * HTS][80]: the slice's rows of dWq, dWk, dWd
+  static constexpr int SB1 = WX + 3 * 16 * HTS * DN1;       // [80]                         (slice 0, like the rest)
   static constexpr int SB2 = SB1 + DN1;                     // [48]
   static constexpr int SW3 = SB2 + 16 * DT2;                // [48]
   static constexpr int SB3 = SW3 + 16 * DT2;                // [1] (+3 pad)
   static constexpr int PART = SB3 + 4;
+  // where row c of [dWq; dWk; dWd] ([3H][80]) sits in the totals [XS][PART]
+  __host__ __device__ static constexpr int wx_at(int c, int n) {
+    return ((c % H) / 16 / HTS) * PART + WX + (((c / H) * HTS + ((c % H) / 16) % HTS) * 16 + (c % 16)) * DN1 + n;
+  }
 };
 
-template <int HT>
+template <int HTS>
 struct WgradLds {                       // one wave's staging area: a strip of 16 rows of every operand
-  static constexpr int H = 16 * HT;
-  static constexpr int S1 = DN1 + 4, S2 = DN2 + 4, SK = H + 4;    // strides: rows 4 apart sit 16 banks apart
+  static constexpr int HS = 16 * HTS;   // the slice's columns of k
+  static constexpr int S1 = DN1 + 4, S2 = DN2 + 4, SK = HS + 4;    // strides: rows 4 apart sit 16 banks apart
   static constexpr int D1 = 0, G1 = 16 * S1, D2 = 2 * 16 * S1, G2 = D2 + 16 * S2, KK = G2 + 16 * S2, DS = KK + 16 * SK,
                        END = DS + 16;
 };
 
-template <int HT>
+template <int HT, int XS>
 __global__ __launch_bounds__(256, 1) void din_mlp_wgrad_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                               int B, int T, const float* __restrict__ d1,
                                                               const float* __restrict__ d2, const float* __restrict__ ds,
                                                               const float* __restrict__ g1, const float* __restrict__ g2,
                                                               float* __restrict__ part) {
-  using WL = WgradLayout<HT>;
-  using SL = WgradLds<HT>;
-  constexpr int H = 16 * HT, XT = 3 * HT;
-  constexpr int F1 = 16 * DN1 / 4, F2 = 16 * DN2 / 4, FK = 16 * H / 4;   // float4s of a strip of d1 / d2 / k
+  using WL = WgradLayout<HT, XS>;
+  constexpr int HTS = WL::HTS, XT = WL::XT, HS = 16 * HTS;
+  using SL = WgradLds<HTS>;
+  constexpr int H = 16 * HT;
+  constexpr int F1 = 16 * DN1 / 4, F2 = 16 * DN2 / 4, FK = 16 * HS / 4;   // float4s of a strip of d1 / d2 / k's slice
   constexpr int N1 = (F1 + 63) / 64, N2 = (F2 + 63) / 64, NK = (FK + 63) / 64;
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l16 = lane & 15, kq = lane >> 4;
+  const int slice = blockIdx.y;
+  const bool lead = slice == 0;                                  // carries dW2 and the column sums
+  const int c0 = slice * HS;                                     // first column of q / k of this slice
   float* my = lds + wave * SL::END;
   const int64_t gw = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
   f32x4 aw2[DT1][DT2], awx[XT][DT1];
@@ -376,22 +400,23 @@ __global__ __launch_bounds__(256, 1) void din_mlp_wgrad_kernel(const float* __re
     for (int i = 0; i < N1; ++i) {
       const int f = lane + 64 * i;
       const bool ok = f < nrows * (DN1 / 4);
-      r.d1[i] = ok ? *reinterpret_cast<const f32x4*>(d1 + m0 * DN1 + 4 * f) : zero4;
+      r.d1[i] = ok && lead ? *reinterpret_cast<const f32x4*>(d1 + m0 * DN1 + 4 * f) : zero4;
       r.g1[i] = ok ? *reinterpret_cast<const f32x4*>(g1 + m0 * DN1 + 4 * f) : zero4;
     }
 #pragma unroll
     for (int i = 0; i < N2; ++i) {
       const int f = lane + 64 * i;
-      const bool ok = f < nrows * (DN2 / 4);
+      const bool ok = lead && f < nrows * (DN2 / 4);
       r.d2[i] = ok ? *reinterpret_cast<const f32x4*>(d2 + m0 * DN2 + 4 * f) : zero4;
       r.g2[i] = ok ? *reinterpret_cast<const f32x4*>(g2 + m0 * DN2 + 4 * f) : zero4;
     }
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
-      const int f = lane + 64 * i;
-      r.k[i] = f < nrows * (H / 4) ? *reinterpret_cast<const f32x4*>(k + m0 * H + 4 * f) : zero4;
+      const int f = lane + 64 * i;                               // row f / (HS/4), float4 f % (HS/4) of the slice
+      r.k[i] = f < nrows * (HS / 4) ? *reinterpret_cast<const f32x4*>(k + (m0 + f / (HS / 4)) * H + c0 + 4 * (f % (HS / 4)))
+                                    : zero4;
     }
-    r.ds = lane < nrows ? ds[m0 + lane] : 0.f;
+    r.ds = lead && lane < nrows ? ds[m0 + lane] : 0.f;
   };
   auto store_strip = [&](const Regs& r) {
 #pragma unroll
@@ -413,7 +438,7 @@ __global__ __launch_bounds__(256, 1) void din_mlp_wgrad_kernel(const float* __re
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
       const int f = lane + 64 * i;
-      if (FK % 64 == 0 || f < FK) *reinterpret_cast<f32x4*>(my + SL::KK + (f / (H / 4)) * SL::SK + 4 * (f % (H / 4))) = r.k[i];
+      if (FK % 64 == 0 || f < FK) *reinterpret_cast<f32x4*>(my + SL::KK + (f / (HS / 4)) * SL::SK + 4 * (f % (HS / 4))) = r.k[i];
     }
     if (lane < 16) my[SL::DS + lane] = r.ds;
   };
@@ -422,13 +447,13 @@ __global__ __launch_bounds__(256, 1) void din_mlp_wgrad_kernel(const float* __re
   const int64_t items = mine * strips;
   Regs regs;
   if (items > 0) load_strip(gw, 0, regs);
-  float qv[HT];
+  float qv[HTS];
   for (int64_t it = 0; it < items; ++it) {
     const int64_t b = gw + (it / strips) * nw;
     const int s = (int)(it % strips);
     if (s == 0) {
 #pragma unroll
-      for (int j = 0; j < HT; ++j) qv[j] = q[b * H + 16 * j + l16];
+      for (int j = 0; j < HTS; ++j) qv[j] = q[b * H + c0 + 16 * j + l16];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the last strip's reads are done before it is overwritten
     __builtin_amdgcn_wave_barrier();
@@ -439,41 +464,43 @@ __global__ __launch_bounds__(256, 1) void din_mlp_wgrad_kernel(const float* __re
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int row = 4 * kq + u;                              // a product step takes rows u, 4+u, 8+u, 12+u
-      float g1v[DT1], d1v[DT1], g2v[DT2], d2v[DT2], kv[HT];
+      float g1v[DT1], kv[HTS];
 #pragma unroll
-      for (int t = 0; t < DT1; ++t) {
-        g1v[t] = my[SL::G1 + row * SL::S1 + 16 * t + l16];
-        d1v[t] = my[SL::D1 + row * SL::S1 + 16 * t + l16];
-      }
+      for (int t = 0; t < DT1; ++t) g1v[t] = my[SL::G1 + row * SL::S1 + 16 * t + l16];
 #pragma unroll
-      for (int t = 0; t < DT2; ++t) {
-        const bool in = 16 * t + l16 < DN2;
-        g2v[t] = in ? my[SL::G2 + row * SL::S2 + 16 * t + l16] : 0.f;
-        d2v[t] = in ? my[SL::D2 + row * SL::S2 + 16 * t + l16] : 0.f;
-      }
+      for (int j = 0; j < HTS; ++j) kv[j] = my[SL::KK + row * SL::SK + 16 * j + l16];
 #pragma unroll
-      for (int j = 0; j < HT; ++j) kv[j] = my[SL::KK + row * SL::SK + 16 * j + l16];
-      const float dsv = my[SL::DS + row];
-#pragma unroll
-      for (int i = 0; i < DT1; ++i)
-#pragma unroll
-        for (int t = 0; t < DT2; ++t) aw2[i][t] = MFMA4(d1v[i], g2v[t], aw2[i][t]);
-#pragma unroll
-      for (int j = 0; j < HT; ++j)
+      for (int j = 0; j < HTS; ++j)
 #pragma unroll
         for (int t = 0; t < DT1; ++t) {
           awx[j][t] = MFMA4(qv[j], g1v[t], awx[j][t]);
-          awx[HT + j][t] = MFMA4(kv[j], g1v[t], awx[HT + j][t]);
-          awx[2 * HT + j][t] = MFMA4(qv[j] * kv[j], g1v[t], awx[2 * HT + j][t]);
+          awx[HTS + j][t] = MFMA4(kv[j], g1v[t], awx[HTS + j][t]);
+          awx[2 * HTS + j][t] = MFMA4(qv[j] * kv[j], g1v[t], awx[2 * HTS + j][t]);
         }
+      if (lead) {
+        float d1v[DT1], g2v[DT2], d2v[DT2];
 #pragma unroll
-      for (int t = 0; t < DT1; ++t) sb1[t] += g1v[t];
+        for (int t = 0; t < DT1; ++t) d1v[t] = my[SL::D1 + row * SL::S1 + 16 * t + l16];
 #pragma unroll
-      for (int t = 0; t < DT2; ++t) {
-        sb2[t] += g2v[t];
-        sw3[t] += dsv * d2v[t];
+        for (int t = 0; t < DT2; ++t) {
+          const bool in = 16 * t + l16 < DN2;
+          g2v[t] = in ? my[SL::G2 + row * SL::S2 + 16 * t + l16] : 0.f;
+          d2v[t] = in ? my[SL::D2 + row * SL::S2 + 16 * t + l16] : 0.f;
+        }
+        const float dsv = my[SL::DS + row];
+#pragma unroll
+        for (int i = 0; i < DT1; ++i)
+#pragma unroll
+          for (int t = 0; t < DT2; ++t) aw2[i][t] = MFMA4(d1v[i], g2v[t], aw2[i][t]);
+#pragma unroll
+        for (int t = 0; t < DT1; ++t) sb1[t] += g1v[t];
+#pragma unroll
+        for (int t = 0; t < DT2; ++t) {
+          sb2[t] += g2v[t];
+          sw3[t] += dsv * d2v[t];
+        }
+        sb3 += dsv;
       }
-      sb3 += dsv;
     }
   }
   // the per-column sums: lanes kq = 0..3 hold different rows of the same column
@@ -485,20 +512,21 @@ __global__ __launch_bounds__(256, 1) void din_mlp_wgrad_kernel(const float* __re
     sw3[t] += __shfl_xor(sw3[t], 16); sw3[t] += __shfl_xor(sw3[t], 32);
   }
   sb3 += __shfl_xor(sb3, 16); sb3 += __shfl_xor(sb3, 32);   // every l16 lane summed the same rows
-  float* P = part + gw * WL::PART;
+  float* P = part + ((int64_t)slice * nw + gw) * WL::PART;     // [slice][wave][PART]
   // tile (i, t): lane (l16, kq) holds D[16i + 4kq + r][16t + l16]
-#pragma unroll
-  for (int i = 0; i < DT1; ++i)
-#pragma unroll
-    for (int t = 0; t < DT2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) P[WL::W2 + (16 * i + 4 * kq + r) * (16 * DT2) + 16 * t + l16] = aw2[i][t][r];
 #pragma unroll
   for (int i = 0; i < XT; ++i)
 #pragma unroll
     for (int t = 0; t < DT1; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) P[WL::WX + (16 * i + 4 * kq + r) * DN1 + 16 * t + l16] = awx[i][t][r];
+  if (!lead) return;                                           // the other slices' totals are read in WX only
+#pragma unroll
+  for (int i = 0; i < DT1; ++i)
+#pragma unroll
+    for (int t = 0; t < DT2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[WL::W2 + (16 * i + 4 * kq + r) * (16 * DT2) + 16 * t + l16] = aw2[i][t][r];
   if (kq == 0) {
 #pragma unroll
     for (int t = 0; t < DT1; ++t) P[WL::SB1 + 16 * t + l16] = sb1[t];
@@ -515,12 +543,18 @@ __global__ __launch_bounds__(256, 1) void din_mlp_wgrad_kernel(const float* __re
 // independent loads in flight), the eight group sums are then added in group order.  The sums run in double
 // precision: these gradients are sums over B*T rows of terms of both signs, and a thousand fp32 partials added in
 // fp32 cost more accuracy (1e-5 of the largest gradient at 60 000 rows) than all the arithmetic before them.
+// blockIdx.y = column slice: its partials are part[slice][nparts][PART], its totals tot[slice][PART]; of the slices
+// after the first only elements [wx_lo, wx_hi) (the dW' tiles) were written and are summed.
 __global__ __launch_bounds__(256) void din_mlp_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, int PART,
-                                                                  float* __restrict__ tot) {
+                                                                  int wx_lo, int wx_hi, float* __restrict__ tot) {
   __shared__ double sm[8][32];
   const int pg = threadIdx.x >> 5, e = blockIdx.x * 32 + (threadIdx.x & 31);
+  part += (int64_t)blockIdx.y * nparts * PART;
+  tot += (int64_t)blockIdx.y * PART;
+  if (blockIdx.y > 0 && (blockIdx.x * 32 + 31 < wx_lo || blockIdx.x * 32 >= wx_hi)) return;   // whole block outside
+  const bool mine = e < PART && (blockIdx.y == 0 || (e >= wx_lo && e < wx_hi));
   double s = 0.0;
-  if (e < PART) {
+  if (mine) {
     int p = pg;
     for (; p + 56 < nparts; p += 64) {
       float v[8];
@@ -533,7 +567,7 @@ __global__ __launch_bounds__(256) void din_mlp_wgrad_reduce_kernel(const float* 
   }
   sm[pg][threadIdx.x & 31] = s;
   __syncthreads();
-  if (pg == 0 && e < PART) {
+  if (pg == 0 && mine) {
     double t = sm[0][threadIdx.x];
 #pragma unroll
     for (int g = 1; g < 8; ++g) t += sm[g][threadIdx.x];
@@ -542,59 +576,63 @@ __global__ __launch_bounds__(256) void din_mlp_wgrad_reduce_kernel(const float* 
 }
 
 // Totals -> parameter gradients: dW2 un-padded, dW' = [dWq; dWk; dWd] unfolded into dW1 = [dWq; dWk; dWq - dWk; dWd].
-template <int HT>
+// One thread per element of the un-sliced order [dW2 (80 x 48) | dW' (3H x 80) | db1 | db2 | dw3 | db3].
+template <int HT, int XS>
 __global__ __launch_bounds__(256) void din_mlp_wgrad_final_kernel(const float* __restrict__ tot, float* __restrict__ dW1,
                                                                  float* __restrict__ db1, float* __restrict__ dW2,
                                                                  float* __restrict__ db2, float* __restrict__ dw3,
                                                                  float* __restrict__ db3) {
-  using WL = WgradLayout<HT>;
+  using WL = WgradLayout<HT, XS>;
   constexpr int H = 16 * HT;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= WL::PART) return;
-  const float s = tot[e];
-  if (e < WL::WX) {
+  constexpr int NW2 = DN1 * 16 * DT2, NWX = 3 * H * DN1;
+  int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < NW2) {
     const int n1 = e / (16 * DT2), n2 = e % (16 * DT2);
-    if (n2 < DN2) dW2[n1 * DN2 + n2] = s;
-  } else if (e < WL::SB1) {
-    const int c = (e - WL::WX) / DN1, n = (e - WL::WX) % DN1;     // row c of [dWq; dWk; dWd]
+    if (n2 < DN2) dW2[n1 * DN2 + n2] = tot[WL::W2 + e];
+    return;
+  }
+  e -= NW2;
+  if (e < NWX) {
+    const int c = e / DN1, n = e % DN1;                           // row c of [dWq; dWk; dWd]
+    const float s = tot[WL::wx_at(c, n)];
     if (c < H) {                                                  // dWq -> W1a, and the plus half of W1c
       dW1[(int64_t)c * DN1 + n] = s;
-      dW1[(int64_t)(2 * H + c) * DN1 + n] = s - tot[WL::WX + (H + c) * DN1 + n];
+      dW1[(int64_t)(2 * H + c) * DN1 + n] = s - tot[WL::wx_at(H + c, n)];
     } else if (c < 2 * H) {
       dW1[(int64_t)c * DN1 + n] = s;                              // dWk -> W1b
     } else {
       dW1[(int64_t)(c + H) * DN1 + n] = s;                        // dWd -> W1d
     }
-  } else if (e < WL::SB2) {
-    db1[e - WL::SB1] = s;
-  } else if (e < WL::SW3) {
-    if (e - WL::SB2 < DN2) db2[e - WL::SB2] = s;
-  } else if (e < WL::SB3) {
-    if (e - WL::SW3 < DN2) dw3[e - WL::SW3] = s;
-  } else if (e == WL::SB3) {
-    db3[0] = s;
+    return;
   }
+  e -= NWX;
+  if (e < DN1) db1[e] = tot[WL::SB1 + e];
+  else if (e < DN1 + DN2) db2[e - DN1] = tot[WL::SB2 + e - DN1];
+  else if (e < DN1 + 2 * DN2) dw3[e - DN1 - DN2] = tot[WL::SW3 + e - DN1 - DN2];
+  else if (e == DN1 + 2 * DN2) db3[0] = tot[WL::SB3];
 }
 
 }  // namespace ctr
 
 using namespace ctr;
 
-static bool din_h_ok(int H) { return H == 16 || H == 32 || H == 64; }
+static bool din_h_ok(int H) { return H == 16 || H == 32 || H == 64 || H == 128; }
 
-// the weight-gradient kernel keeps (3H/16 * 5 + 15) accumulator tiles in registers: H = 64 would not fit
-extern "C" int ctr_din_attn_mlp_supported(int H, int n1, int n2) { return (H == 16 || H == 32) && n1 == DN1 && n2 == DN2; }
+extern "C" int ctr_din_attn_mlp_supported(int H, int n1, int n2) { return din_h_ok(H) && n1 == DN1 && n2 == DN2; }
 
 static int din_grid(int B, int per_cu) {
   const int64_t need = cdiv(B, 4);
   const int64_t cap = 256 * per_cu;
   return (int)(need < cap ? need : cap);
 }
+// resident blocks per CU of the forward / backward kernels: their weight image in LDS is 33 KB at H = 16, 49 KB at
+// 32, 81 KB at 64 and 146 KB at 128 (a block re-stages it, so no more blocks than stay resident)
+static int din_blocks_per_cu(int H) { return H <= 32 ? 3 : 1; }
 
 extern "C" int ctr_din_attn_mlp_fwd(const float* q, const float* k, int B, int T, int H, const float* W1,
                                     const float* b1, const float* W2, const float* b2, const float* w3,
                                     const float* b3, float* d1_out, float* d2_out, float* score_out, void* stream) {
-  CTR_REQUIRE(B >= 0 && T > 0 && din_h_ok(H), "ctr_din_attn_mlp_fwd: H=%d must be 16, 32 or 64 (T > 0)", H);
+  CTR_REQUIRE(B >= 0 && T > 0 && din_h_ok(H), "ctr_din_attn_mlp_fwd: H=%d must be 16, 32, 64 or 128 (T > 0)", H);
   CTR_REQUIRE(q && k && W1 && b1 && W2 && b2 && w3 && b3 && score_out, "ctr_din_attn_mlp_fwd: null pointer");
   CTR_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)d1_out % 16) == 0 &&
                   ((uintptr_t)d2_out % 16) == 0,
@@ -607,12 +645,13 @@ extern "C" int ctr_din_attn_mlp_fwd(const float* q, const float* k, int B, int T
     if (shm > 48 * 1024)                                                                                         \
       CTR_HIP(hipFuncSetAttribute((const void*)din_mlp_fwd_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)shm));                                                                    \
-    hipLaunchKernelGGL(din_mlp_fwd_kernel<HT>, dim3(din_grid(B, 3)), dim3(256), shm, st, q, k, B, T, W1, b1, W2, \
+    hipLaunchKernelGGL(din_mlp_fwd_kernel<HT>, dim3(din_grid(B, din_blocks_per_cu(H))), dim3(256), shm, st, q, k, B, T, W1, b1, W2, \
                        b2, w3, b3, d1_out, d2_out, score_out);                                                   \
   } while (0)
   if (H == 16) LAUNCH(1);
   else if (H == 32) LAUNCH(2);
-  else LAUNCH(4);
+  else if (H == 64) LAUNCH(4);
+  else LAUNCH(8);
 #undef LAUNCH
   CTR_LAUNCH_CHECK();
   return CTR_OK;
@@ -622,7 +661,7 @@ extern "C" int ctr_din_attn_mlp_bwd(const float* q, const float* k, int B, int T
                                     const float* W2, const float* w3, const float* d1, const float* d2,
                                     const float* dscore, float* g1_out, float* g2_out, float* dq_out, float* dk,
                                     int accumulate_dk, void* stream) {
-  CTR_REQUIRE(B >= 0 && T > 0 && din_h_ok(H), "ctr_din_attn_mlp_bwd: H=%d must be 16, 32 or 64 (T > 0)", H);
+  CTR_REQUIRE(B >= 0 && T > 0 && din_h_ok(H), "ctr_din_attn_mlp_bwd: H=%d must be 16, 32, 64 or 128 (T > 0)", H);
   CTR_REQUIRE(q && k && W1 && W2 && w3 && d1 && d2 && dscore && g1_out && g2_out && dq_out && dk,
               "ctr_din_attn_mlp_bwd: null pointer");
   CTR_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)d1 % 16) == 0 &&
@@ -637,32 +676,35 @@ extern "C" int ctr_din_attn_mlp_bwd(const float* q, const float* k, int B, int T
     if (shm > 48 * 1024)                                                                                         \
       CTR_HIP(hipFuncSetAttribute((const void*)din_mlp_bwd_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)shm));                                                                    \
-    hipLaunchKernelGGL(din_mlp_bwd_kernel<HT>, dim3(din_grid(B, 3)), dim3(256), shm, st, q, k, B, T, W1, W2, w3, \
+    hipLaunchKernelGGL(din_mlp_bwd_kernel<HT>, dim3(din_grid(B, din_blocks_per_cu(H))), dim3(256), shm, st, q, k, B, T, W1, W2, w3, \
                        d1, d2, dscore, g1_out, g2_out, dq_out, dk, accumulate_dk);                               \
   } while (0)
   if (H == 16) LAUNCH(1);
   else if (H == 32) LAUNCH(2);
-  else LAUNCH(4);
+  else if (H == 64) LAUNCH(4);
+  else LAUNCH(8);
 #undef LAUNCH
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
 
 static int wgrad_parts(int B) { return din_grid(B, 1) * 4; }
+static int wgrad_slices(int H) { return H <= 32 ? 1 : H / 32; }
 static size_t wgrad_part_floats(int H) {
-  return H == 16 ? WgradLayout<1>::PART : H == 32 ? WgradLayout<2>::PART : WgradLayout<4>::PART;
+  return H == 16 ? WgradLayout<1, 1>::PART : WgradLayout<2, 1>::PART;      // a slice of a wider row is 32 columns
 }
 
 extern "C" size_t ctr_din_attn_mlp_wgrad_workspace_bytes(int B, int H) {
   if (!din_h_ok(H) || B <= 0) return 0;
-  return (size_t)(wgrad_parts(B) + 1) * wgrad_part_floats(H) * sizeof(float);      // the partials and their totals
+  // [slices][waves] partials and [slices] totals
+  return (size_t)wgrad_slices(H) * (wgrad_parts(B) + 1) * wgrad_part_floats(H) * sizeof(float);
 }
 
 extern "C" int ctr_din_attn_mlp_wgrad(const float* q, const float* k, int B, int T, int H, const float* d1,
                                       const float* d2, const float* dscore, const float* g1, const float* g2,
                                       float* dW1, float* db1, float* dW2, float* db2, float* dw3, float* db3,
                                       void* workspace, size_t workspace_bytes, void* stream) {
-  CTR_REQUIRE(B > 0 && T > 0 && (H == 16 || H == 32), "ctr_din_attn_mlp_wgrad: H=%d must be 16 or 32 (B, T > 0)", H);
+  CTR_REQUIRE(B > 0 && T > 0 && din_h_ok(H), "ctr_din_attn_mlp_wgrad: H=%d must be 16, 32, 64 or 128 (B, T > 0)", H);
   CTR_REQUIRE(q && k && d1 && d2 && dscore && g1 && g2 && dW1 && db1 && dW2 && db2 && dw3 && db3 && workspace,
               "ctr_din_attn_mlp_wgrad: null pointer");
   const size_t need = ctr_din_attn_mlp_wgrad_workspace_bytes(B, H);
@@ -673,22 +715,26 @@ extern "C" int ctr_din_attn_mlp_wgrad(const float* q, const float* k, int B, int
   hipStream_t st = (hipStream_t)stream;
   const int blocks = din_grid(B, 1), parts = blocks * 4;
   float* part = (float*)workspace;
-#define LAUNCH(HT)                                                                                                  \
+#define LAUNCH(HT, XS)                                                                                              \
   do {                                                                                                              \
-    const size_t shm = (size_t)4 * WgradLds<HT>::END * sizeof(float);                                               \
+    using WL = WgradLayout<HT, XS>;                                                                                 \
+    const size_t shm = (size_t)4 * WgradLds<HT / XS>::END * sizeof(float);                                          \
     if (shm > 48 * 1024)                                                                                            \
-      CTR_HIP(hipFuncSetAttribute((const void*)din_mlp_wgrad_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  (int)shm));                                                                       \
-    hipLaunchKernelGGL(din_mlp_wgrad_kernel<HT>, dim3(blocks), dim3(256), shm, st, q, k, B, T, d1, d2, dscore, g1,  \
-                       g2, part);                                                                                   \
-    float* tot = part + (size_t)parts * WgradLayout<HT>::PART;                                                      \
-    hipLaunchKernelGGL(din_mlp_wgrad_reduce_kernel, dim3((unsigned)cdiv(WgradLayout<HT>::PART, 32)), dim3(256), 0,  \
-                       st, part, parts, (int)WgradLayout<HT>::PART, tot);                                           \
-    hipLaunchKernelGGL(din_mlp_wgrad_final_kernel<HT>, dim3((unsigned)cdiv(WgradLayout<HT>::PART, 256)), dim3(256), \
-                       0, st, tot, dW1, db1, dW2, db2, dw3, db3);                                                   \
+      CTR_HIP(hipFuncSetAttribute((const void*)din_mlp_wgrad_kernel<HT, XS>,                                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                           \
+    hipLaunchKernelGGL((din_mlp_wgrad_kernel<HT, XS>), dim3(blocks, XS), dim3(256), shm, st, q, k, B, T, d1, d2,    \
+                       dscore, g1, g2, part);                                                                       \
+    float* tot = part + (size_t)XS * parts * WL::PART;                                                              \
+    hipLaunchKernelGGL(din_mlp_wgrad_reduce_kernel, dim3((unsigned)cdiv(WL::PART, 32), XS), dim3(256), 0, st, part, \
+                       parts, (int)WL::PART, (int)WL::WX, (int)WL::SB1, tot);                                       \
+    constexpr int NOUT = DN1 * 16 * DT2 + 3 * 16 * HT * DN1 + DN1 + 2 * DN2 + 1;                                    \
+    hipLaunchKernelGGL((din_mlp_wgrad_final_kernel<HT, XS>), dim3((unsigned)cdiv(NOUT, 256)), dim3(256), 0, st,     \
+                       tot, dW1, db1, dW2, db2, dw3, db3);                                                          \
   } while (0)
-  if (H == 16) LAUNCH(1);
-  else LAUNCH(2);
+  if (H == 16) LAUNCH(1, 1);
+  else if (H == 32) LAUNCH(2, 1);
+  else if (H == 64) LAUNCH(4, 2);
+  else LAUNCH(8, 4);
 #undef LAUNCH
   CTR_LAUNCH_CHECK();
   return CTR_OK;

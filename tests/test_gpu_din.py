@@ -11,13 +11,14 @@ from tests.helpers import assert_close, rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _setup(sess, H, seed=0, item_count=40, cate_count=6, B=9, T=11):
+def _setup(sess, H, seed=0, item_count=40, cate_count=6, B=9, T=11, fused=True):
     import recommendation_amd as ra
     ra.enable_zoo_imports()
     from DIN import DIN
     rng = np.random.default_rng(seed)
     cfg = O.default_cfg('DIN')
     cfg.hidden_units = H
+    cfg.fused_attention = fused
     cate_list = rng.integers(0, cate_count, item_count)
     P = O.din_init_params(cfg, 5, item_count, cate_count, seed=seed + 1)
     # non-trivial values for the variables that initialise to constants
@@ -41,11 +42,15 @@ def _setup(sess, H, seed=0, item_count=40, cate_count=6, B=9, T=11):
     return m, orc, (u, i, y, hist, sl), (u, i, j, hist, sl)
 
 
-@pytest.mark.parametrize('H,B,T', [(8, 9, 11), (32, 9, 11), (32, 300, 200), (128, 64, 200)])
-def test_din_train_and_eval_match_oracle(sess, H, B, T):
-    """The last two cases have the history length of the Amazon-Books benchmark shape (T = 200): the per-sample
-    block kernels walk several tiles of positions."""
-    m, orc, uij, uij_eval = _setup(sess, H, B=B, T=T, item_count=40 if B < 100 else 5000, cate_count=6 if B < 100 else 80)
+@pytest.mark.parametrize('H,B,T,fused', [(8, 9, 11, True), (32, 9, 11, True), (32, 300, 200, True), (64, 40, 200, True),
+                                         (128, 64, 200, True), (128, 20, 50, False)])
+def test_din_train_and_eval_match_oracle(sess, H, B, T, fused):
+    """The T = 200 cases have the history length of the Amazon-Books benchmark shape: the per-sample block kernels
+    walk several tiles of positions.  H = 8 and the last case go layer by layer through the materialised
+    [B*T, 4H] (no fused scoring network for that width / fused_attention=False)."""
+    m, orc, uij, uij_eval = _setup(sess, H, B=B, T=T, item_count=40 if B < 100 else 5000, cate_count=6 if B < 100 else 80,
+                                   fused=fused)
+    assert m.fused_attention == (fused and H >= 16)
     auc_g, pn_g = m.eval(sess, uij_eval)
     auc_o, pn_o = orc.eval(uij_eval)
     assert abs(float(auc_g) - float(auc_o)) < 1e-6

@@ -35,7 +35,8 @@ def _reference(c, B, T, H):
     return d1.detach(), d2.detach(), score.detach(), G
 
 
-@pytest.mark.parametrize('B,T,H', [(5, 200, 32), (64, 33, 16), (3, 7, 32), (9, 16, 32), (2, 50, 64)])
+@pytest.mark.parametrize('B,T,H', [(5, 200, 32), (64, 33, 16), (3, 7, 32), (9, 16, 32), (2, 50, 64), (11, 40, 64),
+                                   (6, 200, 128), (1500, 3, 128)])
 def test_din_attn_mlp_matches_the_literal_graph(sess, B, T, H):
     from recommendation_amd import ops
     c = _case(B, T, H, 100 * B + T + H)
@@ -62,9 +63,8 @@ def test_din_attn_mlp_matches_the_literal_graph(sess, B, T, H):
     dk2 = z(B * T, H)
     ops.din_attn_mlp_bwd(f['q'], f['k'], f['W1'], f['W2'], f['w3'], d1, d2, f['ds'], g1, g2, dq, dk2, B=B, T=T, H=H)
     assert_close(dk2.cpu().numpy(), G['k'].numpy(), TOL, 'dk')
-    if not ops.din_attn_mlp_supported(H):
-        assert H == 64
-        return
+    # H = 64 / 128: the weight-gradient launch runs in 2 / 4 column slices; (1500, 3, 128) has more samples than
+    # waves, so every slice's waves walk several samples
     out = dict(W1=z(4 * H, 80), b1=z(80), W2=z(80, 40), b2=z(40), w3=z(40), b3=z(1))
     for rep in range(2):
         o = out if rep == 0 else {n: torch.full_like(v, 7.0) for n, v in out.items()}
@@ -79,8 +79,9 @@ def test_din_attn_mlp_matches_the_literal_graph(sess, B, T, H):
 
 def test_din_attn_mlp_rejects_unsupported_shapes(sess):
     from recommendation_amd import ops
-    assert ops.din_attn_mlp_supported(32) and ops.din_attn_mlp_supported(16)
-    assert not ops.din_attn_mlp_supported(128) and not ops.din_attn_mlp_supported(32, 64, 40)
+    assert all(ops.din_attn_mlp_supported(h) for h in (16, 32, 64, 128))
+    assert not ops.din_attn_mlp_supported(48) and not ops.din_attn_mlp_supported(256)
+    assert not ops.din_attn_mlp_supported(32, 64, 40)
     c = _case(2, 4, 48, 1)
     f = {n: v.to(torch.float32).to(DEV).contiguous() for n, v in c.items()}
     with pytest.raises(Exception):
