@@ -373,11 +373,13 @@ int ctr_unit_bwd(int B, int K, const float* dl, const float* w, const float* X, 
 /* The same, and dX's first keep_a_cols columns and the keep_b_cols after them leave multiplied by the keep masks
  * of two dropouts, element indices b*keep_a_cols + k and b*keep_b_cols + (k - keep_a_cols) (what ctr_dropout_apply2
  * would do to dX afterwards; same bits): DeepFM's unit sees [first | second | tower], and the gradients of the
- * two FM terms before their dropout (DeepFM/DeepFM.py:58,63) are what ctr_gemm_f32's fm_bwd epilogue takes. */
+ * two FM terms before their dropout (DeepFM/DeepFM.py:58,63) are what ctr_gemm_f32's fm_bwd epilogue takes.
+ * masked_amax_out (optional, CTR_AMAX_FLOATS floats): the largest |dX| over the masked columns is raised there -
+ * the tower's incoming gradient, whose maximum the two-term fp16 product that consumes it wants (ctr_epilogue_t). */
 int ctr_unit_bwd_keep(int B, int K, const float* dl, const float* w, const float* X, int64_t ldx, float* dX, int64_t lddx,
                       int mask_from, float mask_scale, int keep_a_cols, const ctr_dropout_t* keep_a, int keep_b_cols,
-                      const ctr_dropout_t* keep_b, float* dw, float* db, void* workspace, size_t workspace_bytes,
-                      void* stream);
+                      const ctr_dropout_t* keep_b, float* masked_amax_out, float* dw, float* db, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Loss head: activation + loss + gradient with respect to the pre-activation.

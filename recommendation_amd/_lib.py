@@ -107,7 +107,7 @@ SIGNATURES = {
     'ctr_unit_bwd_supported': (i, [i]),
     'ctr_unit_bwd_workspace_bytes': (sz, [i, i]),
     'ctr_unit_bwd': (i, [i, i, vp, vp, vp, i64, vp, i64, i, f, vp, vp, vp, sz, vp]),
-    'ctr_unit_bwd_keep': (i, [i, i, vp, vp, vp, i64, vp, i64, i, f, i, DP, i, DP, vp, vp, vp, sz, vp]),
+    'ctr_unit_bwd_keep': (i, [i, i, vp, vp, vp, i64, vp, i64, i, f, i, DP, i, DP, vp, vp, vp, vp, sz, vp]),
     'ctr_mlp_chain_supported': (i, [i, i, i, i]),
     'ctr_mlp_chain_fwd': (i, [i, i, vp, i64, i, vp, vp, DP, vp, i64, i, vp, vp, DP, vp, i64, i, vp, vp, DP, vp, i64, vp]),
     'ctr_mlp_chain_bwd_supported': (i, [i, i, i]),

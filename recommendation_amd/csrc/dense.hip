@@ -351,8 +351,9 @@ __global__ __launch_bounds__(256) void unit_bwd_kernel(int B, int K, const float
                                                       int64_t ldx, float* __restrict__ dX, int64_t lddx,
                                                       int mask_from, float mask_scale, int rows_per_block,
                                                       float* __restrict__ part, int keep_a_cols, Drop keep_a,
-                                                      int keep_b_cols, Drop keep_b) {
+                                                      int keep_b_cols, Drop keep_b, float* __restrict__ amax_out) {
   keep_a = resolve_drop(keep_a); keep_b = resolve_drop(keep_b);
+  float amx = 0.f;                                  // max |dX| over the masked columns (amax_out)
   __shared__ float red[256], dred[256];
   const int rps = 256 / K;                          // sample rows per step
   const int r = threadIdx.x / K, k = threadIdx.x - r * K;
@@ -385,10 +386,14 @@ __global__ __launch_bounds__(256) void unit_bwd_kernel(int B, int K, const float
         if (masked) g = x[u] > 0.f ? g * mask_scale : 0.f;
         if (in_a) g *= drop_mul(keep_a, (uint64_t)bb * keep_a_cols + k);
         else if (in_b) g *= drop_mul(keep_b, (uint64_t)bb * keep_b_cols + (k - keep_a_cols));
-        if (bb < b1) dX[bb * lddx + k] = g;
+        if (bb < b1) {
+          dX[bb * lddx + k] = g;
+          if (masked) amx = fmaxf(amx, fabsf(g));
+        }
       }
     }
   }
+  if (amax_out) raise_amax(amax_out, amx);
   red[threadIdx.x] = acc;
   dred[threadIdx.x] = dsum;
   __syncthreads();
@@ -410,8 +415,9 @@ __global__ __launch_bounds__(256) void unit_bwd_wide_kernel(int B, int K, const 
                                                            const float* __restrict__ w, const float* __restrict__ X,
                                                            int64_t ldx, float* __restrict__ dX, int64_t lddx,
                                                            int mask_from, float mask_scale, int rows_per_block,
-                                                           float* __restrict__ part) {
+                                                           float* __restrict__ part, float* __restrict__ amax_out) {
   const int t = threadIdx.x;
+  float amx = 0.f;                                  // max |dX| over the masked columns (amax_out)
   float wv[NC], acc[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -443,6 +449,7 @@ __global__ __launch_bounds__(256) void unit_bwd_wide_kernel(int B, int K, const 
         if (k >= mask_from) {
           g0 = x0[c] > 0.f ? g0 * mask_scale : 0.f;
           g1 = x1[c] > 0.f ? g1 * mask_scale : 0.f;
+          amx = fmaxf(amx, fmaxf(fabsf(g0), fabsf(g1)));         // g1 is zero past the last row
         }
         dX[b * lddx + k] = g0;
         if (two) dX[(b + 1) * lddx + k] = g1;
@@ -455,6 +462,7 @@ __global__ __launch_bounds__(256) void unit_bwd_wide_kernel(int B, int K, const 
     if (k < K) part[(int64_t)blockIdx.x * (K + 1) + k] = acc[c];
   }
   if (t == 0) part[(int64_t)blockIdx.x * (K + 1) + K] = dsum;   // every thread walked the same dl values
+  if (amax_out) raise_amax(amax_out, amx);
 }
 
 // out[k] = sum over the partial rows in a fixed order; column K is the bias gradient
@@ -503,14 +511,15 @@ extern "C" size_t ctr_unit_bwd_workspace_bytes(int B, int K) {
 extern "C" int ctr_unit_bwd(int B, int K, const float* dl, const float* w, const float* X, int64_t ldx, float* dX,
                             int64_t lddx, int mask_from, float mask_scale, float* dw, float* db, void* workspace,
                             size_t workspace_bytes, void* stream) {
-  return ctr_unit_bwd_keep(B, K, dl, w, X, ldx, dX, lddx, mask_from, mask_scale, 0, nullptr, 0, nullptr, dw, db,
-                           workspace, workspace_bytes, stream);
+  return ctr_unit_bwd_keep(B, K, dl, w, X, ldx, dX, lddx, mask_from, mask_scale, 0, nullptr, 0, nullptr, nullptr, dw,
+                           db, workspace, workspace_bytes, stream);
 }
 
 extern "C" int ctr_unit_bwd_keep(int B, int K, const float* dl, const float* w, const float* X, int64_t ldx, float* dX,
                                  int64_t lddx, int mask_from, float mask_scale, int keep_a_cols,
-                                 const ctr_dropout_t* keep_a, int keep_b_cols, const ctr_dropout_t* keep_b, float* dw,
-                                 float* db, void* workspace, size_t workspace_bytes, void* stream) {
+                                 const ctr_dropout_t* keep_a, int keep_b_cols, const ctr_dropout_t* keep_b,
+                                 float* masked_amax_out, float* dw, float* db, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
   CTR_REQUIRE(keep_a_cols >= 0 && keep_b_cols >= 0 && keep_a_cols + keep_b_cols <= K,
               "ctr_unit_bwd_keep: keep blocks wider than K");
   const Drop ka = make_drop(keep_a), kb = make_drop(keep_b);
@@ -528,11 +537,11 @@ extern "C" int ctr_unit_bwd_keep(int B, int K, const float* dl, const float* w, 
   const int rpb = unit_bwd_rows_per_block(B, K);
   if (K <= UB_KMAX) {
     hipLaunchKernelGGL(unit_bwd_kernel, dim3(nb), dim3(256), 0, st, B, K, dl, w, X, ldx, dX, lddx, mask_from, mask_scale,
-                       rpb, part, keep_a_cols, ka, keep_b_cols, kb);
+                       rpb, part, keep_a_cols, ka, keep_b_cols, kb, masked_amax_out);
   } else {
 #define UW(NC_)                                                                                                  \
   hipLaunchKernelGGL(unit_bwd_wide_kernel<NC_>, dim3(nb), dim3(256), 0, st, B, K, dl, w, X, ldx, dX, lddx, mask_from, \
-                     mask_scale, rpb, part)
+                     mask_scale, rpb, part, masked_amax_out)
     const int nc = (int)cdiv(K, 256);
     if (nc <= 2) UW(2); else if (nc <= 4) UW(4); else if (nc <= 8) UW(8); else if (nc <= 12) UW(12); else UW(16);
 #undef UW

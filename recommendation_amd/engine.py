@@ -349,6 +349,11 @@ class Tower:
         ops.absmax_tensors(self.dense.flat, self._am_offs, self._am_cnts, self.am)
         self._have_g = set()
 
+    def g_last_amax(self):
+        """The record of the gradient with respect to the last layer's output (None without enable_amax()), for a
+        producer that can raise it while it writes that gradient (unit_backward)."""
+        return None if self.am is None else self._slot('g', len(self.names) - 1)
+
     def _slot(self, kind, i):
         n = len(self.names)
         k = (dict(w=0, a=n, g=2 * n)[kind] + i) * ops.AMAX_FLOATS
@@ -391,9 +396,9 @@ class Tower:
         return self._chain
 
     def backward(self, x, acts, g_last, gbufs, rates, dx, ws, accumulate_dx=False, g_last_masked=False, side=None,
-                 ext=None, dx_fm=None):
+                 ext=None, dx_fm=None, g_last_has_amax=False):
         """g_last: gradient w.r.t. acts[-1] (post relu+dropout); it is masked in place unless the caller
-        already did (g_last_masked).
+        already did (g_last_masked; g_last_has_amax: and raised g_last_amax() to its largest magnitude).
         gbufs[i]: scratch [B, L_i] for i < n-1.  dx (optional): [B, >= d_in] receives dL/dx
         (added to its content when accumulate_dx).  ext (optional): per layer, the layer's input as a [B, K+1] view
         whose last column is ones (ones_padded), or None.  dx_fm (optional): the fm_bwd argument of ops.gemm for the
@@ -404,6 +409,8 @@ class Tower:
             ops.relu_mask_apply(g_last, acts[n - 1], scale[n - 1])
         g = g_last
         am = self.am is not None
+        if am and g_last_masked and g_last_has_amax:
+            self._have_g.add(n - 1)
         n_fwd_gemm = n - self._chain_len(acts)          # layers whose output word the forward pass raised
 
         def in_amax(i):                                  # word of layer i's input, or None
@@ -504,17 +511,19 @@ class Tower:
         return self._bwd_chain
 
 
-def unit_backward(dense, wn, bn, x, dx, dl, ws, mask_from=-1, rate=0.0, keep=None):
+def unit_backward(dense, wn, bn, x, dx, dl, ws, mask_from=-1, rate=0.0, keep=None, g_amax=None):
     """Backward of an output unit y = x w + b: dx = dl w^T, dw, db.  Columns mask_from.. of x are the output of
     a tower's last relu (+ dropout at `rate`) layer; returns True when their mask was applied to dx here (one
     fused pass), False when the caller (Tower.backward) still has to.  keep (optional): (cols_a, drop_a, cols_b,
-    drop_b), the keep masks of two dropouts for dx's leading column blocks (ops.unit_bwd)."""
+    drop_b), the keep masks of two dropouts for dx's leading column blocks (ops.unit_bwd).  g_amax (optional,
+    Tower.g_last_amax()): the record of the tower's incoming gradient; the fused pass raises it (a True return then
+    also means Tower.backward can be told g_last_has_amax)."""
     B, K = x.shape
     w = dense.p(wn).reshape(-1)
     if ops.unit_bwd_supported(K):
         scale = 1.0 / (1.0 - rate) if rate else 1.0
         ops.unit_bwd(dl, w, x, dx, dense.g(wn).reshape(-1), dense.g(bn).reshape(-1), mask_from=mask_from,
-                     mask_scale=scale, keep=keep, ws=ws)
+                     mask_scale=scale, keep=keep, masked_amax=g_amax if mask_from >= 0 else None, ws=ws)
         return mask_from >= 0
     ops.rowdot_bwd_x(dl, w, dx)
     if keep is not None:

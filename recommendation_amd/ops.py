@@ -354,10 +354,11 @@ def unit_bwd_supported(K):
 
 
 @_timed
-def unit_bwd(dl, w, x, dx, dw, db, *, mask_from=-1, mask_scale=1.0, keep=None, ws):
+def unit_bwd(dl, w, x, dx, dw, db, *, mask_from=-1, mask_scale=1.0, keep=None, masked_amax=None, ws):
     """Backward of the output unit y = x w + b: dx = dl w^T (relu/dropout-masked from column mask_from on),
     dw = x^T dl, db = sum dl, one pass over x.  keep (optional): (cols_a, drop_a, cols_b, drop_b) - the keep masks
-    of two dropouts on dx's first cols_a columns and the cols_b after them (as dropout_apply2 afterwards)."""
+    of two dropouts on dx's first cols_a columns and the cols_b after them (as dropout_apply2 afterwards).
+    masked_amax (optional): a record (AMAX_FLOATS floats) that receives max |dx| over the masked columns."""
     B, K = x.shape
     if dl.numel() != B or w.numel() != K or dw.numel() != K or tuple(dx.shape) != (B, K):
         raise ValueError('unit_bwd: shapes disagree')
@@ -367,8 +368,9 @@ def unit_bwd(dl, w, x, dx, dw, db, *, mask_from=-1, mask_scale=1.0, keep=None, w
     ca, da, cb, db_ = keep if keep is not None else (0, None, 0, None)
     check(lib().ctr_unit_bwd_keep(B, K, _ptr(dl, torch.float32), _ptr(w, torch.float32), xp, ldx, dp, ldd, int(mask_from),
                                   float(mask_scale), int(ca), C.byref(da) if da is not None else None, int(cb),
-                                  C.byref(db_) if db_ is not None else None, _ptr(dw, torch.float32),
-                                  _ptr(db, torch.float32), wp, wn, _stream()), 'ctr_unit_bwd_keep')
+                                  C.byref(db_) if db_ is not None else None, _amax_rec(masked_amax, 'masked_amax'),
+                                  _ptr(dw, torch.float32), _ptr(db, torch.float32), wp, wn, _stream()),
+          'ctr_unit_bwd_keep')
 
 
 def mlp_chain_supported(K0, widths):

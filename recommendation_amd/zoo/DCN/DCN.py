@@ -76,9 +76,12 @@ class DCN(CTRModel):
         B = idx.shape[0]
         stack, dstack, dl = bufs['stack'], bufs['dstack'], bufs['dlogit']
         wn, bn = 'stack_layer/stack_w_%d' % (n - 1), 'stack_layer/stack_b_%d' % (n - 1)
-        fused = unit_backward(self.dense, wn, bn, stack, dstack, dl, ws, mask_from=D, rate=self.dropout)
+        # the unit's backward also raises the record of the gradient it hands to the tower (no pass of its own)
+        g_amax = self.tower.g_last_amax()
+        fused = unit_backward(self.dense, wn, bn, stack, dstack, dl, ws, mask_from=D, rate=self.dropout, g_amax=g_amax)
         self.tower.backward(bufs['x0'], bufs['acts'], dstack[:, D:], bufs['gbufs'], [self.dropout] * n,
-                            bufs['dx0'], ws, g_last_masked=fused, side=self.session, ext=bufs['ext'])
+                            bufs['dx0'], ws, g_last_masked=fused, side=self.session, ext=bufs['ext'],
+                            g_last_has_amax=fused and g_amax is not None)
         ops.cross_bwd(bufs['x0'], self.dense.stacked(self._wn), self.dense.stacked(self._bn), bufs['aux'],
                       dstack[:, :D], bufs['dx0'], self.dense.stacked(self._wn, self.dense.grad),
                       self.dense.stacked(self._bn, self.dense.grad), ws, accumulate=True)

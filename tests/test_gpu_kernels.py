@@ -757,11 +757,17 @@ def test_fused_output_unit_backward(ops_ws, B, K, mask_from):
     dxd = torch.full((B, K + 5), 7.0, device=DEV)
     dw, db = torch.zeros(K, device=DEV), torch.zeros(1, device=DEV)
     assert ops.unit_bwd_supported(K) and not ops.unit_bwd_supported(4097)
-    ops.unit_bwd(dev(dl), dev(w), xd[:, :K], dxd[:, :K], dw, db, mask_from=mask_from, mask_scale=1.25, ws=ws)
+    amax = torch.zeros(ops.AMAX_FLOATS, device=DEV)
+    ops.unit_bwd(dev(dl), dev(w), xd[:, :K], dxd[:, :K], dw, db, mask_from=mask_from, mask_scale=1.25, masked_amax=amax,
+                 ws=ws)
     ref = dl[:, None].astype(np.float64) * w[None, :]
     if mask_from >= 0:
         ref[:, mask_from:] *= np.where(x[:, mask_from:] > 0, 1.25, 0.0)
     assert rel_err(dxd[:, :K].cpu().numpy(), ref) < 1e-6
+    # the record holds exactly the largest magnitude written to the masked columns (what ctr_absmax would find there)
+    got = dxd[:, :K].cpu().numpy()
+    want = float(np.abs(got[:, mask_from:]).max()) if 0 <= mask_from < K else 0.0
+    assert float(amax.max().item()) == want
     assert (dxd[:, K:] == 7.0).all()
     assert rel_err(dw.cpu().numpy(), x.astype(np.float64).T @ dl) < 1e-5
     assert abs(float(db.item()) - float(dl.astype(np.float64).sum())) < 1e-6
