@@ -521,7 +521,9 @@ def run_din(sess, args, H, steps, warmup, B=2048, T=200):
     if fl:
         ach = fl * B / (us * 1e-6) / 1e12
         out['roofline'] = dict(kernel=dom, bound='mfma', achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
-                               frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=None, avg_us=us, flops_per_sample=fl)
+                               frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=None, avg_us=us, flops_per_sample=fl,
+                               flops_note='flops of the reference graph (first layer 4H wide, DIN/DIN.py:169-185); the kernel '
+                                          'multiplies 2H columns per row plus H per sample (q(W1a+W1c) + k(W1b-W1c) + (q*k)W1d)')
     else:
         out['roofline'] = dict(kernel=dom, bound='hbm', achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None,
                                traffic=None, avg_us=us)

@@ -6,6 +6,7 @@
 // (weight gradients) are split along K into fixed-order partial slabs, reduced by a second
 // kernel: no atomics, bitwise reproducible.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace ctr {
@@ -1314,7 +1315,8 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
       return CTR_OK;
     }
   }
-  const Plan p = make_plan(M, N, K, g_gemm_mode != CTR_GEMM_FP32_MFMA && !trans_a);   // wide tiles lose on A^T B (measured)
+  static const bool no_wide = getenv("CTR_GEMM_NO_WIDE") != nullptr;   // measurement switch: 128 x 128 tiles everywhere
+  const Plan p = make_plan(M, N, K, !no_wide && g_gemm_mode != CTR_GEMM_FP32_MFMA && !trans_a);   // wide tiles lose on A^T B (measured)
   float* partial = nullptr;
   if (p.splits > 1) {
     const size_t need = (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float);
