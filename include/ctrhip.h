@@ -644,6 +644,16 @@ int ctr_dice_fwd(const float* x, int64_t x_ld, int rows, int cols, const float* 
 int ctr_dice_bwd(const float* x, int64_t x_ld, int rows, int cols, const float* alpha, float eps,
                  const float* dy, int64_t dy_ld, float* dx, int64_t dx_ld,
                  float* dalpha_src, int64_t dalpha_ld, void* stream);
+/* Backward of ctr_bn_infer and of ctr_dice_fwd together with the column sums their parameters need, one launch
+ * each (a block per 16 columns walks all rows; fixed summation order): for the [batch, <= a few hundred] tensors
+ * after DIN's attention (DIN/DIN.py:45,53-57), where an elementwise pass plus two-stage column sums are five
+ * launches.  ctr_bn_infer_bwd: dx = gamma * dy * rsqrt(var + eps), dgamma = sum_r dy * xhat, dbeta = sum_r dy
+ * (dbeta, var optional).  ctr_dice_bwd_sum: dx as ctr_dice_bwd, dalpha = sum_r dy * (1 - p) * x. */
+int ctr_bn_infer_bwd(const float* dy, int64_t dy_ld, const float* xhat, int64_t xhat_ld, int rows, int cols,
+                     const float* gamma, const float* var, float eps, float* dx, int64_t dx_ld,
+                     float* dgamma, float* dbeta, void* stream);
+int ctr_dice_bwd_sum(const float* x, int64_t x_ld, int rows, int cols, const float* alpha, float eps,
+                     const float* dy, int64_t dy_ld, float* dx, int64_t dx_ld, float* dalpha, void* stream);
 /* g[r,c] *= y[r,c]*(1-y[r,c]): backward of a sigmoid layer given its output (DIN/DIN.py:175-176). */
 int ctr_dsigmoid_apply(float* g, int64_t g_ld, const float* y, int64_t y_ld, int rows, int cols, void* stream);
 /* out_mean[0] = mean(a[i] - b[i] > 0)   (mf_auc, DIN/DIN.py:92) */

@@ -140,6 +140,8 @@ SIGNATURES = {
     'ctr_bn_infer': (i, [vp, i64, i, i, vp, vp, vp, vp, f, vp, i64, vp, i64, vp]),
     'ctr_dice_fwd': (i, [vp, i64, i, i, vp, f, vp, i64, vp]),
     'ctr_dice_bwd': (i, [vp, i64, i, i, vp, f, vp, i64, vp, i64, vp, i64, vp]),
+    'ctr_bn_infer_bwd': (i, [vp, i64, vp, i64, i, i, vp, vp, f, vp, i64, vp, vp, vp]),
+    'ctr_dice_bwd_sum': (i, [vp, i64, i, i, vp, f, vp, i64, vp, i64, vp, vp]),
     'ctr_dsigmoid_apply': (i, [vp, i64, vp, i64, i, i, vp]),
     'ctr_mean_positive_diff': (i, [vp, vp, i, vp, vp]),
     'ctr_copy2d': (i, [vp, i64, vp, i64, i, i, i, vp]),

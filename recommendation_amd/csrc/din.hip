@@ -346,6 +346,67 @@ __global__ __launch_bounds__(256) void dice_kernel(int bwd, const float* __restr
   }
 }
 
+// Elementwise backward of a per-column layer and the column sums its parameters need, in one launch, for the
+// narrow [rows, cols] tensors after the attention (rows = batch): a block owns 16 columns and walks all rows in 64
+// row phases (thread = (column, phase); four rows in flight), the phases are added in phase order through LDS, so the
+// sums are bitwise reproducible.  Few blocks: meant for batches up to some ten thousand rows, where the separate
+// elementwise pass, two-stage column sums and their five launches cost more than the arithmetic.
+//   BN (inference statistics, DIN/DIN.py:45,53): dx = gamma * (dy * rsqrt(var + eps)); sum_a = sum dy * xhat (dgamma),
+//       sum_b = sum dy (dbeta).
+//   DICE (DIN/DIN.py:149-166): dx as dice_kernel's backward; sum_a = sum dy * (1 - p) * x (dalpha).
+constexpr int CB_COLS = 16, CB_PH = 64;
+template <bool DICE>
+__global__ __launch_bounds__(CB_COLS * CB_PH) void colwise_bwd_kernel(
+    const float* __restrict__ x, int64_t x_ld, const float* __restrict__ dy, int64_t dy_ld, int rows, int cols,
+    const float* __restrict__ par, const float* __restrict__ var, float eps, float* __restrict__ dx, int64_t dx_ld,
+    float* __restrict__ sum_a, float* __restrict__ sum_b) {
+  __shared__ float red_a[CB_PH][CB_COLS + 1], red_b[CB_PH][CB_COLS + 1];
+  const int lc = threadIdx.x % CB_COLS, ph = threadIdx.x / CB_COLS;
+  const int c = blockIdx.x * CB_COLS + lc;
+  const bool on = c < cols;
+  const float pv = on ? par[c] : 0.f;                                   // gamma / alpha
+  const float rs = (!DICE && on) ? rsqrtf((var ? var[c] : 1.f) + eps) : 0.f;
+  const float c0 = rsqrtf(1.f + eps);
+  float acc_a = 0.f, acc_b = 0.f;
+  if (on) {
+    for (int r0 = ph; r0 < rows; r0 += 4 * CB_PH) {
+      float xv[4], gv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * CB_PH;
+        const bool live = r < rows;
+        xv[u] = live ? x[(int64_t)r * x_ld + c] : 0.f;
+        gv[u] = live ? dy[(int64_t)r * dy_ld + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * CB_PH;
+        if (r >= rows) break;
+        float d;
+        if (DICE) {
+          const float p = 1.f / (1.f + expf(-xv[u] * c0));
+          d = gv[u] * (pv * (1.f - p) + p + xv[u] * (1.f - pv) * p * (1.f - p) * c0);
+          acc_a += gv[u] * (1.f - p) * xv[u];
+        } else {
+          d = pv * (gv[u] * rs);
+          acc_a += gv[u] * xv[u];
+          acc_b += gv[u];
+        }
+        dx[(int64_t)r * dx_ld + c] = d;
+      }
+    }
+  }
+  red_a[ph][lc] = acc_a;
+  red_b[ph][lc] = acc_b;
+  __syncthreads();
+  if (ph == 0 && on) {
+    float a = 0.f, b = 0.f;
+    for (int q = 0; q < CB_PH; ++q) { a += red_a[q][lc]; b += red_b[q][lc]; }
+    sum_a[c] = a;
+    if (!DICE && sum_b) sum_b[c] = b;
+  }
+}
+
 // g[r,c] *= y[r,c] * (1 - y[r,c])
 __global__ __launch_bounds__(256) void dsigmoid_kernel(float* __restrict__ g, int64_t g_ld,
                                                       const float* __restrict__ y, int64_t y_ld, int rows, int cols) {
@@ -481,6 +542,32 @@ extern "C" int ctr_dice_bwd(const float* x, int64_t x_ld, int rows, int cols, co
   CTR_REQUIRE(x && alpha && dy && dx, "ctr_dice_bwd: null pointer");
   hipLaunchKernelGGL(dice_kernel, dim3(grid_for((int64_t)rows * cols)), dim3(256), 0, (hipStream_t)stream, 1, x, x_ld,
                      rows, cols, alpha, eps, dy, dy_ld, dx, dx_ld, dalpha_src, dalpha_ld);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_bn_infer_bwd(const float* dy, int64_t dy_ld, const float* xhat, int64_t xhat_ld, int rows, int cols,
+                                const float* gamma, const float* var, float eps, float* dx, int64_t dx_ld,
+                                float* dgamma, float* dbeta, void* stream) {
+  CTR_REQUIRE(rows >= 0 && cols >= 0, "ctr_bn_infer_bwd: bad size");
+  if (cols == 0) return CTR_OK;
+  CTR_REQUIRE(dy && xhat && gamma && dx && dgamma && dy_ld >= cols && xhat_ld >= cols && dx_ld >= cols,
+              "ctr_bn_infer_bwd: null pointer / ld");
+  hipLaunchKernelGGL(colwise_bwd_kernel<false>, dim3((unsigned)cdiv(cols, CB_COLS)), dim3(CB_COLS * CB_PH), 0,
+                     (hipStream_t)stream, xhat, xhat_ld, dy, dy_ld, rows, cols, gamma, var, eps, dx, dx_ld, dgamma, dbeta);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_dice_bwd_sum(const float* x, int64_t x_ld, int rows, int cols, const float* alpha, float eps,
+                                const float* dy, int64_t dy_ld, float* dx, int64_t dx_ld, float* dalpha, void* stream) {
+  CTR_REQUIRE(rows >= 0 && cols >= 0, "ctr_dice_bwd_sum: bad size");
+  if (cols == 0) return CTR_OK;
+  CTR_REQUIRE(x && alpha && dy && dx && dalpha && x_ld >= cols && dy_ld >= cols && dx_ld >= cols,
+              "ctr_dice_bwd_sum: null pointer / ld");
+  hipLaunchKernelGGL(colwise_bwd_kernel<true>, dim3((unsigned)cdiv(cols, CB_COLS)), dim3(CB_COLS * CB_PH), 0,
+                     (hipStream_t)stream, x, x_ld, dy, dy_ld, rows, cols, alpha, (const float*)nullptr, eps, dx, dx_ld,
+                     dalpha, (float*)nullptr);
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }

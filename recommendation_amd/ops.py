@@ -1093,6 +1093,36 @@ def dice_bwd(x, alpha, dy, dx, dalpha_src=None, eps=1e-3):
 
 
 @_timed
+def bn_infer_bwd(dy, xhat, dx, *, gamma, var=None, eps=1e-3, dgamma, dbeta=None):
+    """Backward of bn_infer in one launch: dx = gamma * dy * rsqrt(var + eps), dgamma = sum_r dy * xhat,
+    dbeta = sum_r dy.  For batch-sized row counts (a block per 16 columns walks all rows)."""
+    rows, cols = dy.shape
+    gp, gld = _rows(dy, 'dy')
+    hp, hld = _rows(xhat, 'xhat')
+    dp, dld = _rows(dx, 'dx')
+    for v in (gamma, var, dgamma, dbeta):
+        if v is not None and v.numel() != cols:
+            raise ValueError('bn_infer_bwd: per-column vectors must have %d entries' % cols)
+    if tuple(xhat.shape) != (rows, cols) or tuple(dx.shape) != (rows, cols):
+        raise ValueError('bn_infer_bwd shape mismatch')
+    check(lib().ctr_bn_infer_bwd(gp, gld, hp, hld, rows, cols, _ptr(gamma, f32), _ptr(var, f32), float(eps), dp, dld,
+                                 _ptr(dgamma, f32), _ptr(dbeta, f32), _stream()), 'ctr_bn_infer_bwd')
+
+
+@_timed
+def dice_bwd_sum(x, alpha, dy, dx, dalpha, eps=1e-3):
+    """dice_bwd and the column sum that is the gradient of alpha, in one launch (batch-sized row counts)."""
+    rows, cols = x.shape
+    xp, xld = _rows(x, 'x')
+    gp, gld = _rows(dy, 'dy')
+    dp, dld = _rows(dx, 'dx')
+    if alpha.numel() != cols or dalpha.numel() != cols or tuple(dy.shape) != (rows, cols) or tuple(dx.shape) != (rows, cols):
+        raise ValueError('dice_bwd_sum shape mismatch')
+    check(lib().ctr_dice_bwd_sum(xp, xld, rows, cols, _ptr(alpha, f32), float(eps), gp, gld, dp, dld, _ptr(dalpha, f32),
+                                 _stream()), 'ctr_dice_bwd_sum')
+
+
+@_timed
 def dsigmoid_apply(g, y):
     rows, cols = g.shape
     gp, gld = _rows(g, 'g')

@@ -176,7 +176,7 @@ class DIN(GraphOwner):
                  ib4=z(B, 4), dib4=z(B, 4), din_all=z(0 if self.fused_attention else B * T, 4 * H), d1=z(B * T, 80), d2=z(B * T, 40),
                  g1=z(B * T, 80), g2=z(B * T, 40), score=z(B * T), dscore=z(B * T), att=z(B * T),
                  pooled=z(B, H), dpooled=z(B, H), xhat1=z(B, H), hist_bn=z(B, H), dhist_bn=z(B, H),
-                 u_emb=z(B, H), din=z(B, 2 * H), ddin=z(B, 2 * H), xhat2=z(B, 2 * H), din_bn=z(B, 2 * H),
+                 din=z(B, 2 * H), ddin=z(B, 2 * H), xhat2=z(B, 2 * H), din_bn=z(B, 2 * H),
                  ddin_bn=z(B, 2 * H), f1=z(B, 80), a1=z(B, 80), f2=z(B, 40), a2=z(B, 40), df1=z(B, 80),
                  da1=z(B, 80), df2=z(B, 40), da2=z(B, 40), t80=z(B, 80), t40=z(B, 40), d3=z(B), logit=z(B),
                  dlogit=z(B), y_out=z(B),
@@ -184,6 +184,7 @@ class DIN(GraphOwner):
                  src=torch.zeros(2 * n, dtype=torch.int32, device=dev),
                  bkeys=torch.zeros(B, dtype=torch.int32, device=dev),
                  bsrc=torch.zeros(B, dtype=torch.int32, device=dev))
+        b['u_emb'] = b['din'][:, :H]        # the dense layer writes the user vector straight into the FCN's input
         return b
 
     def _dev_i32(self, a):
@@ -222,11 +223,11 @@ class DIN(GraphOwner):
                      mean=d.p(p + 'moving_mean'), var=d.p(p + 'moving_variance'), eps=BN_EPS, xhat=b['xhat1'])
         ops.gemm(b['hist_bn'], d.p('embedding/dense/kernel'), b['u_emb'], bias=d.p('embedding/dense/bias'), ws=ws)
 
-    def _fcn(self, b, x_emb, tag, B, keep):
-        """BN(concat(u_emb, x_emb)) -> f1 -> dice -> f2 -> dice -> f3 (DIN/DIN.py:52-58); returns d3 in b['d3']."""
+    def _fcn(self, b, x_emb, tag, B, keep, d3_out=None):
+        """BN(concat(u_emb, x_emb)) -> f1 -> dice -> f2 -> dice -> f3 (DIN/DIN.py:52-58); d3 goes to d3_out, else
+        to b['d3']."""
         d, H, ws = self.dense, self.H, self.session.ws
-        ops.copy2d(b['u_emb'], b['din'][:, :H])
-        ops.copy2d(x_emb, b['din'][:, H:])
+        ops.copy2d(x_emb, b['din'][:, H:])           # b['u_emb'] is din[:, :H]
         p = 'fcn/b1/'
         ops.bn_infer(b['din'], b['din_bn'], gamma=d.p(p + 'gamma'), beta=d.p(p + 'beta'), mean=d.p(p + 'moving_mean'),
                      var=d.p(p + 'moving_variance'), eps=BN_EPS, xhat=b['xhat2'] if keep else None)
@@ -234,10 +235,32 @@ class DIN(GraphOwner):
         ops.dice_fwd(b['f1'], d.p('fcn/alphadice_1_%s' % tag), b['a1'], BN_EPS)
         ops.gemm(b['a1'], d.p('fcn/f2/kernel'), b['f2'], bias=d.p('fcn/f2/bias'), ws=ws)
         ops.dice_fwd(b['f2'], d.p('fcn/alphadice_2_%s' % tag), b['a2'], BN_EPS)
-        ops.rowdot_fwd(b['a2'], d.p('fcn/f3/kernel').reshape(-1), d.p('fcn/f3/bias'), b['d3'])
+        ops.rowdot_fwd(b['a2'], d.p('fcn/f3/kernel').reshape(-1), d.p('fcn/f3/bias'), b['d3'] if d3_out is None else d3_out)
 
     def _item_bias(self, ids, out4):
         ops.embed_fwd(self.bias_table.weight, self.bias_table.row_offset, ids.view(-1, 1), E=4, z_out=out4)
+
+    SMALL_ROWS = 16384                   # up to here the per-column layers' backward runs as one launch each
+
+    def _bn_backward(self, dy, xhat, dx, prefix):
+        """Backward of an inference-mode batch norm: dx, and the gradients of gamma and beta."""
+        d, ws = self.dense, self.session.ws
+        if dy.shape[0] <= self.SMALL_ROWS:
+            ops.bn_infer_bwd(dy, xhat, dx, gamma=d.p(prefix + 'gamma'), var=d.p(prefix + 'moving_variance'), eps=BN_EPS,
+                             dgamma=d.g(prefix + 'gamma'), dbeta=d.g(prefix + 'beta'))
+            return
+        ops.colsum(dy, d.g(prefix + 'gamma'), w=xhat, w_group=1, ws=ws)
+        ops.colsum(dy, d.g(prefix + 'beta'), ws=ws)
+        ops.bn_infer(dy, dx, gamma=d.p(prefix + 'gamma'), var=d.p(prefix + 'moving_variance'), eps=BN_EPS)
+
+    def _dice_backward(self, x, alpha_name, dy, dx, scratch):
+        """Backward of Dice: dx, and the gradient of its alphas."""
+        d, ws = self.dense, self.session.ws
+        if x.shape[0] <= self.SMALL_ROWS:
+            ops.dice_bwd_sum(x, d.p(alpha_name), dy, dx, d.g(alpha_name), BN_EPS)
+            return
+        ops.dice_bwd(x, d.p(alpha_name), dy, dx, scratch, BN_EPS)
+        ops.colsum(scratch, d.g(alpha_name), ws=ws)
 
     def _attention_mlp_backward_unfused(self, b, ds, i_emb, h_emb, dq, dk, B, T):
         """The scoring network's backward layer by layer over the materialised [B*T, 4H] (any H)."""
@@ -289,33 +312,25 @@ class DIN(GraphOwner):
         self._lookup(ids, b)
         self._item_bias(i, b['ib4'])
         self._user_vector(b, sl, B, T)
-        self._fcn(b, b['emb'][:B], 'i', B, keep=True)
-        ops.copy2d(b['d3'].view(B, 1), b['logit'].view(B, 1))
+        self._fcn(b, b['emb'][:B], 'i', B, keep=True, d3_out=b['logit'])
         ops.copy2d(b['ib4'][:, :1], b['logit'].view(B, 1), accumulate=True)          # logits = i_b + d3
         ops.loss_head(LOSS_SCE_LOGIT, b['logit'], y, y_out=b['y_out'], loss_out=self._loss_dev, dx=b['dlogit'], ws=ws)
         # backward: FCN
         dl = b['dlogit']
         ops.rowdot_bwd_x(dl, d.p('fcn/f3/kernel').reshape(-1), b['da2'])
         ops.dense_wgrad(b['a2'], dl.view(B, 1), d.g('fcn/f3/kernel'), d.g('fcn/f3/bias'), ws=ws)
-        ops.dice_bwd(b['f2'], d.p('fcn/alphadice_2_i'), b['da2'], b['df2'], b['t40'], BN_EPS)
-        ops.colsum(b['t40'], d.g('fcn/alphadice_2_i'), ws=ws)
+        self._dice_backward(b['f2'], 'fcn/alphadice_2_i', b['da2'], b['df2'], b['t40'])
         ops.dense_wgrad(b['a1'], b['df2'], d.g('fcn/f2/kernel'), d.g('fcn/f2/bias'), ws=ws)
         ops.gemm(b['df2'], d.p('fcn/f2/kernel'), b['da1'], trans_b=True, ws=ws)
-        ops.dice_bwd(b['f1'], d.p('fcn/alphadice_1_i'), b['da1'], b['df1'], b['t80'], BN_EPS)
-        ops.colsum(b['t80'], d.g('fcn/alphadice_1_i'), ws=ws)
+        self._dice_backward(b['f1'], 'fcn/alphadice_1_i', b['da1'], b['df1'], b['t80'])
         ops.dense_wgrad(b['din_bn'], b['df1'], d.g('fcn/f1/kernel'), d.g('fcn/f1/bias'), ws=ws)
         ops.gemm(b['df1'], d.p('fcn/f1/kernel'), b['ddin_bn'], trans_b=True, ws=ws)
-        ops.colsum(b['ddin_bn'], d.g('fcn/b1/gamma'), w=b['xhat2'], w_group=1, ws=ws)
-        ops.colsum(b['ddin_bn'], d.g('fcn/b1/beta'), ws=ws)
-        ops.bn_infer(b['ddin_bn'], b['ddin'], gamma=d.p('fcn/b1/gamma'), var=d.p('fcn/b1/moving_variance'), eps=BN_EPS)
+        self._bn_backward(b['ddin_bn'], b['xhat2'], b['ddin'], 'fcn/b1/')
         # backward: dense H, batch norm, attention pooling
         du = b['ddin'][:, :H]
         ops.dense_wgrad(b['hist_bn'], du, d.g('embedding/dense/kernel'), d.g('embedding/dense/bias'), ws=ws)
         ops.gemm(du, d.p('embedding/dense/kernel'), b['dhist_bn'], trans_b=True, ws=ws)
-        p = 'embedding/batch_normalization/'
-        ops.colsum(b['dhist_bn'], d.g(p + 'gamma'), w=b['xhat1'], w_group=1, ws=ws)
-        ops.colsum(b['dhist_bn'], d.g(p + 'beta'), ws=ws)
-        ops.bn_infer(b['dhist_bn'], b['dpooled'], gamma=d.p(p + 'gamma'), var=d.p(p + 'moving_variance'), eps=BN_EPS)
+        self._bn_backward(b['dhist_bn'], b['xhat1'], b['dpooled'], 'embedding/batch_normalization/')
         i_emb, h_emb = b['emb'][:B], b['emb'][B:B + B * T]
         dq, dk = b['demb'][:B], b['demb'][B:B + B * T]
         ops.din_attn_pool_bwd(b['dpooled'], b['att'], sl, h_emb, b['dscore'], dk, B=B, T=T, H=H)
