@@ -260,7 +260,7 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
     ops.set_timer(None)
     eager_blocks = None
     from recommendation_amd.model_base import GRAPH_MAX_BATCH
-    if world == 1 and B <= GRAPH_MAX_BATCH:
+    if world == 1 and model.graph_pays(B):
         # small batches are launch-bound: run() replays the step from a captured graph there, and that is the figure
         # of this workload (the eager time is kept beside it)
         for i in range(2):
@@ -306,7 +306,7 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
                            parallelism='dp%d + %s-sharded tables' % (world, shard) if world > 1 else 'single'),
                final_loss=loss if np.isfinite(loss) else None)
     if eager_blocks is not None:
-        out['step_runs_as'] = 'captured graph replay (batch <= %d, as run() does)' % GRAPH_MAX_BATCH
+        out['step_runs_as'] = 'captured graph replay (launch-bound step: batch <= %d and narrow towers, as run() does)' % GRAPH_MAX_BATCH
         out['eager'] = dict(value=B * steps / float(np.median(eager_blocks)), timing=timing_of(eager_blocks, steps))
     if bf16 is not None:
         out['bf16_tower_mode'] = bf16

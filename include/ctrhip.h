@@ -168,9 +168,16 @@ int ctr_embed_bwd_dz_blocks(const float* gz, int64_t gz_ld, const float* g_first
  *   S-mode (rmode == 0): key = row_offset[f] + idx[b,f],   src = b*N + f
  *   R-mode (rmode != 0): key = row_offset[f] + 1,          src = b*N + row_offset[f] + idx[b,f]
  * (out-of-range ids get key = total_rows and are ignored later), and sorts the pairs by
- * key with a stable LSD radix sort.  keys_out / src_out: [B*F] uint32.
+ * key with a stable LSD radix sort (pairs of equal valid key stay in sample order).  keys_out / src_out: [B*F] uint32.
  * ---------------------------------------------------------------------------------- */
 size_t ctr_emb_sort_workspace_bytes(int64_t n_items);
+/* Workspace with which ctr_emb_sort can take its field-segmented path (never less than
+ * ctr_emb_sort_workspace_bytes(B*F)): the pairs are laid out field by field and every field is sorted on the
+ * bits its own table needs (one pass for up to 511 rows, three for ten million), without scan launches.  Taken for 1024 <= B <= 131072
+ * when the workspace is at least this large; otherwise the global sort runs.  Same result either way, except the
+ * order of the out-of-range pairs among themselves (key = total_rows, behind everything: by sample with the
+ * global sort, by field with this one; they are ignored later). */
+size_t ctr_emb_sort_workspace_bytes_fields(int B, int F, int64_t total_rows, int rmode);
 int ctr_emb_sort(const int32_t* idx, const int64_t* row_offset, int B, int F, int N,
                  int64_t total_rows, int rmode,
                  uint32_t* keys_out, uint32_t* src_out,

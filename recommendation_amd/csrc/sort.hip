@@ -1,7 +1,8 @@
 // Stable LSD radix sort of (uint32 key, uint32 value) pairs, 9 or 10 bits per pass, and the
 // (key, src) pair builder of the embedding backward.  A pass is three launches: per-tile digit
 // histogram -> exclusive scan of the [tile][digit] counts -> stable scatter; the builder leaves
-// the first pass's histogram behind, so that pass starts at its scan.
+// the first pass's histogram behind, so that pass starts at its scan.  The embedding backward's pairs of batches
+// between 1024 and 131072 samples take the field-segmented sort further down instead (a launch per pass).
 // Stability inside a tile: the lanes of a 64-key chunk that carry the same digit find each other
 // through a 64-bit lane mask per digit in LDS (an atomic OR of runs of neighbouring lanes, which
 // commutes), and per-wave running digit counters in LDS order the chunks; the result is bitwise
@@ -10,6 +11,7 @@
 // addresses (one 4-byte store per lane and array to ~500 places per tile is bound by the number
 // of write requests, not by bytes).
 #include "common.h"
+#include <stdlib.h>
 #include <mutex>
 
 namespace ctr {
@@ -450,6 +452,271 @@ static int run_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
 }
 
 // ---------------------------------------------------------------------------------------
+// Field-segmented pair sort of the embedding backward.  A key is (field, id): the builder writes the pairs
+// field-major (field f's pairs at [f*B, (f+1)*B) in sample order), which sorts them by field for free, and the radix
+// passes then run inside each field on the bits ITS ids need: ceil(bits(V_f) / 9) passes of equal width <= 9 bits -
+// one pass for a table of up to 511 rows, three for ten million - instead of three passes over every pair for
+// 26-bit global row numbers.  A field is a segment of Tf = ceil(B / 4096) tiles, so a scatter block finds its
+// offsets by reading the Tf digit counts of its own field: no scan launch.  A sort is the builder, then a histogram
+// and a scatter launch per pass; blocks of fields whose passes are done return at once; a field's last pass writes
+// the final split arrays with key = row_offset[f] + id.  Ids outside their table travel as id = V_f (behind every
+// valid id of the field); the last pass moves them behind all fields with key = total_rows, ordered by field.
+// No atomics on global memory (a device-scope atomic is one fabric transaction: a per-tile flush of next-pass
+// digit counts by integer atomics was measured at +10 us per launch) and nothing to clear between calls.
+// ---------------------------------------------------------------------------------------
+constexpr int FS_BINS = 512;
+constexpr int FS_MAX_TF = 32;            // tiles per field (B <= 131072): a scatter thread holds one count per tile
+constexpr int FS_SB = 128;               // samples per builder block
+constexpr int FS_FG = 32;                // fields per builder block
+
+// What a field's passes look like: ids 0 .. V-1 are valid, Vs is the id an invalid lookup travels with.
+// R-mode: every valid pair of a field has the same key, so the id is 0 (valid) or 1.
+__device__ __forceinline__ void fs_plan(int64_t V, int rmode, uint32_t& Vs, int& passes, int& rb) {
+  Vs = rmode ? 1u : (uint32_t)V;
+  const int bits = Vs == 0u ? 1 : 32 - __builtin_clz(Vs);
+  passes = (bits + 8) / 9;
+  rb = (bits + passes - 1) / passes;
+}
+
+// grid (ceil(B / FS_SB), ceil(F / FS_FG)): a block turns its [samples][fields] slab of ids into pairs and writes
+// every field's 128 pairs as one contiguous piece.  All of a thread's id loads are in flight together.
+__global__ __launch_bounds__(256) void fs_build_kernel(const int32_t* __restrict__ idx,
+                                                       const int64_t* __restrict__ row_offset, int B, int F, int N,
+                                                       int rmode, uint2* __restrict__ pairs) {
+  __shared__ int32_t ids[FS_SB * (FS_FG + 1)];      // [sample][field], odd pitch: a wave reads one field of 64 samples
+  __shared__ int64_t offs[FS_FG + 1];
+  constexpr int PER = FS_SB * FS_FG / 256;          // 16 ids per thread
+  const int f0 = blockIdx.y * FS_FG, fgc = F - f0 < FS_FG ? F - f0 : FS_FG;
+  const int b0 = blockIdx.x * FS_SB, sb = B - b0 < FS_SB ? B - b0 : FS_SB;
+  const int lf = threadIdx.x & (FS_FG - 1), ls = threadIdx.x / FS_FG;      // field of the slab, first sample
+  int32_t v[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int s = ls + u * (256 / FS_FG);
+    v[u] = (lf < fgc && s < sb) ? idx[(int64_t)(b0 + s) * F + f0 + lf] : 0;
+  }
+  for (int i = threadIdx.x; i <= fgc; i += 256) offs[i] = row_offset[f0 + i];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) ids[(ls + u * (256 / FS_FG)) * (FS_FG + 1) + lf] = v[u];
+  __syncthreads();
+#pragma unroll 4
+  for (int u = 0; u < PER; ++u) {
+    const int j = threadIdx.x + 256 * u;
+    const int ff = j / FS_SB, s = j % FS_SB;
+    if (ff >= fgc || s >= sb) continue;
+    const int f = f0 + ff;
+    const uint32_t b = (uint32_t)(b0 + s);
+    const int x = ids[s * (FS_FG + 1) + ff];
+    const int64_t off = offs[ff], V = offs[ff + 1] - off;
+    const bool ok = x >= 0 && x < V;
+    const uint32_t sid = ok ? (rmode ? 0u : (uint32_t)x) : (rmode ? 1u : (uint32_t)V);
+    const uint32_t src = rmode ? (ok ? (uint32_t)((int64_t)b * N + off + x) : 0u) : b * (uint32_t)N + (uint32_t)f;
+    pairs[(uint32_t)f * (uint32_t)B + b] = make_uint2(sid, src);
+  }
+}
+
+// counts[f][t][digit] of one pass for the fields that still have one; block (f, t) = blockIdx.x.  The first pass also
+// counts the tile's invalid lookups into invc[f][t].
+__global__ __launch_bounds__(SORT_THREADS) void fs_hist_kernel(const uint2* __restrict__ in,
+                                                              const int64_t* __restrict__ row_offset, int B, int Tf,
+                                                              int pass, int rmode, uint32_t* __restrict__ counts,
+                                                              uint32_t* __restrict__ invc) {
+  __shared__ uint32_t hist[FS_BINS];
+  __shared__ uint32_t ninv;
+  const int f = blockIdx.x / Tf, t = blockIdx.x - f * Tf;
+  uint32_t Vs;
+  int passes, rb;
+  fs_plan(row_offset[f + 1] - row_offset[f], rmode, Vs, passes, rb);
+  if (pass >= passes) return;
+  const int shift = pass * rb;
+  const uint32_t mask = (1u << rb) - 1u;
+  const int left = B - t * SORT_TILE;
+  const uint32_t cnt = left < SORT_TILE ? (uint32_t)left : (uint32_t)SORT_TILE;
+  const uint2* tile = in + ((uint32_t)f * (uint32_t)B + (uint32_t)t * SORT_TILE);
+  uint32_t k[SORT_CHUNKS];
+#pragma unroll
+  for (int c = 0; c < SORT_CHUNKS; ++c) {
+    const uint32_t i = c * SORT_THREADS + threadIdx.x;
+    k[c] = i < cnt ? tile[i].x : 0u;
+  }
+  hist[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) ninv = 0u;
+  __syncthreads();
+  uint32_t bad = 0u;
+#pragma unroll
+  for (int c = 0; c < SORT_CHUNKS; ++c) {
+    const bool valid = c * SORT_THREADS + threadIdx.x < cnt;
+    hist_add_chunk(hist, (k[c] >> shift) & mask, valid);
+    bad += (uint32_t)__popcll(__ballot(valid && k[c] == Vs));
+  }
+  if (pass == 0 && bad != 0u && (threadIdx.x & 63) == 0) atomicAdd(&ninv, bad);
+  __syncthreads();
+  counts[(int64_t)blockIdx.x * FS_BINS + threadIdx.x] = hist[threadIdx.x];
+  if (pass == 0 && threadIdx.x == 0) invc[blockIdx.x] = ninv;
+}
+
+// One pass's stable scatter inside the fields: block (f, t) = blockIdx.x moves tile t of field f.  in / out: the uint2
+// pairs between passes; keys_out / src_out: the final arrays (written by a field's last pass); counts: this pass's
+// [F][Tf][512] digit counts; invc: [F][Tf] invalid lookups per tile.  The ranking inside the tile is that of
+// radix_scatter_kernel.
+__global__ __launch_bounds__(SORT_THREADS) void fs_scatter_kernel(
+    const uint2* __restrict__ in, uint2* __restrict__ out, uint32_t* __restrict__ keys_out,
+    uint32_t* __restrict__ src_out, const int64_t* __restrict__ row_offset, int B, int F, int Tf, int pass, int rmode,
+    int64_t total_rows, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ invc) {
+  constexpr int RBINS = FS_BINS, MSLOTS = 512;
+  __shared__ uint32_t whist32[SORT_WAVES][RBINS / 2];
+  __shared__ uint32_t tstart[RBINS];
+  __shared__ uint32_t goff[RBINS];                       // (position in the field of digit d's run in this tile) - tstart[d]
+  __shared__ unsigned long long lds64[SORT_TILE];
+  __shared__ uint32_t wtot_a[SORT_WAVES], wtot_b[SORT_WAVES];
+  __shared__ uint32_t inv_red[3][SORT_WAVES];
+  uint16_t* whist = (uint16_t*)&whist32[0][0];
+  const int f = blockIdx.x / Tf, t = blockIdx.x - f * Tf;
+  const int64_t off = row_offset[f], V = row_offset[f + 1] - off;
+  uint32_t Vs;
+  int passes, rb;
+  fs_plan(V, rmode, Vs, passes, rb);
+  if (pass >= passes) return;                            // the whole block: this field is in its final place
+  const bool last = pass == passes - 1;
+  const int shift = pass * rb;
+  const uint32_t mask = (1u << rb) - 1u;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int left = B - t * SORT_TILE;
+  const uint32_t cnt = left < SORT_TILE ? (uint32_t)left : (uint32_t)SORT_TILE;
+  const uint32_t fbase = (uint32_t)f * (uint32_t)B, tbase = fbase + (uint32_t)t * SORT_TILE;
+  uint32_t key[SORT_CHUNKS], val[SORT_CHUNKS], rank[SORT_CHUNKS];
+#pragma unroll
+  for (int c = 0; c < SORT_CHUNKS; ++c) {
+    const uint32_t i = wave * (SORT_CHUNKS * 64) + c * 64 + lane;
+    key[c] = 0u;
+    val[c] = 0u;
+    if (i < cnt) {
+      const uint2 kv = in[tbase + i];
+      key[c] = kv.x;
+      val[c] = kv.y;
+    }
+  }
+  // digit d = threadIdx.x: the field's count (over its Tf tiles) and the count in the tiles before this one; every
+  // tile's count is requested before the first is used
+  uint32_t gb[1], sc = 0u;
+  {
+    const uint32_t* col = counts + (int64_t)f * Tf * RBINS + threadIdx.x;
+    uint32_t cc[FS_MAX_TF];
+#pragma unroll
+    for (int tt = 0; tt < FS_MAX_TF; ++tt) cc[tt] = tt < Tf ? col[(int64_t)tt * RBINS] : 0u;
+    uint32_t tot = 0u;
+#pragma unroll
+    for (int tt = 0; tt < FS_MAX_TF; ++tt) {
+      tot += cc[tt];
+      if (tt < t) sc += cc[tt];
+    }
+    gb[0] = tot;
+  }
+  // invalid lookups (last pass only): in the fields before this one, in this field, in all
+  uint32_t inv_before = 0u, inv_f = 0u, inv_total = 0u;
+  if (last) {
+    for (int g = threadIdx.x; g < F * Tf; g += SORT_THREADS) {
+      const uint32_t c = invc[g];
+      const int gf = g / Tf;
+      inv_total += c;
+      if (gf < f) inv_before += c;
+      if (gf == f) inv_f += c;
+    }
+  }
+  for (int i = threadIdx.x; i < SORT_WAVES * RBINS / 2; i += SORT_THREADS) (&whist32[0][0])[i] = 0u;
+  for (int i = threadIdx.x; i < SORT_TILE; i += SORT_THREADS) lds64[i] = 0ull;
+  if (last) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      inv_total += (uint32_t)__shfl_xor((int)inv_total, o);
+      inv_before += (uint32_t)__shfl_xor((int)inv_before, o);
+      inv_f += (uint32_t)__shfl_xor((int)inv_f, o);
+    }
+    if (lane == 0) { inv_red[0][wave] = inv_total; inv_red[1][wave] = inv_before; inv_red[2][wave] = inv_f; }
+  }
+  block_excl_scan<1>(gb, wtot_a, lane, wave);            // its barrier also orders the clearing above
+  if (last) {
+    inv_total = inv_before = inv_f = 0u;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) { inv_total += inv_red[0][w]; inv_before += inv_red[1][w]; inv_f += inv_red[2][w]; }
+  }
+  unsigned long long* mrow = lds64 + wave * MSLOTS;
+#pragma unroll
+  for (int c = 0; c < SORT_CHUNKS; ++c) {
+    const uint32_t i = wave * (SORT_CHUNKS * 64) + c * 64 + lane;
+    const bool valid = i < cnt;
+    const uint32_t d = (key[c] >> shift) & mask;
+    bool head;
+    const unsigned long long run = run_mask(d, valid, head);
+    if (head) atomicOr(&mrow[d], run);
+    unsigned long long peers = mrow[d];
+    mrow[d] = 0ull;
+    if (!valid) peers = 1ull << lane;
+    const uint32_t in_chunk =
+        __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+    const uint32_t hshift = (d & 1u) * 16u;
+    uint32_t prior = 0;
+    if (valid && in_chunk == 0) prior = atomicAdd(&whist32[wave][d >> 1], (uint32_t)__popcll(peers) << hshift);
+    prior = (uint32_t)__shfl((int)prior, __ffsll((long long)peers) - 1);
+    rank[c] = ((prior >> hshift) & 0xFFFFu) + in_chunk;
+  }
+  __syncthreads();
+  uint32_t ts[1];
+  {
+    const int d = threadIdx.x;
+    uint32_t run = 0;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) {
+      const uint32_t c = whist[w * RBINS + d];
+      whist[w * RBINS + d] = (uint16_t)run;
+      run += c;
+    }
+    ts[0] = run;
+  }
+  block_excl_scan<1>(ts, wtot_b, lane, wave);
+  tstart[threadIdx.x] = ts[0];
+  goff[threadIdx.x] = gb[0] + sc - ts[0];
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < SORT_CHUNKS; ++c) {
+    const uint32_t i = wave * (SORT_CHUNKS * 64) + c * 64 + lane;
+    if (i < cnt) {
+      const uint32_t d = (key[c] >> shift) & mask;
+      lds64[tstart[d] + whist[wave * RBINS + d] + rank[c]] = (unsigned long long)key[c] | ((unsigned long long)val[c] << 32);
+    }
+  }
+  __syncthreads();
+  if (!last) {
+#pragma unroll
+    for (int c = 0; c < SORT_CHUNKS; ++c) {
+      const uint32_t i = c * SORT_THREADS + threadIdx.x;
+      if (i < cnt) {
+        const unsigned long long kv = lds64[i];
+        const uint32_t pos = goff[((uint32_t)kv >> shift) & mask] + i;            // position in the field
+        ((unsigned long long*)out)[fbase + pos] = kv;
+      }
+    }
+    return;
+  }
+  // last pass of this field: final keys, invalid lookups behind all fields
+  const uint32_t n = (uint32_t)B * (uint32_t)F;
+  const uint32_t key_base = (uint32_t)off + (rmode ? 1u : 0u);
+#pragma unroll
+  for (int c = 0; c < SORT_CHUNKS; ++c) {
+    const uint32_t i = c * SORT_THREADS + threadIdx.x;
+    if (i < cnt) {
+      const unsigned long long kv = lds64[i];
+      const uint32_t k = (uint32_t)kv;
+      const uint32_t pos = goff[(k >> shift) & mask] + i;
+      const bool good = k != Vs;
+      const uint32_t dst = good ? fbase - inv_before + pos : n - inv_total + inv_before + (pos - ((uint32_t)B - inv_f));
+      keys_out[dst] = good ? key_base + (rmode ? 0u : k) : (uint32_t)total_rows;
+      src_out[dst] = (uint32_t)(kv >> 32);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Evaluation metrics on the device: AUC with average ranks for ties (sort the scores with the radix
 // sort above, then every positive finds its tie group by two binary searches) and the log loss of
 // tf.losses.log_loss; double-precision sums in a fixed order.
@@ -545,6 +812,46 @@ extern "C" int ctr_auc(const float* score, const float* label, int64_t n, float*
 
 extern "C" size_t ctr_emb_sort_workspace_bytes(int64_t n_items) { return sort_ws_bytes(n_items); }
 
+// The field-segmented path: batches of at least 1024 samples (below that a field's tile is mostly empty and the
+// global sort has fewer blocks) and at most FS_MAX_TF tiles per field.  CTR_SORT_FIELDS=0 keeps the global sort.
+static bool fs_eligible(int64_t B, int64_t F) {
+  static const bool off = getenv("CTR_SORT_FIELDS") && getenv("CTR_SORT_FIELDS")[0] == '0';
+  return !off && F >= 1 && B >= 1024 && cdiv(B, SORT_TILE) <= FS_MAX_TF;
+}
+static int fs_max_passes(int64_t total_rows, int rmode) { return rmode ? 1 : (bits_for((uint64_t)total_rows) + 8) / 9; }
+static size_t fs_counter_bytes(int64_t B, int64_t F) {
+  return align_up((size_t)F * cdiv(B, SORT_TILE) * (FS_BINS + 1) * 4, 256);
+}
+static size_t fs_ws_bytes(int64_t B, int64_t F) { return 2 * align_up((size_t)(B * F) * 8, 256) + fs_counter_bytes(B, F); }
+
+extern "C" size_t ctr_emb_sort_workspace_bytes_fields(int B, int F, int64_t total_rows, int rmode) {
+  const int64_t n = (int64_t)B * F;
+  size_t need = sort_ws_bytes(n);
+  if (fs_eligible(B, F) && fs_ws_bytes(B, F) > need) need = fs_ws_bytes(B, F);
+  return need;
+}
+
+static void fs_sort(const int32_t* idx, const int64_t* row_offset, int B, int F, int N, int64_t total_rows, int rmode,
+                    uint32_t* keys_out, uint32_t* src_out, void* workspace, hipStream_t st) {
+  const int64_t n = (int64_t)B * F;
+  const int Tf = (int)cdiv(B, SORT_TILE), pmax = fs_max_passes(total_rows, rmode);
+  char* p = (char*)workspace;
+  uint2* pa = (uint2*)p; p += align_up((size_t)n * 8, 256);
+  uint2* pb = (uint2*)p; p += align_up((size_t)n * 8, 256);
+  uint32_t* counts = (uint32_t*)p;                         // [F][Tf][512], rewritten by every pass's histogram
+  uint32_t* invc = counts + (size_t)F * Tf * FS_BINS;      // [F][Tf], written by the first pass's histogram
+  hipLaunchKernelGGL(fs_build_kernel, dim3((unsigned)cdiv(B, FS_SB), (unsigned)cdiv(F, FS_FG)), dim3(256), 0, st, idx,
+                     row_offset, B, F, N, rmode, pa);
+  for (int ps = 0; ps < pmax; ++ps) {
+    const uint2* in = (ps & 1) ? pb : pa;
+    uint2* out = (ps & 1) ? pa : pb;
+    hipLaunchKernelGGL(fs_hist_kernel, dim3((unsigned)(F * Tf)), dim3(SORT_THREADS), 0, st, in, row_offset, B, Tf, ps,
+                       rmode, counts, invc);
+    hipLaunchKernelGGL(fs_scatter_kernel, dim3((unsigned)(F * Tf)), dim3(SORT_THREADS), 0, st, in, out, keys_out, src_out,
+                       row_offset, B, F, Tf, ps, rmode, total_rows, counts, invc);
+  }
+}
+
 extern "C" int ctr_emb_sort(const int32_t* idx, const int64_t* row_offset, int B, int F, int N,
                             int64_t total_rows, int rmode, uint32_t* keys_out, uint32_t* src_out,
                             void* workspace, size_t workspace_bytes, void* stream) {
@@ -560,6 +867,12 @@ extern "C" int ctr_emb_sort(const int32_t* idx, const int64_t* row_offset, int B
     return CTR_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (fs_eligible(B, F) && (int64_t)F * cdiv(B, SORT_TILE) < 0x7FFFFFFFll &&
+      workspace_bytes >= fs_ws_bytes(B, F)) {
+    fs_sort(idx, row_offset, B, F, N, total_rows, rmode, keys_out, src_out, workspace, st);
+    CTR_LAUNCH_CHECK();
+    return CTR_OK;
+  }
   const SortWs w = carve(workspace, n);
   const int kbits = bits_for((uint64_t)total_rows), rb = digit_bits(kbits), passes = (kbits + rb - 1) / rb;
   if (rb == 10)

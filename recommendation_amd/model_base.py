@@ -221,7 +221,15 @@ class GraphOwner:
             pass
 
 
+# The pair sort on the side stream beside the forward pass (it reads only the ids).  Off: measured on one box, the
+# DeepFM step went 0.838 -> 0.835 ms and the DCN share 1.260 -> 1.271 - the GPU is busy on both streams already, the
+# sort's launches take from the gather and the first product what they give back later.
+EARLY_SORT = os.environ.get('CTR_EARLY_SORT', '0') == '1'
 GRAPH_MAX_BATCH = 16384     # above this a step is GPU-bound and a captured graph gains nothing
+# ... and so is a smaller batch through wide towers (batch x dense weights above this): a replayed step is one chain
+# of launches, the eager one runs its weight gradients and the pair sort on a second stream (DCN with three 1024-wide
+# layers at batch 8192: 1.25 ms eager, 1.29 ms replayed)
+GRAPH_MAX_WORK = 6e9
 
 
 class CTRModel(GraphOwner):
@@ -548,15 +556,35 @@ class CTRModel(GraphOwner):
         (computed with the pre-update weights, as the reference's fetch does)."""
         B = idx.shape[0]
         bufs = self._buffers(B)
+        self._presorted = self._sort_early(idx, bufs)
         self._forward(idx, xc, bufs, True)
         self._loss(bufs, yy, True)
         self._backward(idx, xc, bufs)
+        self._presorted = False
         self.session.side_join()                            # weight gradients issued to the side stream
         if self.world > 1:
             self.comm.all_reduce_sum(self.dense.grad)       # loss gradient was pre-scaled by 1/world
         self.dense.apply(self._optimizer())
         self.global_step += 1
         return self._loss_dev
+
+    def graph_pays(self, B):
+        """Whether a training step at batch B is launch-bound, i.e. run() replays it from a captured graph."""
+        return B <= GRAPH_MAX_BATCH and B * float(self.dense.flat.numel()) <= GRAPH_MAX_WORK
+
+    def _sort_early(self, idx, bufs):
+        """The (key, src) pair sort of the table backward reads only the ids: with a side stream it is issued here,
+        before the forward pass, and its chain of short launches runs beside the gather and the first tower product
+        instead of between the last activation gradient and the row update.  Returns whether it was issued
+        (_tables_backward then waits for its mark instead of sorting)."""
+        s = self.session
+        if not (EARLY_SORT and s.side_enabled and self.world == 1 and isinstance(self.front, EmbedFront)) \
+                or isinstance(idx, Bags) or idx.numel() == 0:
+            return False
+        with s.side_stream():
+            self.front.sort_pairs(idx, bufs['keys'], bufs['src'], s.ws_side)
+            s.side_mark()
+        return True
 
     def train_step_graphed(self, idx, xc, yy):
         """train_step replayed from a captured HIP graph (one per batch size).  What changes from step to step -
@@ -644,7 +672,7 @@ class CTRModel(GraphOwner):
         if is_train:
             # the reference's loop feeds small mini-batches (128 by default): launch-bound, so replay a graph
             # (bags change their member count from batch to batch and run eagerly)
-            graphed = idx.shape[0] <= GRAPH_MAX_BATCH and not isinstance(idx, Bags)
+            graphed = self.graph_pays(idx.shape[0]) and not isinstance(idx, Bags)
             step = self.train_step_graphed if graphed else self.train_step
             step(idx, xc, yy)
             host = self._scalars.cpu()                  # loss + out-of-range counter in one copy
@@ -745,5 +773,8 @@ class CTRModel(GraphOwner):
                 n = max(idx.nnz, 2 * (self._bag_pairs[0].numel() if self._bag_pairs else 0))
                 self._bag_pairs = tuple(torch.zeros(n, dtype=torch.int32, device=self.session.device) for _ in range(2))
             keys, src = self._bag_pairs
+        if getattr(self, '_presorted', False):
+            self.session.wait_mark()
+            kw['presorted'] = True
         self.front.backward_tables(idx, dz, keys, src, self.session.ws, self._optimizer(),
                                    lazy=(self.adam_mode == 'lazy'), **kw)

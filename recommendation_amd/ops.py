@@ -319,7 +319,7 @@ def emb_sort(idx, row_offset, *, N, total_rows, rmode, keys_out, src_out, ws):
     n = B * F
     if keys_out.numel() < n or src_out.numel() < n:
         raise ValueError('sort outputs too small')
-    wp, wn = ws.get(lib().ctr_emb_sort_workspace_bytes(n))
+    wp, wn = ws.get(lib().ctr_emb_sort_workspace_bytes_fields(B, F, int(total_rows), int(bool(rmode))))
     check(lib().ctr_emb_sort(_ptr(idx, torch.int32), _ptr(row_offset, torch.int64), B, F, N, int(total_rows),
                              int(bool(rmode)), _ptr(keys_out), _ptr(src_out), wp, wn, _stream()), 'ctr_emb_sort')
 

@@ -31,6 +31,7 @@ class Session:
         self._fork_ev = None
         self._join_ev = None
         self._side_open = False
+        self._mark_ev = None
         # False: side_stream() is a no-op context (per-kernel timing passes, graph captures; CTR_NO_SIDE=1: experiments)
         self.side_enabled = os.environ.get('CTR_NO_SIDE', '0') != '1'
         # captured graphs (with the static buffers, streams and events they refer to) whose model was closed or
@@ -86,6 +87,17 @@ class Session:
             self._join_ev.record(self._side)
             torch.cuda.current_stream().wait_event(self._join_ev)
             self._side_open = False
+
+    def side_mark(self):
+        """Records a mark on the side stream after everything issued to it so far; wait_mark() makes the current
+        stream wait for it (for side work whose result the main stream needs before the join, e.g. the pair sort
+        that runs beside the forward pass)."""
+        if self._mark_ev is None:
+            self._mark_ev = torch.cuda.Event()
+        self._mark_ev.record(self._side)
+
+    def wait_mark(self):
+        torch.cuda.current_stream().wait_event(self._mark_ev)
 
     def synchronize(self):
         torch.cuda.synchronize(self.device)

@@ -113,3 +113,17 @@ def assert_weights_track(P_gpu, P_ref, name='', tol=1e-4):
         ref = P_ref[k].numpy() if hasattr(P_ref[k], 'numpy') else np.asarray(P_ref[k])
         r = rel_err(v, ref)
         assert r < tol, '%s %s: weights differ by %.3g (max-norm relative)' % (name, k, r)
+
+
+def assert_sorted_pairs(keys, src, key_ref, src_ref, total):
+    """keys / src (uint32 arrays from ctr_emb_sort) against the definition: the pairs (key_ref[i], src_ref[i]) in
+    stable key order.  Pairs with the sentinel key `total` (out-of-range ids) sit behind everything; their order
+    among themselves is by sample or by field depending on the sort path, so the tail is compared as a set."""
+    key_ref = np.asarray(key_ref).astype(np.uint32)
+    src_ref = np.asarray(src_ref).astype(np.uint32)
+    order = np.argsort(key_ref, kind='stable')
+    nv = int((key_ref != total).sum())
+    assert np.array_equal(keys[:nv], key_ref[order][:nv])
+    assert np.array_equal(src[:nv], src_ref[order][:nv])
+    assert np.all(keys[nv:] == total)
+    assert np.array_equal(np.sort(src[nv:]), np.sort(src_ref[order][nv:]))

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import ctr_oracle as O
-from tests.helpers import assert_close, rel_err
+from tests.helpers import assert_close, assert_sorted_pairs, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -110,10 +110,11 @@ def test_embed_onehot_rmode_bit_exact(ops_ws):
 
 
 @pytest.mark.parametrize('rmode', [False, True])
-@pytest.mark.parametrize('B', [1, 37, 128, 1638, 1639])
+@pytest.mark.parametrize('B', [1, 37, 128, 1023, 1024, 1638, 1639, 4096, 4097, 9001])
 def test_emb_sort_pairs_small_and_large_batches(ops_ws, B, rmode):
     """(key, src) pairs of the table backward in stable key order, from one pair to several radix tiles, in both
-    table semantics; out-of-range ids get the sentinel key."""
+    table semantics; out-of-range ids get the sentinel key.  From 1024 samples on the sort runs field by field (one
+    tile per field, then two and three with a ragged last one)."""
     ops, ws = ops_ws
     rng = np.random.default_rng(B)
     cards = [3, 50, 7, 1000, 20]
@@ -135,12 +136,45 @@ def test_emb_sort_pairs_small_and_large_batches(ops_ws, B, rmode):
         k = np.where(ok, offs[:-1][None] + idx, total)
         v = np.broadcast_to(b * N + f, (B, F))
     k, v = k.reshape(-1).astype(np.uint32), np.ascontiguousarray(v).reshape(-1).astype(np.uint32)
-    order = np.argsort(k, kind='stable')
     keys = torch.zeros(B * F, dtype=torch.int32, device=DEV)
     src = torch.zeros(B * F, dtype=torch.int32, device=DEV)
     ops.emb_sort(dev(idx), dev(offs), N=N, total_rows=total, rmode=rmode, keys_out=keys, src_out=src, ws=ws)
-    assert np.array_equal(keys.cpu().numpy().view(np.uint32), k[order])
-    assert np.array_equal(src.cpu().numpy().view(np.uint32), v[order])
+    assert_sorted_pairs(keys.cpu().numpy().view(np.uint32), src.cpu().numpy().view(np.uint32), k, v, total)
+
+
+@pytest.mark.parametrize('skew', [False, True])
+@pytest.mark.parametrize('B,cards', [(5000, [3, 511, 512, 513, 262143, 262144, 262145, 1, 40, 5000000]),
+                                     (20000, [2, 300, 70000, 9000000, 17, 140000]),
+                                     (2000, list(range(1, 40)))])
+def test_emb_sort_by_fields_pass_counts_and_tile_boundaries(ops_ws, B, cards, skew):
+    """The field-segmented sort: tables whose ids need one, two and three passes side by side (sizes around 2^9 and
+    2^18, where the pass count changes; a one-row table; a ten-million-row table), several tiles per field with a
+    ragged last one, more fields than one builder block takes, uniform and heavy-tailed ids (long runs of one id
+    across tiles), out-of-range ids in several fields.  Run twice: the same bits (the counters are integer atomics)."""
+    ops, ws = ops_ws
+    rng = np.random.default_rng(B + len(cards) + skew)
+    F = len(cards)
+    offs = np.zeros(F + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(cards)
+    total = int(offs[-1])
+    if skew:
+        idx = np.stack([np.minimum(rng.pareto(0.7, B).astype(np.int64), v - 1) for v in cards], 1)
+    else:
+        idx = np.stack([rng.integers(0, v, B) for v in cards], 1)
+    idx = idx.astype(np.int32)
+    for f in (0, F // 2, F - 1):
+        idx[rng.integers(0, B, 3), f] = [-1, cards[f], 2 ** 31 - 1]
+    ok = (idx >= 0) & (idx < np.array(cards)[None])
+    k = np.where(ok, offs[:-1][None] + idx, total).reshape(-1)
+    v = (np.arange(B, dtype=np.int64)[:, None] * F + np.arange(F, dtype=np.int64)[None]).reshape(-1)
+    outs = []
+    for _ in range(2):
+        keys = torch.full((B * F,), -1, dtype=torch.int32, device=DEV)
+        src = torch.full((B * F,), -1, dtype=torch.int32, device=DEV)
+        ops.emb_sort(dev(idx), dev(offs), N=F, total_rows=total, rmode=False, keys_out=keys, src_out=src, ws=ws)
+        outs.append((keys.cpu().numpy().view(np.uint32), src.cpu().numpy().view(np.uint32)))
+    assert_sorted_pairs(outs[0][0], outs[0][1], k, v, total)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize('B,F', [(9, 600), (5, 1100), (3000, 1), (700, 13)])

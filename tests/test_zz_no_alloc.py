@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.helpers import assert_sorted_pairs
+
 pytestmark = pytest.mark.gpu
 
 
@@ -25,7 +27,8 @@ def _sort_both(lib, idx, row_offset, N, total_rows, rmode):
         if static:
             rc = lib.ctr_emb_sort_static(*args, stream)
         else:
-            nbytes = lib.ctr_emb_sort_workspace_bytes(n)
+            # the workspace with which ctr_emb_sort takes the same path as the built-in scratch allows
+            nbytes = lib.ctr_emb_sort_workspace_bytes_fields(B, F, total_rows, rmode)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             rc = lib.ctr_emb_sort(*args, C.c_void_p(ws.data_ptr()), nbytes, stream)
         assert rc == 0, lib.ctr_last_error()
@@ -53,8 +56,7 @@ def test_static_scratch_sort_matches_workspace_sort_on_two_calls_in_a_row():
         assert np.all(ku[:-1] <= ku[1:])
         # against the definition: stable sort of (key, src) by key
         key = np.where((ids >= 0) & (ids < np.asarray(cards)), offs[:-1] + ids, total).reshape(-1).astype(np.uint32)
-        order = np.argsort(key, kind='stable')
-        assert np.array_equal(ku, key[order]) and np.array_equal(s0.view(np.uint32), order.astype(np.uint32))
+        assert_sorted_pairs(ku, s0.view(np.uint32), key, np.arange(key.size), total)
     # reference-exact (one-hot) pair form too
     idx = torch.as_tensor(rng.integers(0, 3, (513, 4)).astype(np.int32), device=dev)
     ro = torch.as_tensor(np.array([0, 3, 6, 9, 12], dtype=np.int64), device=dev)
