@@ -239,6 +239,16 @@ int ctr_emb_sparse_apply(const uint32_t* keys_sorted, const uint32_t* src_sorted
                          const float* dz, int64_t dz_ld, const float* src_scale,
                          float* tables, float* slot0, float* slot1,
                          const ctr_opt_t* opt, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the optimizer slots at a row pitch of their own: row r of slot0 / slot1 starts slot_ld floats after
+ * row r - 1 (ctr_emb_sparse_apply: slot_ld = E).  For Adam's m and v kept side by side in one [rows, 2E] buffer
+ * (slot1 = slot0 + E, slot_ld = 2E): at E = 16 a touched row's m and v are then ONE 128-byte line instead of two
+ * half-used ones (tf.train.AdamOptimizer's slots, DeepFM/DeepFM.py:32,100, are separate variables; only their
+ * values are part of the contract). */
+int ctr_emb_sparse_apply_ld(const uint32_t* keys_sorted, const uint32_t* src_sorted, int64_t n_items,
+                            int N, int E, int64_t total_rows,
+                            const float* dz, int64_t dz_ld, const float* src_scale,
+                            float* tables, float* slot0, float* slot1, int64_t slot_ld,
+                            const ctr_opt_t* opt, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Dense tower pieces.

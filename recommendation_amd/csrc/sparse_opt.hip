@@ -85,7 +85,7 @@ template <int G>
 __global__ __launch_bounds__(256) void sparse_apply_kernel(
     const uint32_t* __restrict__ keys, const uint32_t* __restrict__ src, int64_t n_items, int N, int E,
     int64_t total_rows, const float* __restrict__ dz, int64_t dz_ld, const float* __restrict__ src_scale,
-    float* __restrict__ tables, float* __restrict__ slot0, float* __restrict__ slot1, Opt opt,
+    float* __restrict__ tables, float* __restrict__ slot0, float* __restrict__ slot1, int64_t slot_ld, Opt opt,
     float* __restrict__ part, float* __restrict__ part_head, uint32_t* __restrict__ head_key) {
   opt = resolve_opt(opt);
   constexpr int R = 64 / G;        // pairs per round
@@ -146,10 +146,10 @@ __global__ __launch_bounds__(256) void sparse_apply_kernel(
           *reinterpret_cast<float4*>(part_head + blk * E + g * 4) = v;
           recorded = k;
         } else {
-          const int64_t off = (int64_t)k * E + g * 4;
+          const int64_t off = (int64_t)k * E + g * 4, soff = (int64_t)k * slot_ld + g * 4;
           opt_apply4(opt, v, reinterpret_cast<float4*>(tables + off),
-                     slot0 ? reinterpret_cast<float4*>(slot0 + off) : nullptr,
-                     slot1 ? reinterpret_cast<float4*>(slot1 + off) : nullptr);
+                     slot0 ? reinterpret_cast<float4*>(slot0 + soff) : nullptr,
+                     slot1 ? reinterpret_cast<float4*>(slot1 + soff) : nullptr);
         }
       }
       if (last && g == 0) head_key[blk] = recorded;
@@ -213,7 +213,7 @@ template <int G>
 __global__ __launch_bounds__(256) void sparse_apply_lean_kernel(
     const uint32_t* __restrict__ keys, const uint32_t* __restrict__ src, int64_t n_items, int N, DivU32 divN,
     int64_t total_rows, const float* __restrict__ dz, int64_t dz_ld, const float* __restrict__ src_scale,
-    float* __restrict__ tables, float* __restrict__ slot0, float* __restrict__ slot1, Opt opt,
+    float* __restrict__ tables, float* __restrict__ slot0, float* __restrict__ slot1, int64_t slot_ld, Opt opt,
     float* __restrict__ part, float* __restrict__ part_head, uint32_t* __restrict__ head_key) {
   opt = resolve_opt(opt);
   constexpr int R = 64 / G, IPG = G, E = 4 * G;
@@ -262,11 +262,12 @@ __global__ __launch_bounds__(256) void sparse_apply_lean_kernel(
     if (to_head[u]) recorded = k[u];
     if (in[u] && last && g == 0) head_key[blk] = recorded;
     const int64_t off = app[u] ? (int64_t)k[u] * E + g * 4 : 0;
+    const int64_t soff = app[u] ? (int64_t)k[u] * slot_ld + g * 4 : 0;
     p[u] = a[u] = c[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (opt.kind != CTR_OPT_GRAD_ONLY) p[u] = *reinterpret_cast<const float4*>(tables + off);
     if (opt.kind == CTR_OPT_ADAM || opt.kind == CTR_OPT_ADAGRAD || opt.kind == CTR_OPT_FTRL)
-      a[u] = *reinterpret_cast<const float4*>(slot0 + off);
-    if (opt.kind == CTR_OPT_ADAM || opt.kind == CTR_OPT_FTRL) c[u] = *reinterpret_cast<const float4*>(slot1 + off);
+      a[u] = *reinterpret_cast<const float4*>(slot0 + soff);
+    if (opt.kind == CTR_OPT_ADAM || opt.kind == CTR_OPT_FTRL) c[u] = *reinterpret_cast<const float4*>(slot1 + soff);
   }
 #pragma unroll
   for (int u = 0; u < IPG; ++u) {
@@ -316,10 +317,10 @@ __global__ __launch_bounds__(256) void sparse_apply_lean_kernel(
 #pragma unroll
   for (int u = 0; u < IPG; ++u) {
     if (!app[u]) continue;
-    const int64_t off = (int64_t)k[u] * E + g * 4;
+    const int64_t off = (int64_t)k[u] * E + g * 4, soff = (int64_t)k[u] * slot_ld + g * 4;
     if (opt.kind != CTR_OPT_GRAD_ONLY) *reinterpret_cast<float4*>(tables + off) = p[u];
-    if (opt.kind != CTR_OPT_SGD) *reinterpret_cast<float4*>(slot0 + off) = a[u];
-    if (opt.kind == CTR_OPT_ADAM || opt.kind == CTR_OPT_FTRL) *reinterpret_cast<float4*>(slot1 + off) = c[u];
+    if (opt.kind != CTR_OPT_SGD) *reinterpret_cast<float4*>(slot0 + soff) = a[u];
+    if (opt.kind == CTR_OPT_ADAM || opt.kind == CTR_OPT_FTRL) *reinterpret_cast<float4*>(slot1 + soff) = c[u];
   }
 }
 
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256) void sparse_apply_lean_kernel(
 template <int G>
 __global__ __launch_bounds__(256) void sparse_apply_tail_kernel(
     const uint32_t* __restrict__ keys, int64_t n_items, int64_t n_blocks, int E,
-    float* __restrict__ tables, float* __restrict__ slot0, float* __restrict__ slot1, Opt opt,
+    float* __restrict__ tables, float* __restrict__ slot0, float* __restrict__ slot1, int64_t slot_ld, Opt opt,
     const float* __restrict__ part, const float* __restrict__ part_head,
     const uint32_t* __restrict__ head_key) {
   opt = resolve_opt(opt);
@@ -380,10 +381,10 @@ __global__ __launch_bounds__(256) void sparse_apply_tail_kernel(
     acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
   }
   if (r == 0) {
-    const int64_t off = (int64_t)key * E + g * 4;
+    const int64_t off = (int64_t)key * E + g * 4, soff = (int64_t)key * slot_ld + g * 4;
     opt_apply4(opt, acc, reinterpret_cast<float4*>(tables + off),
-               slot0 ? reinterpret_cast<float4*>(slot0 + off) : nullptr,
-               slot1 ? reinterpret_cast<float4*>(slot1 + off) : nullptr);
+               slot0 ? reinterpret_cast<float4*>(slot0 + soff) : nullptr,
+               slot1 ? reinterpret_cast<float4*>(slot1 + soff) : nullptr);
   }
 }
 
@@ -438,7 +439,18 @@ extern "C" int ctr_emb_sparse_apply(const uint32_t* keys_sorted, const uint32_t*
                                     int64_t dz_ld, const float* src_scale, float* tables, float* slot0,
                                     float* slot1, const ctr_opt_t* opt, void* workspace,
                                     size_t workspace_bytes, void* stream) {
+  return ctr_emb_sparse_apply_ld(keys_sorted, src_sorted, n_items, N, E, total_rows, dz, dz_ld, src_scale, tables,
+                                 slot0, slot1, E, opt, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ctr_emb_sparse_apply_ld(const uint32_t* keys_sorted, const uint32_t* src_sorted,
+                                       int64_t n_items, int N, int E, int64_t total_rows, const float* dz,
+                                       int64_t dz_ld, const float* src_scale, float* tables, float* slot0,
+                                       float* slot1, int64_t slot_ld, const ctr_opt_t* opt, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
   CTR_REQUIRE(opt, "ctr_emb_sparse_apply: opt is null");
+  CTR_REQUIRE(slot_ld >= E && slot_ld % 4 == 0 && ((uintptr_t)slot0 % 16) == 0 && ((uintptr_t)slot1 % 16) == 0,
+              "ctr_emb_sparse_apply: slot_ld must be a multiple of 4 floats, at least E, and the slots 16-byte aligned");
   CTR_REQUIRE(n_items >= 0 && N > 0, "ctr_emb_sparse_apply: bad size");
   CTR_REQUIRE(E >= 4 && E <= 256 && (E & (E - 1)) == 0, "ctr_emb_sparse_apply: E=%d must be a power of two in [4,256]", E);
   if (n_items == 0) return CTR_OK;
@@ -473,9 +485,9 @@ extern "C" int ctr_emb_sparse_apply(const uint32_t* keys_sorted, const uint32_t*
     const DivU32 divN = make_div((uint32_t)N);
 #define LEAN(GG)                                                                                          \
   hipLaunchKernelGGL(sparse_apply_lean_kernel<GG>, grid, block, 0, st, keys_sorted, src_sorted, n_items, N, divN,      \
-                     total_rows, dz, dz_ld, src_scale, tab, slot0, slot1, o, part, part_head, head_key);               \
+                     total_rows, dz, dz_ld, src_scale, tab, slot0, slot1, slot_ld, o, part, part_head, head_key);      \
   hipLaunchKernelGGL(sparse_apply_tail_kernel<GG>, grid2, block, 0, st, keys_sorted, n_items, nb, E, tab, \
-                     slot0, slot1, o, part, part_head, head_key)
+                     slot0, slot1, slot_ld, o, part, part_head, head_key)
     switch (G) {
       case 1: LEAN(1); break;
       case 2: LEAN(2); break;
@@ -488,9 +500,9 @@ extern "C" int ctr_emb_sparse_apply(const uint32_t* keys_sorted, const uint32_t*
   }
 #define LAUNCH(GG)                                                                                   \
   hipLaunchKernelGGL(sparse_apply_kernel<GG>, grid, block, 0, st, keys_sorted, src_sorted, n_items, N, \
-                     E, total_rows, dz, dz_ld, src_scale, tab, slot0, slot1, o, part, part_head, head_key); \
+                     E, total_rows, dz, dz_ld, src_scale, tab, slot0, slot1, slot_ld, o, part, part_head, head_key); \
   hipLaunchKernelGGL(sparse_apply_tail_kernel<GG>, grid2, block, 0, st, keys_sorted, n_items, nb, E, tab, \
-                     slot0, slot1, o, part, part_head, head_key)
+                     slot0, slot1, slot_ld, o, part, part_head, head_key)
   switch (G) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;

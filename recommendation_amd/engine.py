@@ -158,8 +158,15 @@ class EmbeddingTables:
 
     def init_slots(self, kind, dense_adam):
         if kind == 'adam':
-            self.slot0 = torch.zeros_like(self.weight)
-            self.slot1 = torch.zeros_like(self.weight)
+            if dense_adam or self.E > 16:
+                self.slot0 = torch.zeros_like(self.weight)
+                self.slot1 = torch.zeros_like(self.weight)
+            else:
+                # rows of up to 64 bytes: m and v side by side in one [rows, 2E] buffer, so the row-wise update
+                # touches one 128-byte line for both (at E = 16) instead of two half-used ones; slot0 / slot1 are
+                # its column blocks (checkpoints and get/set see [rows, E] tensors as before)
+                self.slots = torch.zeros(self.total_rows, 2 * self.E, dtype=torch.float32, device=self.weight.device)
+                self.slot0, self.slot1 = self.slots[:, :self.E], self.slots[:, self.E:]
             if dense_adam:
                 self.grad = torch.zeros_like(self.weight)
         elif kind == 'adagrad':

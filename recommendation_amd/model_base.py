@@ -430,7 +430,7 @@ class CTRModel(GraphOwner):
             if t is None:
                 continue
             if self.world == 1:
-                sd['tables/slot%d' % s] = t.detach().cpu()
+                sd['tables/slot%d' % s] = t.detach().cpu().contiguous()     # m | v may share one buffer (column blocks)
             else:                                         # per field, so that another layout can pick rows out
                 for fl, f in enumerate(self._own_fields):
                     sd['tables/slot%d/%d' % (s, f)] = self.tables.table(fl, t).detach().cpu().contiguous()

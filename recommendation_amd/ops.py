@@ -530,17 +530,28 @@ def make_opt(kind, lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8, l1=0.0, l2=0.0, lr_
 @_timed
 def emb_sparse_apply(keys, src, n_items, *, N, E, total_rows, dz, opt, ws, tables=None, slot0=None, slot1=None,
                      src_scale=None):
+    """slot0 / slot1: [total_rows, E], contiguous or both column blocks of one wider row-major buffer (the same row
+    pitch: Adam's m | v side by side, engine.EmbeddingTables)."""
     dzp, dzld = _rows(dz, 'dz')
-    for t, nm in ((tables, 'tables'), (slot0, 'slot0'), (slot1, 'slot1')):
-        if t is not None and (t.numel() < total_rows * E or not t.is_contiguous()):
-            raise ValueError('%s must be contiguous [total_rows, E]' % nm)
+    if tables is not None and (tables.numel() < total_rows * E or not tables.is_contiguous()):
+        raise ValueError('tables must be contiguous [total_rows, E]')
+    slot_ld = E
+    for t, nm in ((slot0, 'slot0'), (slot1, 'slot1')):
+        if t is None:
+            continue
+        if t.dim() != 2 or t.shape[0] < total_rows or t.shape[1] != E or t.stride(1) != 1 or t.stride(0) % 4:
+            raise ValueError('%s must be [total_rows, E] with unit column stride and a row pitch of whole float4s' % nm)
+        if t is slot0:
+            slot_ld = t.stride(0)
+        elif slot0 is not None and t.stride(0) != slot_ld:
+            raise ValueError('slot0 and slot1 must share one row pitch')
     if dz.shape[1] < N * E:
         raise ValueError('dz narrower than N*E')
     wp, wn = ws.get(lib().ctr_emb_sparse_apply_workspace_bytes(int(n_items), E))
-    check(lib().ctr_emb_sparse_apply(_ptr(keys), _ptr(src), int(n_items), N, E, int(total_rows), dzp, dzld,
-                                     _ptr(src_scale, torch.float32), _ptr(tables, torch.float32),
-                                     _ptr(slot0, torch.float32), _ptr(slot1, torch.float32), C.byref(opt),
-                                     wp, wn, _stream()), 'ctr_emb_sparse_apply')
+    check(lib().ctr_emb_sparse_apply_ld(_ptr(keys), _ptr(src), int(n_items), N, E, int(total_rows), dzp, dzld,
+                                        _ptr(src_scale, torch.float32), _ptr(tables, torch.float32),
+                                        _ptr(slot0, torch.float32), _ptr(slot1, torch.float32), int(slot_ld),
+                                        C.byref(opt), wp, wn, _stream()), 'ctr_emb_sparse_apply')
 
 
 # ------------------------------------------------------------------ dense pieces

@@ -286,6 +286,38 @@ def test_sparse_optimizers_match_tf1_formulas(ops_ws, kind):
     assert np.array_equal(out[~touched], W[~touched])             # untouched rows are not written
 
 
+@pytest.mark.parametrize('E', [4, 16, 64])
+def test_sparse_adam_with_m_and_v_side_by_side_leaves_the_same_bits(ops_ws, E):
+    """ctr_emb_sparse_apply_ld: Adam's slots as the two column blocks of one [rows, 2E] buffer (row pitch 2E) against
+    two separate [rows, E] arrays - every word of W, m and v identical after two steps, hot rows (runs across
+    several 64-pair blocks: the tail pass) included."""
+    ops, ws = ops_ws
+    rng = np.random.default_rng(E)
+    cards = [3, 900, 50000]
+    F, B = len(cards), 5000
+    offs = np.zeros(F + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(cards)
+    total = int(offs[-1])
+    idx = np.stack([np.minimum(rng.pareto(0.8, B).astype(np.int64), v - 1) for v in cards], 1).astype(np.int32)
+    keys = torch.zeros(B * F, dtype=torch.int32, device=DEV)
+    src = torch.zeros(B * F, dtype=torch.int32, device=DEV)
+    ops.emb_sort(dev(idx), dev(offs), N=F, total_rows=total, rmode=False, keys_out=keys, src_out=src, ws=ws)
+    W0 = rng.standard_normal((total, E)).astype(np.float32)
+    Wa, Wb = dev(W0), dev(W0)
+    ma, va = torch.zeros(total, E, device=DEV), torch.zeros(total, E, device=DEV)
+    mv = torch.zeros(total, 2 * E, device=DEV)
+    mb, vb = mv[:, :E], mv[:, E:]
+    for step in range(2):
+        dz = dev(rng.standard_normal((B, F * E)).astype(np.float32))
+        opt = ops.make_opt(1, lr=0.01 * (step + 1), beta1=0.9, beta2=0.999, eps=1e-8)
+        ops.emb_sparse_apply(keys, src, B * F, N=F, E=E, total_rows=total, dz=dz, opt=opt, tables=Wa, slot0=ma, slot1=va, ws=ws)
+        ops.emb_sparse_apply(keys, src, B * F, N=F, E=E, total_rows=total, dz=dz, opt=opt, tables=Wb, slot0=mb, slot1=vb, ws=ws)
+    assert torch.equal(Wa, Wb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert float(ma.abs().sum()) > 0
+    with pytest.raises(ValueError, match='one row pitch'):
+        ops.emb_sparse_apply(keys, src, B * F, N=F, E=E, total_rows=total, dz=dz, opt=opt, tables=Wb, slot0=mb, slot1=va, ws=ws)
+
+
 GEMM_SHAPES = [(1, 1, 1), (5, 3, 2), (130, 70, 33), (257, 129, 19), (64, 1, 300), (429, 256, 5000),
                (1000, 429, 256), (33, 250, 4096)]
 

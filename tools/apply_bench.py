@@ -22,7 +22,11 @@ gen = torch.Generator(device='cuda'); gen.manual_seed(1)
 idx = zipf_ids(cards, B, 1.05, gen, 'cuda')
 offs = torch.as_tensor(np.concatenate([[0], np.cumsum(cards)]).astype(np.int64), device='cuda')
 W = torch.randn(rows, E, device='cuda') * 0.01
-m = torch.zeros_like(W); v = torch.zeros_like(W)
+if os.environ.get('APPLY_MV', '0') == '1':      # Adam's m | v side by side: one 128-byte line per touched row at E = 16
+    mv = torch.zeros(rows, 2 * E, device='cuda')
+    m, v = mv[:, :E], mv[:, E:]
+else:
+    m = torch.zeros_like(W); v = torch.zeros_like(W)
 dz = torch.randn(B, N * E, device='cuda')
 keys = torch.empty(B * F, dtype=torch.int32, device='cuda'); src = torch.empty_like(keys)
 junk = torch.empty(1 << 28, device='cuda')
