@@ -74,6 +74,9 @@ MODEL_ARGS = {
     'PNN_outer': dict(inner_product=False, product_size=50, hidden_layers=[32, 64, 128], dropout=0.2),
     'AFM': dict(attention_size=10, dropout=0.2),
     'AFM_pairs': dict(attention_size=10, dropout=0.2, attention='pairs'),
+    # the headline model with the table update exactly as tf.train.AdamOptimizer applies an IndexedSlices gradient
+    # (DeepFM/DeepFM.py:32,100): m and v of EVERY row decay and every row moves, each step
+    'DeepFM_tf1adam': dict(deep_layers=[256, 128, 64, 32], dropout_fm=0.5, dropout_deep=0.2, adam_mode='tf1'),
 }
 
 
@@ -82,8 +85,8 @@ def build_model(variant, embed, shard, comm, sess, cards, rank, world):
     import recommendation_amd as ra
     ra.enable_zoo_imports()
     name = variant.split('_')[0]
-    margs = SimpleNamespace(embed_size=embed, regular_rate=0.1, learning_rate=0.001, decay_steps=10000,
-                            decay_rate=0.99, mode='S', adam_mode='lazy', init_std=0.01, **MODEL_ARGS[variant])
+    margs = SimpleNamespace(**dict(dict(embed_size=embed, regular_rate=0.1, learning_rate=0.001, decay_steps=10000,
+                                        decay_rate=0.99, mode='S', adam_mode='lazy', init_std=0.01), **MODEL_ARGS[variant]))
     cls = getattr(importlib.import_module('%s.%s' % (name, name)), name)
     if world > 1:
         margs.world_size, margs.rank, margs.shard = world, rank, shard
@@ -300,8 +303,10 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
                timing=timing_of(blocks, steps),
                config=dict(workload='%s %s shape: 13 dense + 26 sparse fields, sum(V)=%d rows, '
                                     'embed dim %d, per-GPU batch %d, Zipf(%.2f) ids (0 = uniform), fwd+bwd+%s (sparse rows: '
-                                    'row-wise update of touched rows), dropout at the reference rates'
-                                    % (variant, shape_name, int(np.sum(cards)), embed, B, alpha, model.OPTIMIZER),
+                                    '%s), dropout at the reference rates'
+                                    % (variant, shape_name, int(np.sum(cards)), embed, B, alpha, model.OPTIMIZER,
+                                       'every table row updated each step, as tf.train.AdamOptimizer does'
+                                       if getattr(model, 'adam_mode', '') == 'tf1' else 'row-wise update of touched rows'),
                            global_batch=world * B,
                            parallelism='dp%d + %s-sharded tables' % (world, shard) if world > 1 else 'single'),
                final_loss=loss if np.isfinite(loss) else None)
@@ -598,6 +603,8 @@ def main():
         for b in (4096, 16384):
             legs['deepfm_B%d' % b] = leg(run_model, 'DeepFM', args, sess, rank, world, dist, st, wu, b, args.embed,
                                          args.shard, light=True)
+        legs['deepfm_tf1_adam'] = leg(run_model, 'DeepFM_tf1adam', args, sess, rank, world, dist, st, wu, args.batch,
+                                      args.embed, args.shard, light=True)
         for v in ('PNN', 'PNN_outer', 'AFM', 'AFM_pairs', 'ESMM', 'NFM'):      # BASELINE configs[3] (+ ESMM of configs[4])
             legs[v] = leg(run_model, v, args, sess, rank, world, dist, st, wu, 65536, 16, 'table', light=True)
         for h in (32, 128):                                                    # BASELINE configs[4]
