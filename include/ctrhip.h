@@ -697,6 +697,21 @@ int ctr_dropout_apply(float* x, int64_t ld, int rows, int cols, const ctr_dropou
 int ctr_dropout_apply2(float* x, int64_t ld, int rows, int cols_a, const ctr_dropout_t* drop_a,
                        int cols_b, const ctr_dropout_t* drop_b, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Input text of the Criteo display-advertising sets -> the arrays a step is fed with (host code, no GPU).
+ * Stands before the path where the reference's loaders stand (pandas.read_csv + the feed conversion,
+ * DeepFM/main.py:13-43, DeepFM/DeepFM.py:37-39); the reference reads its own two-column CSV only.
+ * A line is  label \t I1..I13 \t C1..C26 : 0/1, thirteen integers, twenty-six hexadecimal tokens of up to eight
+ * digits; any field may be empty (dense 0, token value 0).  ids[r][f] = value(C_f) mod cards[f] (the token's own
+ * 32 bits as its hash), dense[r][j] = I_j, or log(1 + max(I_j, 0)) with log_dense != 0.  The text is cut into
+ * n_threads pieces at line boundaries and parsed in parallel.  At most max_rows samples are written (label
+ * [max_rows], dense [max_rows, 13], ids [max_rows, 26], host memory); *rows_out = samples written.
+ * ctr_criteo_tsv_count: the number of non-empty lines.
+ * ---------------------------------------------------------------------------------- */
+int64_t ctr_criteo_tsv_count(const char* text, int64_t len);
+int ctr_criteo_tsv_parse(const char* text, int64_t len, const int64_t* cards, int log_dense, int n_threads,
+                         int64_t max_rows, float* label, float* dense, int32_t* ids, int64_t* rows_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,8 @@ SIGNATURES = {
     'ctr_embed_bwd_dz': (i, [vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i, i, i, DP, DP, vp, i64, vp]),
     'ctr_embed_bwd_dz_blocks': (i, [vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i, i, i, DP, DP, vp, i64, vp, vp, vp, i, vp]),
     'ctr_embed_assemble_fwd': (i, [vp, vp, vp, vp, vp, i, i, i, i, vp, i64, i, vp, i64, vp, vp, i64, DP, DP, vp]),
+    'ctr_criteo_tsv_count': (i64, [vp, i64]),
+    'ctr_criteo_tsv_parse': (i, [vp, i64, vp, i, i, i64, vp, vp, vp, vp]),
     'ctr_emb_sort_workspace_bytes': (sz, [i64]),
     'ctr_emb_sort_workspace_bytes_fields': (sz, [i, i, i64, i]),
     'ctr_emb_sort': (i, [vp, vp, i, i, i, i64, i, vp, vp, vp, sz, vp]),
