@@ -49,8 +49,9 @@ def parse():
     ap.add_argument('--alpha', type=float, default=1.05, help='Zipf exponent of the ids (0 = uniform)')
     ap.add_argument('--model', default='DeepFM', choices=sorted(MODEL_ARGS),
                     help='DeepFM is the headline workload; the others time the same step for their family')
-    ap.add_argument('--comm', default='rccl', choices=['rccl', 'host-staged'],
-                    help='host-staged: gloo through host memory, to rehearse N>1 with all ranks on one GPU')
+    ap.add_argument('--comm', default='rccl', choices=['rccl', 'rccl-abi', 'host-staged'],
+                    help='rccl: torch.distributed (nccl backend); rccl-abi: the library\'s own ctr_comm_* entry points; '
+                         'host-staged: gloo through host memory, to rehearse N>1 with all ranks on one GPU')
     ap.add_argument('--shard', default=None, choices=['table', 'row'],
                     help='N>1: whole tables per rank (default for the Criteo-Kaggle models), or row r of field f on rank '
                          '(r + f) %% N (default for DCN: its Criteo-1TB tables do not fit one owner)')
@@ -90,6 +91,9 @@ def build_model(variant, embed, shard, comm, sess, cards, rank, world):
     cls = getattr(importlib.import_module('%s.%s' % (name, name)), name)
     if world > 1:
         margs.world_size, margs.rank, margs.shard = world, rank, shard
+        if comm == 'rccl-abi':
+            from recommendation_amd.distributed import CtrComm
+            margs.comm = CtrComm()
         if comm == 'host-staged':
             from recommendation_amd.distributed import HostStagedComm
             margs.comm = HostStagedComm()

@@ -698,6 +698,30 @@ int ctr_dropout_apply2(float* x, int64_t ld, int rows, int cols_a, const ctr_dro
                        int cols_b, const ctr_dropout_t* drop_b, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Collectives of the sharded tables and the data-parallel towers, one communicator per process and GPU, over
+ * RCCL (xGMI inside a node).  The reference is one process (DeepFM/main.py:69 opens a single tf.Session) and has
+ * no counterpart; these are what a host that binds only this header needs for the multi-GPU path:
+ *   - ids out / rows back / gradient rows out of the table- and row-sharded lookups: ctr_all2all (equal pieces,
+ *     sizes known on the host: no count exchange) or ctr_all2allv;
+ *   - the towers' flat gradient buffer: ctr_allreduce_sum_f32 (the loss gradient is pre-scaled by 1 / world).
+ * RCCL is loaded at the first call; every call enqueues on `stream` and returns.  Bootstrap: rank 0 calls
+ * ctr_comm_unique_id and hands the CTR_COMM_ID_BYTES bytes to every rank by any means (file, socket, MPI); every
+ * rank then calls ctr_comm_init with its GPU current.  Offsets and sizes are bytes; piece p goes to / comes from
+ * rank p.
+ * ---------------------------------------------------------------------------------- */
+#define CTR_COMM_ID_BYTES 128
+typedef struct ctr_comm ctr_comm_t;
+int ctr_comm_unique_id(void* id_out);
+int ctr_comm_init(const void* id, int world, int rank, ctr_comm_t** comm_out);
+int ctr_comm_destroy(ctr_comm_t* comm);
+int ctr_comm_world(const ctr_comm_t* comm);
+int ctr_comm_rank(const ctr_comm_t* comm);
+int ctr_allreduce_sum_f32(ctr_comm_t* comm, float* buf, int64_t n, void* stream);
+int ctr_all2all(ctr_comm_t* comm, const void* send, void* recv, int64_t bytes_per_peer, void* stream);
+int ctr_all2allv(ctr_comm_t* comm, const void* send, const int64_t* send_offset, const int64_t* send_bytes,
+                 void* recv, const int64_t* recv_offset, const int64_t* recv_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Input text of the Criteo display-advertising sets -> the arrays a step is fed with (host code, no GPU).
  * Stands before the path where the reference's loaders stand (pandas.read_csv + the feed conversion,
  * DeepFM/main.py:13-43, DeepFM/DeepFM.py:37-39); the reference reads its own two-column CSV only.

@@ -45,6 +45,7 @@ class Epilogue(C.Structure):
 
 
 OPT_GRAD_ONLY, OPT_ADAM, OPT_ADAGRAD, OPT_SGD, OPT_FTRL = 0, 1, 2, 3, 4
+COMM_ID_BYTES = 128          # CTR_COMM_ID_BYTES
 LOSS_SIGMOID_LOGLOSS, LOSS_IDENTITY_LOGLOSS, LOSS_SIGMOID_SCE_PROB, LOSS_SCE_LOGIT, LOSS_PROB_SCE = 0, 1, 2, 3, 4
 
 i, i64, sz, f = C.c_int, C.c_int64, C.c_size_t, C.c_float
@@ -63,6 +64,14 @@ SIGNATURES = {
     'ctr_embed_bwd_dz': (i, [vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i, i, i, DP, DP, vp, i64, vp]),
     'ctr_embed_bwd_dz_blocks': (i, [vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i, i, i, DP, DP, vp, i64, vp, vp, vp, i, vp]),
     'ctr_embed_assemble_fwd': (i, [vp, vp, vp, vp, vp, i, i, i, i, vp, i64, i, vp, i64, vp, vp, i64, DP, DP, vp]),
+    'ctr_comm_unique_id': (i, [vp]),
+    'ctr_comm_init': (i, [vp, i, i, C.POINTER(vp)]),
+    'ctr_comm_destroy': (i, [vp]),
+    'ctr_comm_world': (i, [vp]),
+    'ctr_comm_rank': (i, [vp]),
+    'ctr_allreduce_sum_f32': (i, [vp, vp, i64, vp]),
+    'ctr_all2all': (i, [vp, vp, vp, i64, vp]),
+    'ctr_all2allv': (i, [vp, vp, vp, vp, vp, vp, vp, vp]),
     'ctr_criteo_tsv_count': (i64, [vp, i64]),
     'ctr_criteo_tsv_parse': (i, [vp, i64, vp, i, i, i64, vp, vp, vp, vp]),
     'ctr_emb_sort_workspace_bytes': (sz, [i64]),

@@ -66,6 +66,83 @@ class TorchComm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
 
+class CtrComm:
+    """The same collectives through the library's own entry points (ctr_comm_init / ctr_all2all(v) /
+    ctr_allreduce_sum_f32 over RCCL): what a host that binds only the C header uses.  The 128-byte id that rank 0
+    creates travels to the others through `exchange` (a callable: bytes-or-None on rank 0 -> bytes on every rank;
+    default: a broadcast over an initialised torch.distributed group, which then carries nothing else)."""
+
+    def __init__(self, world=None, rank=None, exchange=None):
+        import ctypes as C
+        from . import _lib
+        self._C, self.lib = C, _lib.load()
+        if world is None or rank is None:
+            import torch.distributed as dist
+            world, rank = dist.get_world_size(), dist.get_rank()
+        self.world, self.rank = int(world), int(rank)
+        ident = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        if self.rank == 0:
+            self._check(self.lib.ctr_comm_unique_id(ident))
+        if self.world > 1 or exchange is not None:
+            raw = (exchange or self._broadcast)(ident.raw if self.rank == 0 else None)
+            ident = C.create_string_buffer(bytes(raw), _lib.COMM_ID_BYTES)
+        self.handle = C.c_void_p()
+        self._check(self.lib.ctr_comm_init(ident, self.world, self.rank, C.byref(self.handle)))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.lib.ctr_last_error().decode())
+
+    @staticmethod
+    def _broadcast(raw):
+        import torch.distributed as dist
+        box = [raw]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def _stream(self):
+        return self._C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def all_to_all(self, out, inp, out_splits=None, in_splits=None):
+        """Rows of `inp` to the ranks, rows of `out` from them (split sizes in rows; None: W equal parts)."""
+        C = self._C
+        if not (out.is_contiguous() and inp.is_contiguous()):
+            raise ValueError('all_to_all needs contiguous tensors')
+        row_o = out.element_size() * (out.numel() // max(out.shape[0], 1))
+        row_i = inp.element_size() * (inp.numel() // max(inp.shape[0], 1))
+        if out_splits is None and in_splits is None and out.shape[0] % self.world == 0 and inp.shape[0] % self.world == 0 \
+                and out.shape[0] * row_o == inp.shape[0] * row_i:
+            self._check(self.lib.ctr_all2all(self.handle, C.c_void_p(inp.data_ptr()), C.c_void_p(out.data_ptr()),
+                                             inp.shape[0] // self.world * row_i, self._stream()))
+            return
+        out_splits = [out.shape[0] // self.world] * self.world if out_splits is None else list(out_splits)
+        in_splits = [inp.shape[0] // self.world] * self.world if in_splits is None else list(in_splits)
+        arr = lambda v: (C.c_int64 * self.world)(*[int(x) for x in v])
+        offs = lambda v: [sum(v[:k]) for k in range(self.world)]
+        self._check(self.lib.ctr_all2allv(self.handle, C.c_void_p(inp.data_ptr()), arr([o * row_i for o in offs(in_splits)]),
+                                          arr([n * row_i for n in in_splits]), C.c_void_p(out.data_ptr()),
+                                          arr([o * row_o for o in offs(out_splits)]), arr([n * row_o for n in out_splits]),
+                                          self._stream()))
+
+    def all_reduce_sum(self, t):
+        if t.dtype == torch.int32:                 # the small event counters (overflowed buckets, bad ids): exact in float32
+            f = t.to(torch.float32)
+            self.all_reduce_sum(f)
+            t.copy_(f)
+            return
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError('all_reduce_sum takes a contiguous float32 (or int32 counter) tensor')
+        self._check(self.lib.ctr_allreduce_sum_f32(self.handle, self._C.c_void_p(t.data_ptr()), t.numel(), self._stream()))
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            torch.cuda.synchronize()
+            self.lib.ctr_comm_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+
 class HostStagedComm:
     """Same collectives staged through host memory over a gloo group.  For rehearsing the multi-rank
     path when several ranks share one GPU (RCCL cannot place two ranks on one device); never the

@@ -33,3 +33,13 @@ def test_rccl_transport_one_rank(sess):
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'RCCL_OK backend=nccl' in r.stdout
+
+
+def test_library_collectives_one_rank(sess):
+    """ctr_comm_* / ctr_all2all(v) / ctr_allreduce_sum_f32 (RCCL behind the C ABI) and distributed.CtrComm: one rank,
+    raw calls and both sharded layouts against the unsharded front end, in a process of its own."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'comm_abi_worker.py')], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'CTR_COMM_OK' in r.stdout
