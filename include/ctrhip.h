@@ -250,6 +250,21 @@ int ctr_emb_sparse_apply_ld(const uint32_t* keys_sorted, const uint32_t* src_sor
                             float* tables, float* slot0, float* slot1, int64_t slot_ld,
                             const ctr_opt_t* opt, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ctr_emb_sparse_apply_ld for a gradient whose rows lack the FM second-order term's product with the looked-up
+ * row (ctr_fm_bwd_t with z == NULL): with g_second ([B, E] rows at pitch g_second_ld, 8-byte aligned, the
+ * gradient with respect to the second-order term with its keep mask on) the gradient of table row k becomes
+ *   sum_j dz[src_j] - (sum_j g_second[b_j, :]) * tables[k, :]        (j over the run of key k, b_j = src_j / N)
+ * with tables[k] read before the update: gradient of DeepFM/DeepFM.py:59-63 with respect to the looked-up row,
+ * d/dz 0.5 ((sum z)^2 - sum z^2) = s - z, whose -z part is the same row for every lookup of k.  Both sums keep
+ * the fixed order of the plain form.  Rows of at most 32 floats; tables is required (read even for
+ * CTR_OPT_GRAD_ONLY).  Workspace: ctr_emb_sparse_apply_fm_workspace_bytes. */
+size_t ctr_emb_sparse_apply_fm_workspace_bytes(int64_t n_items, int E);
+int ctr_emb_sparse_apply_fm(const uint32_t* keys_sorted, const uint32_t* src_sorted, int64_t n_items,
+                            int N, int E, int64_t total_rows,
+                            const float* dz, int64_t dz_ld, const float* g_second, int64_t g_second_ld,
+                            float* tables, float* slot0, float* slot1, int64_t slot_ld,
+                            const ctr_opt_t* opt, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Dense tower pieces.
  * Replaces: tf.matmul + bias + relu + tf.layers.dropout chains and their gradients
@@ -270,6 +285,9 @@ int ctr_emb_sparse_apply_ld(const uint32_t* keys_sorted, const uint32_t* src_sor
  * (gradient of DeepFM/DeepFM.py:55-66).  g_first / g_second are the gradients with respect to the first- and
  * second-order terms BEFORE their dropout (ctr_dropout_apply puts the keep masks on them); each is optional;
  * s ([M,E] contiguous) and z are needed with g_second and must be 16-byte aligned with z_ld % 4 == 0, E % 4 == 0.
+ * z == NULL leaves the z term out (C += g_first + g_second * s): for the single-id lookup a row of Z IS the table
+ * row, the same for every lookup of it, so the term is subtracted once per table row by the row update instead
+ * (ctr_emb_sparse_apply_fm) and the product does not read Z.
  * ---------------------------------------------------------------------------------- */
 typedef struct {
   const float* g_first;

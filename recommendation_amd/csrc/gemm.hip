@@ -46,7 +46,8 @@ __device__ static inline float epilogue(const Epi& e, float v, int m, int n, int
     const int f = n / e.fm.E, c = n - f * e.fm.E;
     if (e.fm.g1) v += e.fm.g1[(int64_t)m * e.fm.g1_ld + f];
     if (e.fm.g2)
-      v = fmaf(e.fm.g2[(int64_t)m * e.fm.g2_ld + c], e.fm.s[(int64_t)m * e.fm.E + c] - e.fm.z[(int64_t)m * e.fm.z_ld + n], v);
+      v = fmaf(e.fm.g2[(int64_t)m * e.fm.g2_ld + c],
+               e.fm.s[(int64_t)m * e.fm.E + c] - (e.fm.z ? e.fm.z[(int64_t)m * e.fm.z_ld + n] : 0.f), v);
   }
   return v;
 }
@@ -177,7 +178,7 @@ __device__ static inline void tile_epilogue(f32x16 (&acc)[TM][TN], float* smem, 
           fz[j][it] = make_float4(0.f, 0.f, 0.f, 0.f);
           fg1[j][it] = 0.f;
           if (m < M && n < epi.fm.cols) {
-            if (epi.fm.g2) fz[j][it] = *reinterpret_cast<const float4*>(epi.fm.z + (int64_t)m * epi.fm.z_ld + n);
+            if (epi.fm.g2 && epi.fm.z) fz[j][it] = *reinterpret_cast<const float4*>(epi.fm.z + (int64_t)m * epi.fm.z_ld + n);
             if (epi.fm.g1) fg1[j][it] = epi.fm.g1[(int64_t)m * epi.fm.g1_ld + (n >> epi.fm.eshift)];
           }
         }
@@ -268,7 +269,8 @@ __device__ static inline void tile_epilogue(f32x16 (&acc)[TM][TN], float* smem, 
                 for (int u = 0; u < 4; ++u) v[u] += t;
               }
               if (epi.fm.g2) {
-                const float4 zz = *reinterpret_cast<const float4*>(epi.fm.z + (int64_t)m * epi.fm.z_ld + n);
+                const float4 zz = epi.fm.z ? *reinterpret_cast<const float4*>(epi.fm.z + (int64_t)m * epi.fm.z_ld + n)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float4 ss = *reinterpret_cast<const float4*>(epi.fm.s + (int64_t)m * epi.fm.E + c);
                 const float* g2 = epi.fm.g2 + (int64_t)m * epi.fm.g2_ld + c;
                 v[0] = fmaf(g2[0], ss.x - zz.x, v[0]);
@@ -1273,9 +1275,11 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
       CTR_REQUIRE(q->n_rows > 0 && q->E > 0 && q->E % 4 == 0 && (int64_t)q->n_rows * q->E <= N,
                   "ctr_gemm_f32: fm_bwd needs n_rows*E <= N and E %% 4 == 0");
       CTR_REQUIRE(!q->g_first || q->g_first_ld >= q->n_rows, "ctr_gemm_f32: fm_bwd g_first_ld too small");
-      CTR_REQUIRE(!q->g_second || (q->g_second_ld >= q->E && q->s && q->z && q->z_ld >= (int64_t)q->n_rows * q->E &&
-                                   q->z_ld % 4 == 0 && ((uintptr_t)q->z % 16) == 0 && ((uintptr_t)q->s % 16) == 0),
-                  "ctr_gemm_f32: fm_bwd with g_second needs s and a 16-byte aligned z with z_ld %% 4 == 0");
+      CTR_REQUIRE(!q->g_second || (q->g_second_ld >= q->E && q->s && ((uintptr_t)q->s % 16) == 0 &&
+                                   (!q->z || (q->z_ld >= (int64_t)q->n_rows * q->E && q->z_ld % 4 == 0 &&
+                                              ((uintptr_t)q->z % 16) == 0))),
+                  "ctr_gemm_f32: fm_bwd with g_second needs a 16-byte aligned s and, if given, a 16-byte aligned z with "
+                  "z_ld %% 4 == 0");
       e.fm.on = 1; e.fm.E = q->E; e.fm.cols = q->n_rows * q->E;
       e.fm.eshift = -1;
       for (int sh = 2; sh < 31; ++sh)

@@ -209,12 +209,16 @@ static inline DivU32 make_div(uint32_t d) {
 // row 0 (its sum joins no run that is applied); table rows of the pairs that end no run are not touched (their
 // lanes load row 0 and store nothing).  Same outputs as the kernel above (part, part_head, head_key
 // for the tail pass); a run's rows are added in pair order, grouped as ((lane-serial) + groups scan).
-template <int G>
+// FM: the gradient rows lack the FM second-order term's product with the looked-up row; a second sum along every run,
+// of g2[sample, :] (the gradient with respect to the second-order term), is carried through the same chain, scan and
+// pieces (part2 / part_head2), and a run's gradient becomes sum(dz) - sum(g2) * W_old[key].
+template <int G, bool FM = false>
 __global__ __launch_bounds__(256) void sparse_apply_lean_kernel(
     const uint32_t* __restrict__ keys, const uint32_t* __restrict__ src, int64_t n_items, int N, DivU32 divN,
     int64_t total_rows, const float* __restrict__ dz, int64_t dz_ld, const float* __restrict__ src_scale,
     float* __restrict__ tables, float* __restrict__ slot0, float* __restrict__ slot1, int64_t slot_ld, Opt opt,
-    float* __restrict__ part, float* __restrict__ part_head, uint32_t* __restrict__ head_key) {
+    float* __restrict__ part, float* __restrict__ part_head, uint32_t* __restrict__ head_key,
+    const float* __restrict__ g2, int64_t g2_ld, float* __restrict__ part2, float* __restrict__ part_head2) {
   opt = resolve_opt(opt);
   constexpr int R = 64 / G, IPG = G, E = 4 * G;
   const int lane = threadIdx.x & 63;
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(256) void sparse_apply_lean_kernel(
   // Which pairs end a run, and how, follows from the keys alone: the table rows of those that get an optimizer step
   // are requested here, together with the gradient rows, so a wave waits for memory twice (keys, then rows), not
   // three times.  A pair that ends nothing loads row 0 and stores nothing.
-  float4 val[IPG], p[IPG], a[IPG], c[IPG];
+  float4 val[IPG], p[IPG], a[IPG], c[IPG], gq[FM ? IPG : 1];
   bool in[IPG], live[IPG], more[IPG];                  // in the block; key inside the tables; next pair has the same key
   bool app[IPG], to_part[IPG], to_head[IPG];
   uint32_t recorded = NO_KEY;
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(256) void sparse_apply_lean_kernel(
     const int64_t off = app[u] ? (int64_t)k[u] * E + g * 4 : 0;
     const int64_t soff = app[u] ? (int64_t)k[u] * slot_ld + g * 4 : 0;
     p[u] = a[u] = c[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (opt.kind != CTR_OPT_GRAD_ONLY) p[u] = *reinterpret_cast<const float4*>(tables + off);
+    if (FM || opt.kind != CTR_OPT_GRAD_ONLY) p[u] = *reinterpret_cast<const float4*>(tables + off);
     if (opt.kind == CTR_OPT_ADAM || opt.kind == CTR_OPT_ADAGRAD || opt.kind == CTR_OPT_FTRL)
       a[u] = *reinterpret_cast<const float4*>(slot0 + soff);
     if (opt.kind == CTR_OPT_ADAM || opt.kind == CTR_OPT_FTRL) c[u] = *reinterpret_cast<const float4*>(slot1 + soff);
@@ -274,6 +278,11 @@ __global__ __launch_bounds__(256) void sparse_apply_lean_kernel(
     const uint32_t sb = divN.quot(sr[u]), sn = sr[u] - sb * (uint32_t)N;      // source = sample * N + row of the sample
     // a pair outside the block or the tables reads row 0: its sum joins no run that is applied
     val[u] = *reinterpret_cast<const float4*>(dz + (live[u] ? (int64_t)sb * dz_ld + sn * E : 0) + g * 4);
+    if (FM) {   // rows of g2 are 8-byte aligned (a column block of a wider buffer)
+      const float* q2 = g2 + (live[u] ? (int64_t)sb * g2_ld : 0) + g * 4;
+      const float2 lo = *reinterpret_cast<const float2*>(q2), hi = *reinterpret_cast<const float2*>(q2 + 2);
+      gq[u] = make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
   }
   if (src_scale) {
 #pragma unroll
@@ -290,27 +299,41 @@ __global__ __launch_bounds__(256) void sparse_apply_lean_kernel(
     const bool same = in[u] && k[u] == k[u - 1];
     chain[u] = chain[u - 1] && same;
     if (same) { val[u].x += val[u - 1].x; val[u].y += val[u - 1].y; val[u].z += val[u - 1].z; val[u].w += val[u - 1].w; }
+    if (FM && same) { gq[u].x += gq[u - 1].x; gq[u].y += gq[u - 1].y; gq[u].z += gq[u - 1].z; gq[u].w += gq[u - 1].w; }
   }
   // the groups' last runs: T = sum of the group's last run, head = it does not continue the previous group's
   const bool joins = q > 0 && in[0] && k[0] == kprev;        // the group's first pair continues the previous group
-  float4 T = val[IPG - 1];
+  float4 T = val[IPG - 1], T2 = FM ? gq[IPG - 1] : make_float4(0.f, 0.f, 0.f, 0.f);
   bool head = !(chain[IPG - 1] && joins);
 #pragma unroll
   for (int d = 1; d < R; d <<= 1) {
     const float4 pT = shfl_up4(T, d * G);
+    float4 pT2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (FM) pT2 = shfl_up4(T2, d * G);
     const int ph = __shfl_up((int)head, d * G);
     if (q >= d && !head) {
       T.x = pT.x + T.x; T.y = pT.y + T.y; T.z = pT.z + T.z; T.w = pT.w + T.w;
+      if (FM) { T2.x = pT2.x + T2.x; T2.y = pT2.y + T2.y; T2.z = pT2.z + T2.z; T2.w = pT2.w + T2.w; }
       head = ph != 0;
     }
   }
   float4 carry = shfl_up4(T, G);                             // the run that ends the previous group, whole
-  if (!joins) carry = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 carry2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (FM) carry2 = shfl_up4(T2, G);
+  if (!joins) carry = carry2 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int u = 0; u < IPG; ++u) {
     if (chain[u]) { val[u].x = carry.x + val[u].x; val[u].y = carry.y + val[u].y; val[u].z = carry.z + val[u].z; val[u].w = carry.w + val[u].w; }
     if (to_part[u]) *reinterpret_cast<float4*>(part + blk * E + g * 4) = val[u];
     if (to_head[u]) *reinterpret_cast<float4*>(part_head + blk * E + g * 4) = val[u];
+    if (FM) {
+      if (chain[u]) { gq[u].x = carry2.x + gq[u].x; gq[u].y = carry2.y + gq[u].y; gq[u].z = carry2.z + gq[u].z; gq[u].w = carry2.w + gq[u].w; }
+      if (to_part[u]) *reinterpret_cast<float4*>(part2 + blk * E + g * 4) = gq[u];
+      if (to_head[u]) *reinterpret_cast<float4*>(part_head2 + blk * E + g * 4) = gq[u];
+      // the run's gradient: minus (sum of g2) times the row as it stood before this update
+      val[u].x = fmaf(-gq[u].x, p[u].x, val[u].x); val[u].y = fmaf(-gq[u].y, p[u].y, val[u].y);
+      val[u].z = fmaf(-gq[u].z, p[u].z, val[u].z); val[u].w = fmaf(-gq[u].w, p[u].w, val[u].w);
+    }
   }
 #pragma unroll
   for (int u = 0; u < IPG; ++u) opt_math4(opt, val[u], p[u], a[u], c[u]);
@@ -329,12 +352,12 @@ __global__ __launch_bounds__(256) void sparse_apply_lean_kernel(
 // blocks only; a hot key's run spans hundreds of blocks, and from the second trip on the wave asks for the first keys
 // and the pieces of 8 * R blocks together (no load waits for another: a block past the arrays reads the last one's).
 // Every lane adds its pieces in ascending order, then the lanes are combined by a fixed shuffle tree.
-template <int G>
+template <int G, bool FM = false>
 __global__ __launch_bounds__(256) void sparse_apply_tail_kernel(
     const uint32_t* __restrict__ keys, int64_t n_items, int64_t n_blocks, int E,
     float* __restrict__ tables, float* __restrict__ slot0, float* __restrict__ slot1, int64_t slot_ld, Opt opt,
     const float* __restrict__ part, const float* __restrict__ part_head,
-    const uint32_t* __restrict__ head_key) {
+    const uint32_t* __restrict__ head_key, const float* __restrict__ part2, const float* __restrict__ part_head2) {
   opt = resolve_opt(opt);
   constexpr int R = 64 / G;
   constexpr int TU = 8;
@@ -344,8 +367,9 @@ __global__ __launch_bounds__(256) void sparse_apply_tail_kernel(
   const uint32_t key = head_key[blk];
   if (key == NO_KEY) return;
   const int g = lane % G, r = lane / G;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (r == 0) acc = *reinterpret_cast<const float4*>(part_head + blk * E + g * 4);
+  if (FM && r == 0) acc2 = *reinterpret_cast<const float4*>(part_head2 + blk * E + g * 4);
   // continuation pieces sit in blocks blk+1, blk+2, ... while the block's first key is `key`
   bool more;
   {
@@ -354,16 +378,21 @@ __global__ __launch_bounds__(256) void sparse_apply_tail_kernel(
     const float4 v = *reinterpret_cast<const float4*>(part + kc * E + g * 4);
     const bool ok = k < n_blocks && fk == key;
     if (ok) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    if (FM) {
+      const float4 v2 = *reinterpret_cast<const float4*>(part2 + kc * E + g * 4);
+      if (ok) { acc2.x += v2.x; acc2.y += v2.y; acc2.z += v2.z; acc2.w += v2.w; }
+    }
     more = __ballot(ok) == __ballot(1);            // the run ends inside a trip as soon as one slot misses
   }
   for (int64_t k0 = blk + 1 + R; more && k0 < n_blocks; k0 += TU * R) {
     uint32_t fk[TU];
-    float4 v[TU];
+    float4 v[TU], v2[FM ? TU : 1];
 #pragma unroll
     for (int u = 0; u < TU; ++u) {
       const int64_t k = k0 + u * R + r, kc = k < n_blocks ? k : n_blocks - 1;
       fk[u] = keys[kc * SEG];
       v[u] = *reinterpret_cast<const float4*>(part + kc * E + g * 4);
+      if (FM) v2[u] = *reinterpret_cast<const float4*>(part2 + kc * E + g * 4);
     }
     bool all = true;
 #pragma unroll
@@ -371,6 +400,7 @@ __global__ __launch_bounds__(256) void sparse_apply_tail_kernel(
       // a block past the run's first miss can carry the key again only if it is the same run: keys are sorted
       const bool ok = k0 + u * R + r < n_blocks && fk[u] == key;
       if (ok) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+      if (FM && ok) { acc2.x += v2[u].x; acc2.y += v2[u].y; acc2.z += v2[u].z; acc2.w += v2[u].w; }
       all = all && ok;
     }
     more = __ballot(all) == __ballot(1);
@@ -379,9 +409,18 @@ __global__ __launch_bounds__(256) void sparse_apply_tail_kernel(
   for (int o = G; o < 64; o <<= 1) {
     acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o);
     acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
+    if (FM) {
+      acc2.x += __shfl_xor(acc2.x, o); acc2.y += __shfl_xor(acc2.y, o);
+      acc2.z += __shfl_xor(acc2.z, o); acc2.w += __shfl_xor(acc2.w, o);
+    }
   }
   if (r == 0) {
     const int64_t off = (int64_t)key * E + g * 4, soff = (int64_t)key * slot_ld + g * 4;
+    if (FM) {
+      const float4 w0 = *reinterpret_cast<const float4*>(tables + off);
+      acc.x = fmaf(-acc2.x, w0.x, acc.x); acc.y = fmaf(-acc2.y, w0.y, acc.y);
+      acc.z = fmaf(-acc2.z, w0.z, acc.z); acc.w = fmaf(-acc2.w, w0.w, acc.w);
+    }
     opt_apply4(opt, acc, reinterpret_cast<float4*>(tables + off),
                slot0 ? reinterpret_cast<float4*>(slot0 + soff) : nullptr,
                slot1 ? reinterpret_cast<float4*>(slot1 + soff) : nullptr);
@@ -425,9 +464,13 @@ static Opt make_opt(const ctr_opt_t* o) {
 
 using namespace ctr;
 
-static size_t apply_ws_bytes(int64_t n_items, int E) {
+static size_t apply_ws_bytes(int64_t n_items, int E, bool fm = false) {
   const int64_t nb = cdiv(n_items > 0 ? n_items : 1, SEG);
-  return 2 * align_up((size_t)nb * E * sizeof(float), 256) + align_up((size_t)nb * sizeof(uint32_t), 256);
+  return (fm ? 4 : 2) * align_up((size_t)nb * E * sizeof(float), 256) + align_up((size_t)nb * sizeof(uint32_t), 256);
+}
+
+extern "C" size_t ctr_emb_sparse_apply_fm_workspace_bytes(int64_t n_items, int E) {
+  return apply_ws_bytes(n_items, E, true);
 }
 
 extern "C" size_t ctr_emb_sparse_apply_workspace_bytes(int64_t n_items, int E) {
@@ -443,11 +486,35 @@ extern "C" int ctr_emb_sparse_apply(const uint32_t* keys_sorted, const uint32_t*
                                  slot0, slot1, E, opt, workspace, workspace_bytes, stream);
 }
 
+static int apply_impl(const uint32_t* keys_sorted, const uint32_t* src_sorted, int64_t n_items, int N, int E,
+                      int64_t total_rows, const float* dz, int64_t dz_ld, const float* src_scale, const float* g2,
+                      int64_t g2_ld, float* tables, float* slot0, float* slot1, int64_t slot_ld, const ctr_opt_t* opt,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int ctr_emb_sparse_apply_ld(const uint32_t* keys_sorted, const uint32_t* src_sorted,
                                        int64_t n_items, int N, int E, int64_t total_rows, const float* dz,
                                        int64_t dz_ld, const float* src_scale, float* tables, float* slot0,
                                        float* slot1, int64_t slot_ld, const ctr_opt_t* opt, void* workspace,
                                        size_t workspace_bytes, void* stream) {
+  return apply_impl(keys_sorted, src_sorted, n_items, N, E, total_rows, dz, dz_ld, src_scale, nullptr, 0, tables, slot0,
+                    slot1, slot_ld, opt, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ctr_emb_sparse_apply_fm(const uint32_t* keys_sorted, const uint32_t* src_sorted, int64_t n_items, int N,
+                                       int E, int64_t total_rows, const float* dz, int64_t dz_ld, const float* g_second,
+                                       int64_t g_second_ld, float* tables, float* slot0, float* slot1, int64_t slot_ld,
+                                       const ctr_opt_t* opt, void* workspace, size_t workspace_bytes, void* stream) {
+  CTR_REQUIRE(g_second && tables, "ctr_emb_sparse_apply_fm: g_second and tables are required");
+  CTR_REQUIRE(E <= 32 && g_second_ld >= E && g_second_ld % 2 == 0 && ((uintptr_t)g_second % 8) == 0,
+              "ctr_emb_sparse_apply_fm: rows of at most 32 floats; g_second 8-byte aligned with an even row pitch >= E");
+  return apply_impl(keys_sorted, src_sorted, n_items, N, E, total_rows, dz, dz_ld, nullptr, g_second, g_second_ld, tables,
+                    slot0, slot1, slot_ld, opt, workspace, workspace_bytes, stream);
+}
+
+static int apply_impl(const uint32_t* keys_sorted, const uint32_t* src_sorted, int64_t n_items, int N, int E,
+                      int64_t total_rows, const float* dz, int64_t dz_ld, const float* src_scale, const float* g2,
+                      int64_t g2_ld, float* tables, float* slot0, float* slot1, int64_t slot_ld, const ctr_opt_t* opt,
+                      void* workspace, size_t workspace_bytes, void* stream) {
   CTR_REQUIRE(opt, "ctr_emb_sparse_apply: opt is null");
   CTR_REQUIRE(slot_ld >= E && slot_ld % 4 == 0 && ((uintptr_t)slot0 % 16) == 0 && ((uintptr_t)slot1 % 16) == 0,
               "ctr_emb_sparse_apply: slot_ld must be a multiple of 4 floats, at least E, and the slots 16-byte aligned");
@@ -464,8 +531,9 @@ extern "C" int ctr_emb_sparse_apply_ld(const uint32_t* keys_sorted, const uint32
     case CTR_OPT_FTRL: CTR_REQUIRE(tables && slot0 && slot1, "ctr_emb_sparse_apply: FTRL needs tables, n, z"); break;
     default: CTR_REQUIRE(false, "ctr_emb_sparse_apply: unknown optimizer kind %d", opt->kind);
   }
-  if (!workspace || workspace_bytes < apply_ws_bytes(n_items, E)) {
-    set_error("ctr_emb_sparse_apply: workspace %zu < %zu", workspace_bytes, apply_ws_bytes(n_items, E));
+  const bool fm = g2 != nullptr;
+  if (!workspace || workspace_bytes < apply_ws_bytes(n_items, E, fm)) {
+    set_error("ctr_emb_sparse_apply: workspace %zu < %zu", workspace_bytes, apply_ws_bytes(n_items, E, fm));
     return CTR_EWORKSPACE;
   }
   const Opt o = make_opt(opt);
@@ -475,19 +543,44 @@ extern "C" int ctr_emb_sparse_apply_ld(const uint32_t* keys_sorted, const uint32
   char* wsp = (char*)workspace;
   float* part = (float*)wsp; wsp += align_up((size_t)nb * E * sizeof(float), 256);
   float* part_head = (float*)wsp; wsp += align_up((size_t)nb * E * sizeof(float), 256);
+  float *part2 = nullptr, *part_head2 = nullptr;
+  if (fm) {
+    part2 = (float*)wsp; wsp += align_up((size_t)nb * E * sizeof(float), 256);
+    part_head2 = (float*)wsp; wsp += align_up((size_t)nb * E * sizeof(float), 256);
+  }
   uint32_t* head_key = (uint32_t*)wsp;
   const dim3 grid((unsigned)cdiv(nb, 4)), block(256);  // one wave per block of SEG pairs; it also sets head_key
   const dim3 grid2((unsigned)cdiv(nb, 4));
   // GRAD_ONLY writes through slot0 only; give the kernel a non-null table pointer it never uses.
   float* tab = tables ? tables : slot0;
   // pair arrays addressable with 32-bit offsets: the short kernel
+  CTR_REQUIRE(!fm || (G <= 8 && fits_buffer(n_items * 4 + 4)), "ctr_emb_sparse_apply_fm: at most 2^30 pairs");
+  if (fm) {
+    const DivU32 divN = make_div((uint32_t)N);
+#define LEANFM(GG)                                                                                              \
+  hipLaunchKernelGGL((sparse_apply_lean_kernel<GG, true>), grid, block, 0, st, keys_sorted, src_sorted, n_items, N, divN, \
+                     total_rows, dz, dz_ld, src_scale, tab, slot0, slot1, slot_ld, o, part, part_head, head_key, g2,      \
+                     g2_ld, part2, part_head2);                                                                           \
+  hipLaunchKernelGGL((sparse_apply_tail_kernel<GG, true>), grid2, block, 0, st, keys_sorted, n_items, nb, E, tab, slot0,  \
+                     slot1, slot_ld, o, part, part_head, head_key, part2, part_head2)
+    switch (G) {
+      case 1: LEANFM(1); break;
+      case 2: LEANFM(2); break;
+      case 4: LEANFM(4); break;
+      case 8: LEANFM(8); break;
+    }
+#undef LEANFM
+    CTR_LAUNCH_CHECK();
+    return CTR_OK;
+  }
   if (G <= 8 && fits_buffer(n_items * 4 + 4) && tables) {
     const DivU32 divN = make_div((uint32_t)N);
 #define LEAN(GG)                                                                                          \
   hipLaunchKernelGGL(sparse_apply_lean_kernel<GG>, grid, block, 0, st, keys_sorted, src_sorted, n_items, N, divN,      \
-                     total_rows, dz, dz_ld, src_scale, tab, slot0, slot1, slot_ld, o, part, part_head, head_key);      \
+                     total_rows, dz, dz_ld, src_scale, tab, slot0, slot1, slot_ld, o, part, part_head, head_key,       \
+                     (const float*)nullptr, (int64_t)0, (float*)nullptr, (float*)nullptr);                             \
   hipLaunchKernelGGL(sparse_apply_tail_kernel<GG>, grid2, block, 0, st, keys_sorted, n_items, nb, E, tab, \
-                     slot0, slot1, slot_ld, o, part, part_head, head_key)
+                     slot0, slot1, slot_ld, o, part, part_head, head_key, (const float*)nullptr, (const float*)nullptr)
     switch (G) {
       case 1: LEAN(1); break;
       case 2: LEAN(2); break;
@@ -502,7 +595,7 @@ extern "C" int ctr_emb_sparse_apply_ld(const uint32_t* keys_sorted, const uint32
   hipLaunchKernelGGL(sparse_apply_kernel<GG>, grid, block, 0, st, keys_sorted, src_sorted, n_items, N, \
                      E, total_rows, dz, dz_ld, src_scale, tab, slot0, slot1, slot_ld, o, part, part_head, head_key); \
   hipLaunchKernelGGL(sparse_apply_tail_kernel<GG>, grid2, block, 0, st, keys_sorted, n_items, nb, E, tab, \
-                     slot0, slot1, slot_ld, o, part, part_head, head_key)
+                     slot0, slot1, slot_ld, o, part, part_head, head_key, (const float*)nullptr, (const float*)nullptr)
   switch (G) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;

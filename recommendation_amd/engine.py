@@ -275,8 +275,10 @@ class EmbedFront:
         ops.emb_sort(idx, t.row_offset, N=self.N, total_rows=t.total_rows, rmode=(self.mode == 'R'),
                      keys_out=keys, src_out=src, ws=ws)
 
-    def backward_tables(self, idx, dz, keys, src, ws, opt, lazy, presorted=False):
-        """dz: [B, >= N*E] gradient with respect to Z.  Sort (key, src), segment-reduce, update."""
+    def backward_tables(self, idx, dz, keys, src, ws, opt, lazy, presorted=False, fm_g2=None):
+        """dz: [B, >= N*E] gradient with respect to Z.  Sort (key, src), segment-reduce, update.
+        fm_g2 (optional): dz lacks -g2 * Z of the FM second-order term; the update subtracts it per table row
+        (single-id standard lookup only: a row of Z is the table row)."""
         t = self.t
         B, F = idx.shape
         n_items = idx.nnz if isinstance(idx, Bags) else B * F     # one pair per bag member
@@ -284,14 +286,17 @@ class EmbedFront:
             return
         if not presorted:
             self.sort_pairs(idx, keys, src, ws)
+        if fm_g2 is not None and (self.mode != 'S' or isinstance(idx, Bags) or self.cont_embed):
+            raise ValueError('fm_g2 is defined for the single-id standard lookup without embedded continuous rows')
         if opt.kind == OPT_ADAM and not lazy:
             t.grad.zero_()
             ops.emb_sparse_apply(keys, src, n_items, N=self.N, E=self.E, total_rows=t.total_rows, dz=dz,
-                                 opt=ops.make_opt(OPT_GRAD_ONLY), slot0=t.grad, ws=ws)
+                                 opt=ops.make_opt(OPT_GRAD_ONLY), slot0=t.grad, ws=ws,
+                                 **(dict(tables=t.weight, fm_g2=fm_g2) if fm_g2 is not None else {}))
             ops.dense_update(t.weight, t.grad, opt, t.slot0, t.slot1)
         else:
             ops.emb_sparse_apply(keys, src, n_items, N=self.N, E=self.E, total_rows=t.total_rows, dz=dz,
-                                 opt=opt, tables=t.weight, slot0=t.slot0, slot1=t.slot1, ws=ws)
+                                 opt=opt, tables=t.weight, slot0=t.slot0, slot1=t.slot1, ws=ws, fm_g2=fm_g2)
 
     def backward_cont_w(self, dz, x_cont, g_cont_w, ws):
         """d cont_w[c,:] = sum_b dz[b, Ncat + c, :] * x_cont[b,c]."""

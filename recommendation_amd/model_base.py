@@ -764,8 +764,10 @@ class CTRModel(GraphOwner):
         route = getattr(self.front, 'dz_route', None)
         return route(B) if route is not None else {}
 
-    def _tables_backward(self, idx, dz, bufs, routed=False):
+    def _tables_backward(self, idx, dz, bufs, routed=False, fm_g2=None):
         kw = dict(dz_in_blocks=True) if routed and hasattr(self.front, 'dz_route') else {}
+        if fm_g2 is not None:
+            kw['fm_g2'] = fm_g2
         keys, src = bufs['keys'], bufs['src']
         if isinstance(idx, Bags) and idx.nnz > keys.numel():
             # one pair per bag member: a pair of buffers that only grows, shared by every batch size

@@ -527,11 +527,20 @@ def make_opt(kind, lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8, l1=0.0, l2=0.0, lr_
                l1=float(l1), l2=float(l2), lr_dev=None if lr_dev is None else lr_dev.data_ptr())
 
 
+def emb_sparse_apply_fm_supported(E, g2):
+    """Whether emb_sparse_apply takes fm_g2 = g2 (rows of at most 32 floats, 8-byte aligned rows of g2)."""
+    return (E <= 32 and E % 4 == 0 and g2.dim() == 2 and g2.shape[1] == E and g2.stride(1) == 1 and g2.stride(0) % 2 == 0
+            and g2.data_ptr() % 8 == 0 and g2.dtype == torch.float32)
+
+
 @_timed
 def emb_sparse_apply(keys, src, n_items, *, N, E, total_rows, dz, opt, ws, tables=None, slot0=None, slot1=None,
-                     src_scale=None):
+                     src_scale=None, fm_g2=None):
     """slot0 / slot1: [total_rows, E], contiguous or both column blocks of one wider row-major buffer (the same row
-    pitch: Adam's m | v side by side, engine.EmbeddingTables)."""
+    pitch: Adam's m | v side by side, engine.EmbeddingTables).
+    fm_g2 (optional [B, E] view): dz was formed without the FM second-order term's product with the looked-up row
+    (gemm fm_bwd with z None); a run's gradient is then sum(dz) - sum(fm_g2[sample]) * tables[key]
+    (ctr_emb_sparse_apply_fm; see emb_sparse_apply_fm_supported)."""
     dzp, dzld = _rows(dz, 'dz')
     if tables is not None and (tables.numel() < total_rows * E or not tables.is_contiguous()):
         raise ValueError('tables must be contiguous [total_rows, E]')
@@ -547,6 +556,16 @@ def emb_sparse_apply(keys, src, n_items, *, N, E, total_rows, dz, opt, ws, table
             raise ValueError('slot0 and slot1 must share one row pitch')
     if dz.shape[1] < N * E:
         raise ValueError('dz narrower than N*E')
+    if fm_g2 is not None:
+        if src_scale is not None or tables is None or not emb_sparse_apply_fm_supported(E, fm_g2):
+            raise ValueError('fm_g2 needs tables, no src_scale, E <= 32 and an 8-byte aligned [B, E] view with an even row pitch')
+        g2p, g2ld = _rows(fm_g2, 'fm_g2')
+        wp, wn = ws.get(lib().ctr_emb_sparse_apply_fm_workspace_bytes(int(n_items), E))
+        check(lib().ctr_emb_sparse_apply_fm(_ptr(keys), _ptr(src), int(n_items), N, E, int(total_rows), dzp, dzld, g2p, g2ld,
+                                            _ptr(tables, torch.float32), _ptr(slot0, torch.float32),
+                                            _ptr(slot1, torch.float32), int(slot_ld), C.byref(opt), wp, wn, _stream()),
+              'ctr_emb_sparse_apply_fm')
+        return
     wp, wn = ws.get(lib().ctr_emb_sparse_apply_workspace_bytes(int(n_items), E))
     check(lib().ctr_emb_sparse_apply_ld(_ptr(keys), _ptr(src), int(n_items), N, E, int(total_rows), dzp, dzld,
                                         _ptr(src_scale, torch.float32), _ptr(tables, torch.float32),
@@ -578,7 +597,8 @@ def gemm(A, B_, Cout, *, trans_a=False, trans_b=False, bias=None, relu=False, si
          a_amax_floor=0.0, b_amax_floor=0.0, amax_out=None):
     """Cout[M,N] = epilogue(op(A) @ op(B_)); all three are 2-D views with contiguous last dim.
     fm_bwd (optional): dict(N, E, g_first, g_second, s, z) - the FM terms of embed_bwd_dz are added to the first N*E
-    columns of the product on its way out (ctr_fm_bwd_t; g_first / g_second already carry their keep masks).
+    columns of the product on its way out (ctr_fm_bwd_t; g_first / g_second already carry their keep masks); z None
+    leaves the term with the looked-up row to emb_sparse_apply(fm_g2=...).
     a_amax / b_amax (optional largest-magnitude records of A and B, AMAX_FLOATS floats each): with both, the product runs as
     the two-term fp16 split; amax_out: raised to max |Cout| (zero it first)."""
     M, N = Cout.shape
@@ -609,7 +629,7 @@ def gemm(A, B_, Cout, *, trans_a=False, trans_b=False, bias=None, relu=False, si
         g1, g2 = fm_bwd.get('g_first'), fm_bwd.get('g_second')
         g1p, g1ld = _rows(g1, 'g_first') if g1 is not None else (None, 0)
         g2p, g2ld = _rows(g2, 'g_second') if g2 is not None else (None, 0)
-        zp, zld = _rows(fm_bwd['z'], 'z') if g2 is not None else (None, 0)
+        zp, zld = _rows(fm_bwd['z'], 'z') if g2 is not None and fm_bwd.get('z') is not None else (None, 0)
         fm = FmBwd(g_first=g1p, g_first_ld=g1ld, g_second=g2p, g_second_ld=g2ld,
                    s=_ptr(fm_bwd['s'], torch.float32) if g2 is not None else None, z=zp, z_ld=zld,
                    n_rows=int(fm_bwd['N']), E=int(fm_bwd['E']))

@@ -22,6 +22,12 @@ class DeepFM(CTRModel):
         # dZ's FM terms ride the epilogue of the product that forms the tower's dx0 (one pass over [B, N*E] less);
         # CTR_FUSE_DZ=0 keeps the separate pass (the same bits either way)
         self.fuse_dz = os.environ.get('CTR_FUSE_DZ', '1') != '0'
+        # CTR_FM_Z_IN_UPDATE=1: of those terms, -g_second * Z is left to the row update - with one id per field a row of
+        # Z is the table row, the same for every lookup of it, so the update subtracts (sum of g_second over the row's
+        # lookups) * row once and the dx0 product does not read Z (113 MB at the benchmark shape).  Off by default:
+        # measured on one box at B = 65536, the product gets 14 us shorter (166 -> 152) and the update 32 us longer
+        # (78 -> 110: one more gathered row and a second running sum per lookup), the step 0.856 -> 0.879 ms.
+        self.fm_z_in_update = os.environ.get('CTR_FM_Z_IN_UPDATE', '0') == '1'
 
     def _dense_shapes(self, sh):
         n = len(self.deep_layers)
@@ -83,9 +89,13 @@ class DeepFM(CTRModel):
         fused = unit_backward(self.dense, wn, bn, concat, dconcat, dl, ws, mask_from=N + E, rate=self.dropout_deep,
                               keep=(N, d1, E, d2) if fuse and (d1 is not None or d2 is not None) else None)
         fm = dict(g_first=dconcat[:, :N], g_second=dconcat[:, N:N + E], s=bufs['s'], z=bufs['x0'])
+        # the term with the looked-up row goes to the row update where that row IS the table row
+        from recommendation_amd.engine import Bags, EmbedFront
+        z_late = (fuse and self.fm_z_in_update and isinstance(self.front, EmbedFront) and self.mode == 'S'
+                  and not isinstance(idx, Bags) and ops.emb_sparse_apply_fm_supported(E, fm['g_second']))
         self.tower.backward(bufs['x0'], bufs['acts'], dconcat[:, N + E:], bufs['gbufs'],
                             [self.dropout_deep] * n, bufs['dx0'], ws, g_last_masked=fused, side=self.session,
-                            ext=bufs['ext'], dx_fm=dict(fm, N=N, E=E) if fuse else None)
+                            ext=bufs['ext'], dx_fm=dict(fm, N=N, E=E, z=None if z_late else fm['z']) if fuse else None)
         if not fuse:
             ops.embed_bwd_dz(bufs['dx0'], B=B, N=N, E=E, gz=bufs['dx0'], drop_first=d1, drop_second=d2, **fm, **route)
-        self._tables_backward(idx, bufs['dx0'], bufs, routed=True)
+        self._tables_backward(idx, bufs['dx0'], bufs, routed=True, fm_g2=fm['g_second'] if z_late else None)

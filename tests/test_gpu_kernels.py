@@ -318,6 +318,68 @@ def test_sparse_adam_with_m_and_v_side_by_side_leaves_the_same_bits(ops_ws, E):
         ops.emb_sparse_apply(keys, src, B * F, N=F, E=E, total_rows=total, dz=dz, opt=opt, tables=Wb, slot0=mb, slot1=va, ws=ws)
 
 
+@pytest.mark.parametrize('kind', ['grad_only', 'adam'])
+@pytest.mark.parametrize('E', [4, 16, 32])
+def test_sparse_apply_with_the_fm_row_term(ops_ws, E, kind):
+    """ctr_emb_sparse_apply_fm: dz without -g2 * Z, the row update subtracting (sum of g2 over the row's lookups) * row -
+    against float64 (gradient of a row = sum over its lookups of dz[b,f] - g2[b] * W[row]) and against the plain update
+    fed the complete gradient; hot rows whose runs cross many 64-pair blocks (the tail pass), out-of-range ids, g2 as
+    a column block at an odd column offset of a wider buffer (8-byte aligned rows)."""
+    ops, ws = ops_ws
+    rng = np.random.default_rng(E + len(kind))
+    cards = [3, 700, 40000]
+    F, B = len(cards), 7000
+    offs = np.zeros(F + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(cards)
+    total = int(offs[-1])
+    idx = np.stack([np.minimum(rng.pareto(0.8, B).astype(np.int64), v - 1) for v in cards], 1).astype(np.int32)
+    idx[11, 1] = -1
+    idx[12, 2] = cards[2]
+    ok = (idx >= 0) & (idx < np.array(cards)[None])
+    W = rng.standard_normal((total, E)).astype(np.float32)
+    dz = rng.standard_normal((B, F * E + 4)).astype(np.float32)
+    wide = rng.standard_normal((B, E + 10)).astype(np.float32)
+    g2 = wide[:, 6:6 + E]
+    rows = offs[:-1][None] + idx
+    Z = np.where(ok[:, :, None], W[np.where(ok, rows, 0)], 0.0).astype(np.float64)
+    full = dz[:, :F * E].astype(np.float64).reshape(B, F, E) - g2.astype(np.float64)[:, None, :] * Z
+    gref = np.zeros((total, E))
+    for f in range(F):
+        np.add.at(gref, rows[ok[:, f], f], full[ok[:, f], f])
+    keys = torch.zeros(B * F, dtype=torch.int32, device=DEV)
+    src = torch.zeros(B * F, dtype=torch.int32, device=DEV)
+    ops.emb_sort(dev(idx), dev(offs), N=F, total_rows=total, rmode=False, keys_out=keys, src_out=src, ws=ws)
+    d_wide = dev(wide)
+    d_g2 = d_wide[:, 6:6 + E]
+    assert ops.emb_sparse_apply_fm_supported(E, d_g2)
+    d_full = dev(np.concatenate([full.reshape(B, F * E), np.zeros((B, 4))], 1).astype(np.float32))
+    if kind == 'grad_only':
+        outs = []
+        for _ in range(2):
+            grad = torch.zeros(total, E, device=DEV)
+            ops.emb_sparse_apply(keys, src, B * F, N=F, E=E, total_rows=total, dz=dev(dz), opt=ops.make_opt(0),
+                                 tables=dev(W), slot0=grad, ws=ws, fm_g2=d_g2)
+            outs.append(grad.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1])
+        assert rel_err(outs[0], gref) < 1e-5
+        return
+    opt = ops.make_opt(1, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8)
+    Wa, Wb = dev(W), dev(W)
+    mv_a, mv_b = torch.zeros(total, 2 * E, device=DEV), torch.zeros(total, 2 * E, device=DEV)
+    ops.emb_sparse_apply(keys, src, B * F, N=F, E=E, total_rows=total, dz=dev(dz), opt=opt, tables=Wa,
+                         slot0=mv_a[:, :E], slot1=mv_a[:, E:], ws=ws, fm_g2=d_g2)
+    ops.emb_sparse_apply(keys, src, B * F, N=F, E=E, total_rows=total, dz=d_full, opt=opt, tables=Wb,
+                         slot0=mv_b[:, :E], slot1=mv_b[:, E:], ws=ws)
+    m_ref = 0.1 * gref
+    touched = np.zeros(total, dtype=bool)
+    for f in range(F):
+        touched[rows[ok[:, f], f]] = True
+    assert rel_err(mv_a[:, :E].cpu().numpy()[touched], m_ref[touched]) < 1e-5
+    assert np.array_equal(Wa.cpu().numpy()[~touched], W[~touched])
+    # against the plain update on the complete gradient: the same first moment up to the rounding of one product
+    assert rel_err(mv_a[:, :E].cpu().numpy(), mv_b[:, :E].cpu().numpy()) < 1e-5
+
+
 GEMM_SHAPES = [(1, 1, 1), (5, 3, 2), (130, 70, 33), (257, 129, 19), (64, 1, 300), (429, 256, 5000),
                (1000, 429, 256), (33, 250, 4096)]
 

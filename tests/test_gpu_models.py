@@ -250,6 +250,7 @@ def test_deepfm_dz_in_the_gemm_epilogue_leaves_the_same_bits(sess, variant):
         P = O.init_params('DeepFM', cfg, seed=21, std=0.3 if variant == 'tiny' else 0.05)
         m = _build(sess, 'DeepFM', cfg, P)
         m.fuse_dz = fuse
+        m.fm_z_in_update = False             # the term with the looked-up row in the epilogue too: the same arithmetic
         losses = []
         for step in range(4):
             Xc, Xf, y = tiny_batch(cfg, B=B, seed=step)
@@ -258,6 +259,37 @@ def test_deepfm_dz_in_the_gemm_epilogue_leaves_the_same_bits(sess, variant):
     assert outs[0][0] == outs[1][0]
     for k in outs[0][1]:
         assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+
+
+@pytest.mark.parametrize('adam_mode', ['tf1', 'lazy'])
+def test_deepfm_fm_row_term_in_the_table_update(sess, adam_mode):
+    """fm_z_in_update (an option; off by default): the dx0 product adds g_first + g_second * s and leaves -g_second * Z to the row
+    update, which subtracts (sum of g_second over a row's lookups) * row once per table row (DeepFM/DeepFM.py:59-63:
+    every lookup of a row sees the same Z row).  Against the form with the term in the product's epilogue: same losses
+    (the forward pass is untouched) and weights within 1e-6 of each other after four steps with dropout on - the two
+    differ only in where one multiplication is rounded; the table gradients against the float64 oracle are held by
+    test_forward_grads_steps.  Run twice: the same bits."""
+    outs = []
+    for late in (True, True, False):
+        cfg = _criteo_like_cfg('DeepFM', 'DeepFM')
+        cfg.dropout_fm, cfg.dropout_deep = 0.5, 0.2
+        cfg.adam_mode = adam_mode
+        P = O.init_params('DeepFM', cfg, seed=21, std=0.05)
+        m = _build(sess, 'DeepFM', cfg, P)
+        m.fm_z_in_update = late
+        losses = []
+        for step in range(4):
+            Xc, Xf, y = tiny_batch(cfg, B=300, seed=step)
+            losses.append(float(m.train_step(*m._upload(Xc, Xf, y)).item()))
+        outs.append((losses, m.get_params()))
+    assert outs[0][0] == outs[1][0] and all(np.array_equal(outs[0][1][k], outs[1][1][k]) for k in outs[0][1])
+    assert np.allclose(outs[0][0], outs[2][0], rtol=1e-6, atol=0)
+    moved = 0.0
+    for k in outs[0][1]:
+        a, b = outs[0][1][k], outs[2][1][k]
+        assert float(np.max(np.abs(a - b))) < 1e-6 * max(1.0, float(np.max(np.abs(b)))), k
+        moved = max(moved, float(np.max(np.abs(b - P[k]))))
+    assert moved > 1e-3                               # the steps did move the weights
 
 
 @pytest.mark.gpu
