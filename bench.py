@@ -77,7 +77,8 @@ MODEL_ARGS = {
     'AFM_pairs': dict(attention_size=10, dropout=0.2, attention='pairs'),
     # the headline model with the table update exactly as tf.train.AdamOptimizer applies an IndexedSlices gradient
     # (DeepFM/DeepFM.py:32,100): m and v of EVERY row decay and every row moves, each step
-    'DeepFM_tf1adam': dict(deep_layers=[256, 128, 64, 32], dropout_fm=0.5, dropout_deep=0.2, adam_mode='tf1'),
+    'DeepFM_tf1adam': dict(deep_layers=[256, 128, 64, 32], dropout_fm=0.5, dropout_deep=0.2, adam_mode='tf1',
+                           table_grads=False),
 }
 
 

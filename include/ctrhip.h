@@ -265,6 +265,17 @@ int ctr_emb_sparse_apply_fm(const uint32_t* keys_sorted, const uint32_t* src_sor
                             float* tables, float* slot0, float* slot1, int64_t slot_ld,
                             const ctr_opt_t* opt, void* workspace, size_t workspace_bytes, void* stream);
 
+/* tf.train.AdamOptimizer on an embedding variable (DeepFM/DeepFM.py:32,100) moves EVERY row each step: rows
+ * without a gradient still decay m and v and take the step lr * m / (sqrt(v) + eps).  In two parts without a dense
+ * gradient buffer: ctr_emb_sparse_apply (CTR_OPT_ADAM) on the rows that received a gradient, then
+ * ctr_adam_untouched_rows on all others - the rows to skip are marked in a byte per table row by
+ * ctr_mark_rows(value = 1) from the sorted keys before, and unmarked with value = 0 after (the map is all zeros
+ * between steps).  tables, m, v: contiguous [rows, E], E % 4 == 0. */
+int ctr_mark_rows(const uint32_t* keys_sorted, int64_t n_items, int64_t total_rows, uint8_t* touched, int value,
+                  void* stream);
+int ctr_adam_untouched_rows(float* tables, float* m, float* v, int64_t rows, int E, const uint8_t* touched,
+                            const ctr_opt_t* opt, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Dense tower pieces.
  * Replaces: tf.matmul + bias + relu + tf.layers.dropout chains and their gradients

@@ -84,6 +84,8 @@ SIGNATURES = {
     'ctr_emb_sparse_apply_workspace_bytes': (sz, [i64, i]),
     'ctr_emb_sparse_apply': (i, [vp, vp, i64, i, i, i64, vp, i64, vp, vp, vp, vp, C.POINTER(Opt), vp, sz, vp]),
     'ctr_emb_sparse_apply_ld': (i, [vp, vp, i64, i, i, i64, vp, i64, vp, vp, vp, vp, i64, C.POINTER(Opt), vp, sz, vp]),
+    'ctr_mark_rows': (i, [vp, i64, i64, vp, i, vp]),
+    'ctr_adam_untouched_rows': (i, [vp, vp, vp, i64, i, vp, C.POINTER(Opt), vp]),
     'ctr_emb_sparse_apply_fm_workspace_bytes': (sz, [i64, i]),
     'ctr_emb_sparse_apply_fm': (i, [vp, vp, i64, i, i, i64, vp, i64, vp, i64, vp, vp, vp, i64, C.POINTER(Opt), vp, sz, vp]),
     'ctr_gemm_f32_workspace_bytes': (sz, [i, i, i]),

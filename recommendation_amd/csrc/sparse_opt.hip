@@ -453,6 +453,64 @@ __global__ __launch_bounds__(256) void dense_update_kernel(float* __restrict__ p
   }
 }
 
+// touched[key] = 1 for every table row that heads a run of the sorted pairs (keys outside the tables mark nothing).
+__global__ __launch_bounds__(256) void mark_rows_kernel(const uint32_t* __restrict__ keys, int64_t n, int64_t total_rows,
+                                                       uint8_t* __restrict__ touched) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t k = keys[i];
+    if ((int64_t)k < total_rows && (i == 0 || keys[i - 1] != k)) touched[k] = 1;
+  }
+}
+
+// tf.train.AdamOptimizer's step on the rows that received no gradient: m = b1 m, v = b2 v, w -= lr m / (sqrt(v) + eps)
+// (the expressions of dense_update_kernel with g = 0, so the same bits), four floats per thread; rows marked in
+// `touched` were updated by the row-wise pass and are skipped.
+__global__ __launch_bounds__(256) void adam_untouched_kernel(float* __restrict__ w, float* __restrict__ m,
+                                                            float* __restrict__ v, int64_t n4, int q_per_row,
+                                                            uint8_t* __restrict__ touched, Opt o) {
+  o = resolve_opt(o);
+  constexpr int U = 4;                                   // quads per thread and trip: twelve row loads in flight
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += U * stride) {
+    float4 mm[U], vv[U], p[U];
+    bool go[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * stride;
+      go[u] = i < n4 && !touched[i / q_per_row];
+      const int64_t j = i < n4 ? i : 0;
+      mm[u] = reinterpret_cast<const float4*>(m)[j];
+      vv[u] = reinterpret_cast<const float4*>(v)[j];
+      p[u] = reinterpret_cast<const float4*>(w)[j];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!go[u]) continue;
+      const int64_t i = i0 + u * stride;
+      const float g = 0.f;
+      float4 a = mm[u], c = vv[u], x = p[u];
+      a.x = o.b1 * a.x + (1.f - o.b1) * g; a.y = o.b1 * a.y + (1.f - o.b1) * g;
+      a.z = o.b1 * a.z + (1.f - o.b1) * g; a.w = o.b1 * a.w + (1.f - o.b1) * g;
+      c.x = o.b2 * c.x + (1.f - o.b2) * g * g; c.y = o.b2 * c.y + (1.f - o.b2) * g * g;
+      c.z = o.b2 * c.z + (1.f - o.b2) * g * g; c.w = o.b2 * c.w + (1.f - o.b2) * g * g;
+      x.x -= o.LR() * a.x / (sqrtf(c.x) + o.eps); x.y -= o.LR() * a.y / (sqrtf(c.y) + o.eps);
+      x.z -= o.LR() * a.z / (sqrtf(c.z) + o.eps); x.w -= o.LR() * a.w / (sqrtf(c.w) + o.eps);
+      reinterpret_cast<float4*>(m)[i] = a;
+      reinterpret_cast<float4*>(v)[i] = c;
+      reinterpret_cast<float4*>(w)[i] = x;
+    }
+  }
+}
+
+// second launch: clears the marks (a row's threads of the pass above all read its mark, so none of them may clear it)
+__global__ __launch_bounds__(256) void unmark_rows_kernel(const uint32_t* __restrict__ keys, int64_t n, int64_t total_rows,
+                                                         uint8_t* __restrict__ touched) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t k = keys[i];
+    if ((int64_t)k < total_rows && (i == 0 || keys[i - 1] != k)) touched[k] = 0;
+  }
+}
+
 static Opt make_opt(const ctr_opt_t* o) {
   Opt r;
   r.kind = o->kind; r.lr = o->lr; r.b1 = o->beta1; r.b2 = o->beta2; r.eps = o->eps; r.l1 = o->l1; r.l2 = o->l2;
@@ -640,6 +698,38 @@ extern "C" int ctr_set_step_words(uint64_t* seed_add, uint64_t seed_add_value, f
   if (!seed_add && !lr_dev) return CTR_OK;
   hipLaunchKernelGGL(set_step_words_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, seed_add, seed_add_value,
                      lr_dev, lr_value);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_mark_rows(const uint32_t* keys_sorted, int64_t n_items, int64_t total_rows, uint8_t* touched, int value,
+                             void* stream) {
+  CTR_REQUIRE(n_items >= 0 && total_rows > 0, "ctr_mark_rows: bad size");
+  if (n_items == 0) return CTR_OK;
+  CTR_REQUIRE(keys_sorted && touched, "ctr_mark_rows: null pointer");
+  const int64_t blocks = cdiv(n_items, 256) < 4096 ? cdiv(n_items, 256) : 4096;
+  if (value)
+    hipLaunchKernelGGL(mark_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, keys_sorted, n_items,
+                       total_rows, touched);
+  else
+    hipLaunchKernelGGL(unmark_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, keys_sorted, n_items,
+                       total_rows, touched);
+  CTR_LAUNCH_CHECK();
+  return CTR_OK;
+}
+
+extern "C" int ctr_adam_untouched_rows(float* tables, float* m, float* v, int64_t rows, int E, const uint8_t* touched,
+                                       const ctr_opt_t* opt, void* stream) {
+  CTR_REQUIRE(opt && opt->kind == CTR_OPT_ADAM, "ctr_adam_untouched_rows: the optimizer must be Adam");
+  CTR_REQUIRE(rows >= 0 && E >= 4 && E % 4 == 0, "ctr_adam_untouched_rows: bad size (E a multiple of 4)");
+  if (rows == 0) return CTR_OK;
+  CTR_REQUIRE(tables && m && v && touched, "ctr_adam_untouched_rows: null pointer");
+  CTR_REQUIRE(((uintptr_t)tables % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
+              "ctr_adam_untouched_rows: 16-byte alignment");
+  const int64_t n4 = rows * (E / 4);
+  const int64_t blocks = cdiv(n4, 256) < 16384 ? cdiv(n4, 256) : 16384;
+  hipLaunchKernelGGL(adam_untouched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tables, m, v, n4,
+                     E / 4, const_cast<uint8_t*>(touched), make_opt(opt));
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }

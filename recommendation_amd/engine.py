@@ -156,7 +156,15 @@ class EmbeddingTables:
         b = self.weight if buf is None else buf
         return b[int(self.offsets_host[f]):int(self.offsets_host[f + 1])]
 
-    def init_slots(self, kind, dense_adam):
+    def init_slots(self, kind, dense_adam, keep_grad=True):
+        """dense_adam: every row moves each step (tf.train.AdamOptimizer); keep_grad: through a dense gradient buffer
+        that get_grads() can show (False: row-wise pass + decay pass of the rows without a gradient, no buffer)."""
+        self.touched = None
+        if kind == 'adam' and dense_adam and not keep_grad:
+            self.slot0 = torch.zeros_like(self.weight)
+            self.slot1 = torch.zeros_like(self.weight)
+            self.touched = torch.zeros(self.total_rows, dtype=torch.uint8, device=self.weight.device)
+            return
         if kind == 'adam':
             if dense_adam or self.E > 16:
                 self.slot0 = torch.zeros_like(self.weight)
@@ -288,7 +296,14 @@ class EmbedFront:
             self.sort_pairs(idx, keys, src, ws)
         if fm_g2 is not None and (self.mode != 'S' or isinstance(idx, Bags) or self.cont_embed):
             raise ValueError('fm_g2 is defined for the single-id standard lookup without embedded continuous rows')
-        if opt.kind == OPT_ADAM and not lazy:
+        if opt.kind == OPT_ADAM and not lazy and t.grad is None:
+            # every row moves, as tf.train.AdamOptimizer moves it, without a dense gradient buffer: the rows with a
+            # gradient by the row-wise pass, all others by the decay pass
+            ops.emb_sparse_apply(keys, src, n_items, N=self.N, E=self.E, total_rows=t.total_rows, dz=dz,
+                                 opt=opt, tables=t.weight, slot0=t.slot0, slot1=t.slot1, ws=ws, fm_g2=fm_g2)
+            ops.adam_untouched_rows(keys, n_items, total_rows=t.total_rows, E=self.E, opt=opt, tables=t.weight,
+                                    slot0=t.slot0, slot1=t.slot1, touched=t.touched)
+        elif opt.kind == OPT_ADAM and not lazy:
             t.grad.zero_()
             ops.emb_sparse_apply(keys, src, n_items, N=self.N, E=self.E, total_rows=t.total_rows, dz=dz,
                                  opt=ops.make_opt(OPT_GRAD_ONLY), slot0=t.grad, ws=ws,

@@ -573,6 +573,23 @@ def emb_sparse_apply(keys, src, n_items, *, N, E, total_rows, dz, opt, ws, table
                                         C.byref(opt), wp, wn, _stream()), 'ctr_emb_sparse_apply')
 
 
+@_timed
+def adam_untouched_rows(keys, n_items, *, total_rows, E, opt, tables, slot0, slot1, touched):
+    """tf.train.AdamOptimizer's step on the table rows that received no gradient this step (m, v decay and the row
+    still moves); the rows the sorted `keys` name were updated by emb_sparse_apply and are skipped.  touched: uint8
+    [total_rows], all zeros on entry and on return."""
+    for t in (tables, slot0, slot1):
+        if not t.is_contiguous() or t.numel() < total_rows * E:
+            raise ValueError('adam_untouched_rows takes contiguous [total_rows, E] tensors')
+    if touched.dtype != torch.uint8 or touched.numel() < total_rows:
+        raise ValueError('touched must be uint8 [total_rows]')
+    kp, tp = _ptr(keys), C.c_void_p(touched.data_ptr())
+    check(lib().ctr_mark_rows(kp, int(n_items), int(total_rows), tp, 1, _stream()), 'ctr_mark_rows')
+    check(lib().ctr_adam_untouched_rows(_ptr(tables, torch.float32), _ptr(slot0, torch.float32), _ptr(slot1, torch.float32),
+                                        int(total_rows), E, tp, C.byref(opt), _stream()), 'ctr_adam_untouched_rows')
+    check(lib().ctr_mark_rows(kp, int(n_items), int(total_rows), tp, 0, _stream()), 'ctr_mark_rows')
+
+
 # ------------------------------------------------------------------ dense pieces
 GEMM_MODES = {'fp32': 0, 'split': 1, 'bf16': 2}
 

@@ -232,6 +232,35 @@ def test_graph_replayed_training_matches_eager(sess, name, mode):
         assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
 
 
+def test_tf1_adam_without_the_dense_gradient_buffer(sess):
+    """adam_mode 'tf1' moves every table row each step, as tf.train.AdamOptimizer does (DeepFM/DeepFM.py:32,100).  With
+    table_grads=False it does so without the dense gradient buffer - the row-wise pass on the rows with a gradient,
+    the decay pass on all others: the same weights and slots as the buffer form to within the last bits (the two
+    row updates are compiled separately), rows that never saw a gradient identical, and still the oracle's AdamTF1."""
+    outs = []
+    for keep in (True, False):
+        cfg = _criteo_like_cfg('DeepFM', 'DeepFM')
+        cfg.dropout_fm = cfg.dropout_deep = 0.0
+        cfg.adam_mode, cfg.table_grads = 'tf1', keep
+        P = O.init_params('DeepFM', cfg, seed=5, std=0.05)
+        m = _build(sess, 'DeepFM', cfg, P)
+        assert (m.tables.grad is None) == (not keep)
+        for step in range(3):
+            Xc, Xf, y = tiny_batch(cfg, B=200, seed=step)
+            m.train_step(*m._upload(Xc, Xf, y))
+        if not keep:
+            assert int(m.tables.touched.sum().item()) == 0          # the marks are cleared after every step
+        outs.append((m.get_params(), m.tables.slot0.cpu().numpy(), m.tables.slot1.cpu().numpy()))
+    for k in outs[0][0]:
+        assert np.allclose(outs[0][0][k], outs[1][0][k], rtol=1e-6, atol=1e-9), k
+    assert rel_err(outs[1][1], outs[0][1]) < 1e-6 and rel_err(outs[1][2], outs[0][2]) < 1e-6
+    orc = O.OracleModel('DeepFM', cfg, P, dtype=torch.float64)
+    for step in range(3):
+        Xc, Xf, y = tiny_batch(cfg, B=200, seed=step)
+        orc.run(Xc, Xf, y, True)
+    assert_weights_track(outs[1][0], orc.P)
+
+
 @pytest.mark.parametrize('variant', ['tiny', 'criteo_like'])
 def test_deepfm_dz_in_the_gemm_epilogue_leaves_the_same_bits(sess, variant):
     """DeepFM training steps with dZ's FM terms added in the epilogue of the dx0 product (the default on one process)
