@@ -145,12 +145,13 @@ def test_emb_sort_pairs_small_and_large_batches(ops_ws, B, rmode):
 @pytest.mark.parametrize('skew', [False, True])
 @pytest.mark.parametrize('B,cards', [(5000, [3, 511, 512, 513, 262143, 262144, 262145, 1, 40, 5000000]),
                                      (20000, [2, 300, 70000, 9000000, 17, 140000]),
-                                     (2000, list(range(1, 40)))])
+                                     (2000, list(range(1, 40))), (131072, [70000, 5]), (131073, [600, 3])])
 def test_emb_sort_by_fields_pass_counts_and_tile_boundaries(ops_ws, B, cards, skew):
     """The field-segmented sort: tables whose ids need one, two and three passes side by side (sizes around 2^9 and
     2^18, where the pass count changes; a one-row table; a ten-million-row table), several tiles per field with a
     ragged last one, more fields than one builder block takes, uniform and heavy-tailed ids (long runs of one id
-    across tiles), out-of-range ids in several fields.  Run twice: the same bits (the counters are integer atomics)."""
+    across tiles), out-of-range ids in several fields; the largest batch that sorts by fields (32 tiles a field) and
+    the first that takes the global sort.  Run twice: the same bits (the counters are integer atomics)."""
     ops, ws = ops_ws
     rng = np.random.default_rng(B + len(cards) + skew)
     F = len(cards)
