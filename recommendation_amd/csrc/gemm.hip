@@ -144,6 +144,7 @@ __device__ static inline void tile_epilogue(f32x16 (&acc)[TM][TN], float* smem, 
   // g_second, and all operands of a row of wave tiles are requested before the first tile is written (requested
   // tile by tile, sixteen dependent round trips per block cost half as much as the product itself)
   const bool fm_fast = PRE && epi.fm.on && !partial && epi.fm.eshift >= 2 && epi.fm.eshift <= 5;
+  const bool g2_pairs = fm_fast && epi.fm.g2 && ((uintptr_t)epi.fm.g2 % 8 == 0) && (epi.fm.g2_ld % 2 == 0);
   // a lane's four bias values depend on its column tile only: fetched once, not once per row group
   float bias4[TN][4];
 #pragma unroll
@@ -169,8 +170,13 @@ __device__ static inline void tile_epilogue(f32x16 (&acc)[TM][TN], float* smem, 
           const int c = nb & (epi.fm.E - 1);
           fs[it] = *reinterpret_cast<const float4*>(epi.fm.s + (int64_t)m * epi.fm.E + c);
           const float* g2 = epi.fm.g2 + (int64_t)m * epi.fm.g2_ld + c;
+          if (g2_pairs) {   // rows of g_second 8-byte aligned: two loads instead of four
+            const float2 lo = *reinterpret_cast<const float2*>(g2), hi = *reinterpret_cast<const float2*>(g2 + 2);
+            fg2[it][0] = lo.x; fg2[it][1] = lo.y; fg2[it][2] = hi.x; fg2[it][3] = hi.y;
+          } else {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) fg2[it][u] = g2[u];
+            for (int u = 0; u < 4; ++u) fg2[it][u] = g2[u];
+          }
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -1347,9 +1353,11 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
   const dim3 grid(p.tiles_n, p.tiles_m, p.splits), block(256);
   // both operands' largest magnitudes are known: the two-term fp16 split (half the matrix-core work of the bf16 one)
   const bool use_f16 = g_gemm_mode == CTR_GEMM_SPLIT_BF16 && g_f16_split && sc.a_amax && sc.b_amax;
+  // measurement switch: extra dynamic LDS per block, i.e. fewer resident blocks per CU
+  static const size_t lds_pad = getenv("CTR_GEMM_LDS_PAD") ? (size_t)atoi(getenv("CTR_GEMM_LDS_PAD")) : 0;
 #define LAUNCH_SPLIT(AK, BK_, TBM, TBN, WGM, NW_, PL_)                                                      \
   do {                                                                                                      \
-    const size_t lds_ = split_lds_bytes(TBM, TBN, PL_);                                                     \
+    const size_t lds_ = split_lds_bytes(TBM, TBN, PL_) + lds_pad;                                           \
     if (lds_ > 64 * 1024)                                                                                   \
       CTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<AK, BK_, TBM, TBN, WGM, NW_, PL_>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));                  \
