@@ -244,11 +244,13 @@ def test_sort_segment_reduce_matches_scatter_add(ops_ws, E, skew):
     assert int((k == total).sum()) == 2
 
 
+@pytest.mark.parametrize('E', [8, 64])
 @pytest.mark.parametrize('kind', ['adam', 'adagrad', 'sgd'])
-def test_sparse_optimizers_match_tf1_formulas(ops_ws, kind):
+def test_sparse_optimizers_match_tf1_formulas(ops_ws, kind, E):
+    """E = 64: sixteen lanes a row, sixteen pairs a wave (the 50-row table's runs cross many of those blocks)."""
     ops, ws = ops_ws
     rng = np.random.default_rng(3)
-    cards, E, B = [50, 7], 8, 300
+    cards, B = [50, 7], 300
     F = 2
     offs = np.array([0, 50, 57], dtype=np.int64)
     total = 57
