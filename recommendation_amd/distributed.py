@@ -135,12 +135,46 @@ class CtrComm:
         self._check(self.lib.ctr_allreduce_sum_f32(self.handle, self._C.c_void_p(t.data_ptr()), t.numel(), self._stream()))
 
     def close(self):
+        """Waits for the device, then destroys the communicator (every rank, at the same point)."""
         if getattr(self, 'handle', None):
             torch.cuda.synchronize()
             self.lib.ctr_comm_destroy(self.handle)
             self.handle = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:            # interpreter shutdown: the runtime may be gone already
+            pass
+
+
+class DirectAllReduce:
+    """Sum of a flat float32 buffer over the ranks as a reduce-scatter and an all-gather, each ONE all-to-all of equal
+    pieces (every pair of GPUs exchanges 1/W of the buffer directly, twice) instead of the collective library's ring:
+    for the towers' few megabytes of gradients on point-to-point links, 2 (W-1)/W of the buffer per rank in two
+    latency-bound steps rather than 2 (W-1) ring steps.  The W pieces of a chunk are added in rank order by
+    ops.colsum, so the sum does not depend on the topology.  Works over any of the transports above."""
+
+    def __init__(self, comm, n, device):
+        self.comm, self.n, W = comm, int(n), comm.world
+        self.chunk = (-(-self.n // W) + 3) // 4 * 4
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=device)
+        self.send, self.recv, self.red = z(W, self.chunk), z(W, self.chunk), z(self.chunk)
+
+    def __call__(self, t, ws):
+        if t.numel() != self.n or t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError('DirectAllReduce was sized for a contiguous float32 buffer of %d elements' % self.n)
+        W = self.comm.world
+        self.send.view(-1)[:self.n].copy_(t.view(-1))              # the padding behind it stays zero
+        self.comm.all_to_all(self.recv, self.send)                 # row r: chunk `rank` as rank r holds it
+        self.ops_colsum(self.recv, self.red, ws)
+        self.send.copy_(self.red.unsqueeze(0).expand(W, self.chunk))
+        self.comm.all_to_all(self.recv, self.send)                 # row r: the finished chunk r
+        t.view(-1).copy_(self.recv.view(-1)[:self.n])
+
+    @staticmethod
+    def ops_colsum(x, out, ws):
+        _ops.colsum(x, out, ws=ws)
 
 
 class HostStagedComm:

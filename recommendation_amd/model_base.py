@@ -313,6 +313,7 @@ class CTRModel(GraphOwner):
         if getattr(self, 'session', None) is not None:
             self.close()                                # captured graphs point at the storage re-allocated below
         self.session = session
+        self._direct_ar = None
         self._bufs.clear()
         self.dense = DenseParams(self.dense_shapes, dev)
         if self.world > 1:
@@ -563,8 +564,14 @@ class CTRModel(GraphOwner):
         self._backward(idx, xc, bufs)
         self._presorted = False
         self.session.side_join()                            # weight gradients issued to the side stream
-        if self.world > 1:
-            self.comm.all_reduce_sum(self.dense.grad)       # loss gradient was pre-scaled by 1/world
+        if self.world > 1:                                  # loss gradient was pre-scaled by 1/world
+            if getattr(self.args, 'dense_allreduce', 'ring') == 'direct':
+                if self._direct_ar is None:
+                    from .distributed import DirectAllReduce
+                    self._direct_ar = DirectAllReduce(self.comm, self.dense.grad.numel(), self.session.device)
+                self._direct_ar(self.dense.grad, self.session.ws)
+            else:
+                self.comm.all_reduce_sum(self.dense.grad)
         self.dense.apply(self._optimizer())
         self.global_step += 1
         return self._loss_dev

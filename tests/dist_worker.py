@@ -118,7 +118,7 @@ def _bad_ids_and_overflow(cls, dcfg, cfg, P, sess, Xc, Xf, y, lo, hi, rank, worl
     dist.barrier()
 
 
-def main(model_name, shard='table', arch='tiny'):
+def main(model_name, shard='table', arch='tiny', dense_allreduce='ring'):
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     import recommendation_amd as ra
@@ -159,6 +159,7 @@ def main(model_name, shard='table', arch='tiny'):
     import copy
     dcfg = copy.copy(cfg)
     dcfg.world_size, dcfg.rank, dcfg.comm, dcfg.shard = world, rank, HostStagedComm(), shard
+    dcfg.dense_allreduce = dense_allreduce        # 'direct': reduce-scatter + all-gather from two all-to-alls
     m = cls(dcfg, F, C, cfg.cate_list)
     m.build()
     m.initialize(sess, params=P)
@@ -193,4 +194,5 @@ def main(model_name, shard='table', arch='tiny'):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else 'table', sys.argv[3] if len(sys.argv) > 3 else 'tiny')
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else 'table', sys.argv[3] if len(sys.argv) > 3 else 'tiny',
+         sys.argv[4] if len(sys.argv) > 4 else 'ring')

@@ -13,11 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                               ('PNN', 'table', 'tiny'), ('DeepFM', 'row', 'tiny'),
                                               ('DCN', 'row', 'tiny'), ('PNN', 'row', 'tiny'),
                                               ('DeepFM', 'table', 'default'), ('DeepFM', 'row', 'default'),
-                                              ('DCN', 'table', 'default')])
+                                              ('DCN', 'table', 'default'), ('DeepFM', 'table', 'tiny direct'),
+                                              ('DCN', 'row', 'default direct')])
 def test_two_ranks_match_one_rank(sess, model, shard, arch):
+    """'... direct': the towers' gradients summed by distributed.DirectAllReduce (two all-to-alls and a fixed-order sum)
+    instead of the transport's all-reduce."""
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-           '--master-addr', '127.0.0.1', '--master-port', '29731', os.path.join(ROOT, 'tests', 'dist_worker.py'), model, shard, arch]
+           '--master-addr', '127.0.0.1', '--master-port', '29731', os.path.join(ROOT, 'tests', 'dist_worker.py'), model, shard] + arch.split()
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'DIST_OK %s %s' % (model, shard) in r.stdout
