@@ -215,7 +215,31 @@ class HostStagedComm:
         t.copy_(c)
 
 
-class ShardedFront:
+class _SortBesideExchange:
+    """The owner's pair sort needs only the ids that arrived in the forward pass, and the gradient exchange leaves the
+    compute units idle: on a GPU the sort runs on a stream of its own while the exchange is under way (the two are
+    joined before the row update).  With any other backend (the CPU stand-ins of the plan tests) the exchange comes
+    first, then the sort, on the one stream there is."""
+    _aux = None
+    _aux_ws = None
+
+    def _sort_beside(self, sort_fn, exchange_fn, ws):
+        if self.ops is not _ops or torch.device(self.device).type != 'cuda':
+            exchange_fn()
+            sort_fn(ws)
+            return
+        cur = torch.cuda.current_stream()
+        if self._aux is None:
+            self._aux = torch.cuda.Stream(self.device)
+            self._aux_ws = _ops.Workspace(self.device)
+        self._aux.wait_stream(cur)                   # after the forward's id exchange and the last update's reads
+        with torch.cuda.stream(self._aux):
+            sort_fn(self._aux_ws)
+        exchange_fn()
+        cur.wait_stream(self._aux)
+
+
+class ShardedFront(_SortBesideExchange):
     """Drop-in for engine.EmbedFront (S semantics) when whole tables are dealt to ranks (pack_fields)."""
 
     def __init__(self, cate_list, E, cont_num, cont_embed, comm, device, backend=_ops):
@@ -312,13 +336,20 @@ class ShardedFront:
         bf = self._buffers(B)
         if not dz_in_blocks:
             ops.rows_gather(dz, bf['send_perm'], B * F, bf['blocks'], F=F, E=E)     # dZ rows in send order
-        self.comm.all_to_all(bf['grows'].view(-1)[:W * B * self.nf_own * E], bf['blocks'][:B * F * E], bf['row_in'],
-                             bf['row_out'])
+        t, n_items = self.t, W * B * self.nf_own
+
+        def exchange():
+            self.comm.all_to_all(bf['grows'].view(-1)[:W * B * self.nf_own * E], bf['blocks'][:B * F * E], bf['row_in'],
+                                 bf['row_out'])
+
+        def sort(sws):
+            if self.nf_own:
+                ops.emb_sort(bf['recv_idx'][:n_items].view(W * B, self.nf_own), t.row_offset, N=self.nf_own,
+                             total_rows=t.total_rows, rmode=False, keys_out=bf['keys'], src_out=bf['src'], ws=sws)
+
+        self._sort_beside(sort, exchange, ws)
         if not self.nf_own:
             return
-        t, n_items = self.t, W * B * self.nf_own
-        ops.emb_sort(bf['recv_idx'][:n_items].view(W * B, self.nf_own), t.row_offset, N=self.nf_own,
-                     total_rows=t.total_rows, rmode=False, keys_out=bf['keys'], src_out=bf['src'], ws=ws)
         if opt.kind == OPT_ADAM and not lazy:
             t.grad.zero_()
             ops.emb_sparse_apply(bf['keys'], bf['src'], n_items, N=self.nf_own, E=E, total_rows=t.total_rows,
@@ -354,7 +385,7 @@ def row_shard_layout(cate_list, W):
     return cards, offs
 
 
-class RowShardedFront:
+class RowShardedFront(_SortBesideExchange):
     """Drop-in for engine.EmbedFront (S semantics) with every table sharded by row over the ranks.
 
     forward : route each lookup (dest = (id + f) mod W, key = row inside the owner's shard) -> stable sort
@@ -472,10 +503,11 @@ class RowShardedFront:
         cap = bf['cap']
         n_recv = W * cap
         ops.rows_gather(dz, bf['slot_perm'], n_recv, bf['back'], F=F, E=E)            # empty slots: zero rows
-        self.comm.all_to_all(bf['rows'].view(-1)[:n_recv * E], bf['back'].view(-1)[:n_recv * E])
         t, total = self.t, max(self.total_local, 1)
-        ops.emb_sort(bf['recv_keys'][:n_recv].view(n_recv, 1), self.shard_offset, N=1, total_rows=total, rmode=False,
-                     keys_out=bf['skeys'], src_out=bf['ssrc'], ws=ws)
+        self._sort_beside(
+            lambda sws: ops.emb_sort(bf['recv_keys'][:n_recv].view(n_recv, 1), self.shard_offset, N=1, total_rows=total,
+                                     rmode=False, keys_out=bf['skeys'], src_out=bf['ssrc'], ws=sws),
+            lambda: self.comm.all_to_all(bf['rows'].view(-1)[:n_recv * E], bf['back'].view(-1)[:n_recv * E]), ws)
         if opt.kind == OPT_ADAM and not lazy:
             t.grad.zero_()
             ops.emb_sparse_apply(bf['skeys'], bf['ssrc'], n_recv, N=1, E=E, total_rows=total, dz=bf['rows'][:n_recv],
