@@ -456,18 +456,25 @@ static int run_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
 // field-major (field f's pairs at [f*B, (f+1)*B) in sample order), which sorts them by field for free, and the radix
 // passes then run inside each field on the bits ITS ids need: ceil(bits(V_f) / 9) passes of equal width <= 9 bits -
 // one pass for a table of up to 511 rows, three for ten million - instead of three passes over every pair for
-// 26-bit global row numbers.  A field is a segment of Tf = ceil(B / 4096) tiles, so a scatter block finds its
-// offsets by reading the Tf digit counts of its own field: no scan launch.  A sort is the builder, then a histogram
-// and a scatter launch per pass; blocks of fields whose passes are done return at once; a field's last pass writes
-// the final split arrays with key = row_offset[f] + id.  Ids outside their table travel as id = V_f (behind every
-// valid id of the field); the last pass moves them behind all fields with key = total_rows, ordered by field.
-// No atomics on global memory (a device-scope atomic is one fabric transaction: a per-tile flush of next-pass
-// digit counts by integer atomics was measured at +10 us per launch) and nothing to clear between calls.
+// 26-bit global row numbers.  A field is a segment of Tf = ceil(B / 4096) tiles.  A sort is the builder and ONE
+// launch per pass: a pass's block ranks its tile, publishes the tile's digit counts (one word per digit with a
+// "written" bit, so a word is its own flag), and reads the counts of the other Tf - 1 tiles of its field as they
+// appear - no histogram launch, no scan launch, no read-modify-write on global memory (a device-scope atomic is one
+// fabric transaction: a per-tile flush of digit counts by integer atomics was measured at +10 us per launch).
+// Blocks wait only for blocks of their own field, at most 31 block indices away, so with workgroups dispatched in
+// index order the wait ends as soon as the field's blocks have ranked their tiles; a wait that lasts FS_WAIT_TICKS
+// stops the kernel instead of hanging it.  Blocks of fields whose passes are done return at once; a field's last
+// pass writes the final split arrays with key = row_offset[f] + id.  Ids outside their table travel as id = V_f
+// (behind every valid id of the field); the last pass moves them behind all fields with key = total_rows, ordered by
+// field.  The count words of pass p live in region p & 1; the builder clears region 0 and a pass's block clears its
+// own slot of the other region for the next pass, so nothing has to be cleared between calls.
 // ---------------------------------------------------------------------------------------
 constexpr int FS_BINS = 512;
 constexpr int FS_MAX_TF = 32;            // tiles per field (B <= 131072): a scatter thread holds one count per tile
 constexpr int FS_SB = 128;               // samples per builder block
 constexpr int FS_FG = 32;                // fields per builder block
+constexpr uint32_t FS_WRITTEN = 0x80000000u;             // a published count word (counts are <= 4096)
+constexpr unsigned long long FS_WAIT_TICKS = 200000000ull;   // 2 s of the 100 MHz wall clock
 
 // What a field's passes look like: ids 0 .. V-1 are valid, Vs is the id an invalid lookup travels with.
 // R-mode: every valid pair of a field has the same key, so the id is 0 (valid) or 1.
@@ -479,12 +486,17 @@ __device__ __forceinline__ void fs_plan(int64_t V, int rmode, uint32_t& Vs, int&
 }
 
 // grid (ceil(B / FS_SB), ceil(F / FS_FG)): a block turns its [samples][fields] slab of ids into pairs and writes
-// every field's 128 pairs as one contiguous piece.  All of a thread's id loads are in flight together.
+// every field's 128 pairs as one contiguous piece.  All of a thread's id loads are in flight together.  It also
+// counts the slab's invalid lookups per field (inv_fine[f][blockIdx.x]) and clears its share of count region 0
+// (count_words words).
 __global__ __launch_bounds__(256) void fs_build_kernel(const int32_t* __restrict__ idx,
                                                        const int64_t* __restrict__ row_offset, int B, int F, int N,
-                                                       int rmode, uint2* __restrict__ pairs) {
+                                                       int rmode, uint2* __restrict__ pairs,
+                                                       uint32_t* __restrict__ inv_fine, uint32_t* __restrict__ counts0,
+                                                       int64_t count_words) {
   __shared__ int32_t ids[FS_SB * (FS_FG + 1)];      // [sample][field], odd pitch: a wave reads one field of 64 samples
   __shared__ int64_t offs[FS_FG + 1];
+  __shared__ uint32_t ninv[FS_FG];
   constexpr int PER = FS_SB * FS_FG / 256;          // 16 ids per thread
   const int f0 = blockIdx.y * FS_FG, fgc = F - f0 < FS_FG ? F - f0 : FS_FG;
   const int b0 = blockIdx.x * FS_SB, sb = B - b0 < FS_SB ? B - b0 : FS_SB;
@@ -496,6 +508,12 @@ __global__ __launch_bounds__(256) void fs_build_kernel(const int32_t* __restrict
     v[u] = (lf < fgc && s < sb) ? idx[(int64_t)(b0 + s) * F + f0 + lf] : 0;
   }
   for (int i = threadIdx.x; i <= fgc; i += 256) offs[i] = row_offset[f0 + i];
+  if (threadIdx.x < FS_FG) ninv[threadIdx.x] = 0u;
+  {
+    const int64_t nthreads = (int64_t)gridDim.x * gridDim.y * 256;
+    const int64_t me = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    for (int64_t q = me; q * 4 < count_words; q += nthreads) ((uint4*)counts0)[q] = make_uint4(0u, 0u, 0u, 0u);
+  }
 #pragma unroll
   for (int u = 0; u < PER; ++u) ids[(ls + u * (256 / FS_FG)) * (FS_FG + 1) + lf] = v[u];
   __syncthreads();
@@ -509,61 +527,27 @@ __global__ __launch_bounds__(256) void fs_build_kernel(const int32_t* __restrict
     const int x = ids[s * (FS_FG + 1) + ff];
     const int64_t off = offs[ff], V = offs[ff + 1] - off;
     const bool ok = x >= 0 && x < V;
+    if (!ok) atomicAdd(&ninv[ff], 1u);
     const uint32_t sid = ok ? (rmode ? 0u : (uint32_t)x) : (rmode ? 1u : (uint32_t)V);
     const uint32_t src = rmode ? (ok ? (uint32_t)((int64_t)b * N + off + x) : 0u) : b * (uint32_t)N + (uint32_t)f;
     pairs[(uint32_t)f * (uint32_t)B + b] = make_uint2(sid, src);
   }
-}
-
-// counts[f][t][digit] of one pass for the fields that still have one; block (f, t) = blockIdx.x.  The first pass also
-// counts the tile's invalid lookups into invc[f][t].
-__global__ __launch_bounds__(SORT_THREADS) void fs_hist_kernel(const uint2* __restrict__ in,
-                                                              const int64_t* __restrict__ row_offset, int B, int Tf,
-                                                              int pass, int rmode, uint32_t* __restrict__ counts,
-                                                              uint32_t* __restrict__ invc) {
-  __shared__ uint32_t hist[FS_BINS];
-  __shared__ uint32_t ninv;
-  const int f = blockIdx.x / Tf, t = blockIdx.x - f * Tf;
-  uint32_t Vs;
-  int passes, rb;
-  fs_plan(row_offset[f + 1] - row_offset[f], rmode, Vs, passes, rb);
-  if (pass >= passes) return;
-  const int shift = pass * rb;
-  const uint32_t mask = (1u << rb) - 1u;
-  const int left = B - t * SORT_TILE;
-  const uint32_t cnt = left < SORT_TILE ? (uint32_t)left : (uint32_t)SORT_TILE;
-  const uint2* tile = in + ((uint32_t)f * (uint32_t)B + (uint32_t)t * SORT_TILE);
-  uint32_t k[SORT_CHUNKS];
-#pragma unroll
-  for (int c = 0; c < SORT_CHUNKS; ++c) {
-    const uint32_t i = c * SORT_THREADS + threadIdx.x;
-    k[c] = i < cnt ? tile[i].x : 0u;
-  }
-  hist[threadIdx.x] = 0u;
-  if (threadIdx.x == 0) ninv = 0u;
   __syncthreads();
-  uint32_t bad = 0u;
-#pragma unroll
-  for (int c = 0; c < SORT_CHUNKS; ++c) {
-    const bool valid = c * SORT_THREADS + threadIdx.x < cnt;
-    hist_add_chunk(hist, (k[c] >> shift) & mask, valid);
-    bad += (uint32_t)__popcll(__ballot(valid && k[c] == Vs));
-  }
-  if (pass == 0 && bad != 0u && (threadIdx.x & 63) == 0) atomicAdd(&ninv, bad);
-  __syncthreads();
-  counts[(int64_t)blockIdx.x * FS_BINS + threadIdx.x] = hist[threadIdx.x];
-  if (pass == 0 && threadIdx.x == 0) invc[blockIdx.x] = ninv;
+  if ((int)threadIdx.x < fgc) inv_fine[(int64_t)(f0 + threadIdx.x) * gridDim.x + blockIdx.x] = ninv[threadIdx.x];
 }
 
 // One pass's stable scatter inside the fields: block (f, t) = blockIdx.x moves tile t of field f.  in / out: the uint2
-// pairs between passes; keys_out / src_out: the final arrays (written by a field's last pass); counts: this pass's
-// [F][Tf][512] digit counts; invc: [F][Tf] invalid lookups per tile.  The ranking inside the tile is that of
-// radix_scatter_kernel.
+// pairs between passes; keys_out / src_out: the final arrays (written by a field's last pass); counts / counts_next:
+// this pass's and the next pass's [F][Tf][512] count words; inv_fine: [F][nb] invalid lookups per builder block
+// (nb = ceil(B / 128)); inv_tile: [F][Tf] the same per tile, written by pass 0 for the later launches.  The ranking
+// inside the tile is that of radix_scatter_kernel.
 __global__ __launch_bounds__(SORT_THREADS) void fs_scatter_kernel(
     const uint2* __restrict__ in, uint2* __restrict__ out, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ src_out, const int64_t* __restrict__ row_offset, int B, int F, int Tf, int pass, int rmode,
-    int64_t total_rows, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ invc) {
+    int64_t total_rows, uint32_t* counts, uint32_t* __restrict__ counts_next, const uint32_t* __restrict__ inv_fine,
+    int nb, uint32_t* __restrict__ inv_tile) {
   constexpr int RBINS = FS_BINS, MSLOTS = 512;
+  constexpr int FINE_PER_TILE = SORT_TILE / FS_SB;
   __shared__ uint32_t whist32[SORT_WAVES][RBINS / 2];
   __shared__ uint32_t tstart[RBINS];
   __shared__ uint32_t goff[RBINS];                       // (position in the field of digit d's run in this tile) - tstart[d]
@@ -596,33 +580,28 @@ __global__ __launch_bounds__(SORT_THREADS) void fs_scatter_kernel(
       val[c] = kv.y;
     }
   }
-  // digit d = threadIdx.x: the field's count (over its Tf tiles) and the count in the tiles before this one; every
-  // tile's count is requested before the first is used
-  uint32_t gb[1], sc = 0u;
-  {
-    const uint32_t* col = counts + (int64_t)f * Tf * RBINS + threadIdx.x;
-    uint32_t cc[FS_MAX_TF];
-#pragma unroll
-    for (int tt = 0; tt < FS_MAX_TF; ++tt) cc[tt] = tt < Tf ? col[(int64_t)tt * RBINS] : 0u;
-    uint32_t tot = 0u;
-#pragma unroll
-    for (int tt = 0; tt < FS_MAX_TF; ++tt) {
-      tot += cc[tt];
-      if (tt < t) sc += cc[tt];
-    }
-    gb[0] = tot;
-  }
-  // invalid lookups (last pass only): in the fields before this one, in this field, in all
+  // invalid lookups (last pass only): in the fields before this one, in this field, in all.  Pass 0 reads the
+  // builder's counts (the other tiles' sums are being written by this launch), later passes pass 0's per-tile sums.
   uint32_t inv_before = 0u, inv_f = 0u, inv_total = 0u;
   if (last) {
-    for (int g = threadIdx.x; g < F * Tf; g += SORT_THREADS) {
-      const uint32_t c = invc[g];
-      const int gf = g / Tf;
+    const uint32_t* src = pass == 0 ? inv_fine : inv_tile;
+    const int per = pass == 0 ? nb : Tf;
+    for (int g = threadIdx.x; g < F * per; g += SORT_THREADS) {
+      const uint32_t c = src[g];
+      const int gf = g / per;
       inv_total += c;
       if (gf < f) inv_before += c;
       if (gf == f) inv_f += c;
     }
   }
+  if (pass == 0 && wave == 0) {
+    const int g = t * FINE_PER_TILE + lane;
+    uint32_t c = (lane < FINE_PER_TILE && g < nb) ? inv_fine[(int64_t)f * nb + g] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+    if (lane == 0) inv_tile[blockIdx.x] = c;
+  }
+  if (!last) counts_next[(int64_t)blockIdx.x * RBINS + threadIdx.x] = 0u;
   for (int i = threadIdx.x; i < SORT_WAVES * RBINS / 2; i += SORT_THREADS) (&whist32[0][0])[i] = 0u;
   for (int i = threadIdx.x; i < SORT_TILE; i += SORT_THREADS) lds64[i] = 0ull;
   if (last) {
@@ -634,7 +613,7 @@ __global__ __launch_bounds__(SORT_THREADS) void fs_scatter_kernel(
     }
     if (lane == 0) { inv_red[0][wave] = inv_total; inv_red[1][wave] = inv_before; inv_red[2][wave] = inv_f; }
   }
-  block_excl_scan<1>(gb, wtot_a, lane, wave);            // its barrier also orders the clearing above
+  __syncthreads();
   if (last) {
     inv_total = inv_before = inv_f = 0u;
 #pragma unroll
@@ -661,6 +640,7 @@ __global__ __launch_bounds__(SORT_THREADS) void fs_scatter_kernel(
     rank[c] = ((prior >> hshift) & 0xFFFFu) + in_chunk;
   }
   __syncthreads();
+  // digit d = threadIdx.x: the tile's count, published at once for the field's other tiles
   uint32_t ts[1];
   {
     const int d = threadIdx.x;
@@ -673,9 +653,11 @@ __global__ __launch_bounds__(SORT_THREADS) void fs_scatter_kernel(
     }
     ts[0] = run;
   }
+  uint32_t* col = counts + (int64_t)f * Tf * RBINS + threadIdx.x;
+  const uint32_t mine = ts[0];
+  __hip_atomic_store(col + (int64_t)t * RBINS, mine | FS_WRITTEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   block_excl_scan<1>(ts, wtot_b, lane, wave);
   tstart[threadIdx.x] = ts[0];
-  goff[threadIdx.x] = gb[0] + sc - ts[0];
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < SORT_CHUNKS; ++c) {
@@ -685,6 +667,40 @@ __global__ __launch_bounds__(SORT_THREADS) void fs_scatter_kernel(
       lds64[tstart[d] + whist[wave * RBINS + d] + rank[c]] = (unsigned long long)key[c] | ((unsigned long long)val[c] << 32);
     }
   }
+  // the field's count of digit d (over its Tf tiles) and the count in the tiles before this one, as the other
+  // tiles publish theirs; every outstanding word is requested in each round
+  uint32_t gb[1], sc = 0u;
+  bool gave_up = false;
+  {
+    uint32_t tot = mine;
+    uint32_t pending = (Tf >= 32 ? 0xFFFFFFFFu : (1u << Tf) - 1u) & ~(1u << t);
+    const unsigned long long t0 = wall_clock64();
+    while (__any(pending != 0u)) {
+      uint32_t got[FS_MAX_TF];
+#pragma unroll
+      for (int tt = 0; tt < FS_MAX_TF; ++tt)
+        got[tt] = (pending >> tt) & 1u
+                      ? __hip_atomic_load(col + (int64_t)tt * RBINS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                      : 0u;
+#pragma unroll
+      for (int tt = 0; tt < FS_MAX_TF; ++tt)
+        if (got[tt] & FS_WRITTEN) {
+          const uint32_t c = got[tt] & ~FS_WRITTEN;
+          tot += c;
+          if (tt < t) sc += c;
+          pending &= ~(1u << tt);
+        }
+      if (wall_clock64() - t0 > FS_WAIT_TICKS) {
+        gave_up = true;
+        break;
+      }
+      if (pending != 0u) __builtin_amdgcn_s_sleep(8);
+    }
+    gb[0] = tot;
+  }
+  if (__syncthreads_or(gave_up)) __builtin_trap();        // a tile of this field never arrived: stop, do not hang
+  block_excl_scan<1>(gb, wtot_a, lane, wave);
+  goff[threadIdx.x] = gb[0] + sc - ts[0];
   __syncthreads();
   if (!last) {
 #pragma unroll
@@ -820,7 +836,8 @@ static bool fs_eligible(int64_t B, int64_t F) {
 }
 static int fs_max_passes(int64_t total_rows, int rmode) { return rmode ? 1 : (bits_for((uint64_t)total_rows) + 8) / 9; }
 static size_t fs_counter_bytes(int64_t B, int64_t F) {
-  return align_up((size_t)F * cdiv(B, SORT_TILE) * (FS_BINS + 1) * 4, 256);
+  // two regions of count words, the builder's invalid counts, the per-tile invalid counts
+  return align_up(((size_t)F * cdiv(B, SORT_TILE) * (2 * FS_BINS + 1) + (size_t)F * cdiv(B, FS_SB)) * 4, 256);
 }
 static size_t fs_ws_bytes(int64_t B, int64_t F) { return 2 * align_up((size_t)(B * F) * 8, 256) + fs_counter_bytes(B, F); }
 
@@ -838,17 +855,19 @@ static void fs_sort(const int32_t* idx, const int64_t* row_offset, int B, int F,
   char* p = (char*)workspace;
   uint2* pa = (uint2*)p; p += align_up((size_t)n * 8, 256);
   uint2* pb = (uint2*)p; p += align_up((size_t)n * 8, 256);
-  uint32_t* counts = (uint32_t*)p;                         // [F][Tf][512], rewritten by every pass's histogram
-  uint32_t* invc = counts + (size_t)F * Tf * FS_BINS;      // [F][Tf], written by the first pass's histogram
-  hipLaunchKernelGGL(fs_build_kernel, dim3((unsigned)cdiv(B, FS_SB), (unsigned)cdiv(F, FS_FG)), dim3(256), 0, st, idx,
-                     row_offset, B, F, N, rmode, pa);
+  const int nb = (int)cdiv(B, FS_SB);
+  const int64_t words = (int64_t)F * Tf * FS_BINS;          // one region of count words: [F][Tf][512], 16-byte multiple
+  uint32_t* counts[2] = {(uint32_t*)p, (uint32_t*)p + words};
+  uint32_t* inv_tile = counts[1] + words;                  // [F][Tf]
+  uint32_t* inv_fine = inv_tile + (size_t)F * Tf;          // [F][nb]
+  hipLaunchKernelGGL(fs_build_kernel, dim3((unsigned)nb, (unsigned)cdiv(F, FS_FG)), dim3(256), 0, st, idx, row_offset, B,
+                     F, N, rmode, pa, inv_fine, counts[0], words);
   for (int ps = 0; ps < pmax; ++ps) {
     const uint2* in = (ps & 1) ? pb : pa;
     uint2* out = (ps & 1) ? pa : pb;
-    hipLaunchKernelGGL(fs_hist_kernel, dim3((unsigned)(F * Tf)), dim3(SORT_THREADS), 0, st, in, row_offset, B, Tf, ps,
-                       rmode, counts, invc);
     hipLaunchKernelGGL(fs_scatter_kernel, dim3((unsigned)(F * Tf)), dim3(SORT_THREADS), 0, st, in, out, keys_out, src_out,
-                       row_offset, B, F, Tf, ps, rmode, total_rows, counts, invc);
+                       row_offset, B, F, Tf, ps, rmode, total_rows, counts[ps & 1], counts[(ps + 1) & 1], inv_fine, nb,
+                       inv_tile);
   }
 }
 
