@@ -1355,6 +1355,11 @@ extern "C" int ctr_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
   const bool use_f16 = g_gemm_mode == CTR_GEMM_SPLIT_BF16 && g_f16_split && sc.a_amax && sc.b_amax;
   // measurement switch: extra dynamic LDS per block, i.e. fewer resident blocks per CU
   static const size_t lds_pad = getenv("CTR_GEMM_LDS_PAD") ? (size_t)atoi(getenv("CTR_GEMM_LDS_PAD")) : 0;
+  // measurement switches (results are wrong with them): every row of A read from its first row (the operand stream
+  // served by the caches), every row of C stored over its first row (no write traffic)
+  static const bool dbg_a0 = getenv("CTR_GEMM_DEBUG_A0") != nullptr, dbg_c0 = getenv("CTR_GEMM_DEBUG_C0") != nullptr;
+  if (dbg_a0 && !trans_a) lda = 0;
+  if (dbg_c0) ldc = 0;
 #define LAUNCH_SPLIT(AK, BK_, TBM, TBN, WGM, NW_, PL_)                                                      \
   do {                                                                                                      \
     const size_t lds_ = split_lds_bytes(TBM, TBN, PL_) + lds_pad;                                           \
