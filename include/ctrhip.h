@@ -173,9 +173,9 @@ int ctr_embed_bwd_dz_blocks(const float* gz, int64_t gz_ld, const float* g_first
 size_t ctr_emb_sort_workspace_bytes(int64_t n_items);
 /* Workspace with which ctr_emb_sort can take its field-segmented path (never less than
  * ctr_emb_sort_workspace_bytes(B*F)): the pairs are laid out field by field and every field is sorted on the
- * bits its own table needs (one pass for up to 511 rows, three for ten million), one launch per pass: the blocks of a
- * field exchange their digit counts through flagged words in the workspace while the pass runs (calls that share a
- * workspace must therefore not overlap in time; calls with workspaces of their own may).  Taken for 1024 <= B <= 131072
+ * bits its own table needs (one pass for up to 511 rows, three for ten million), without scan launches; up to
+ * B = 16384 a pass is one launch whose blocks exchange their digit counts through flagged words in the workspace
+ * while it runs (calls that share a workspace must not overlap in time, as with any workspace).  Taken for 1024 <= B <= 131072
  * when the workspace is at least this large; otherwise the global sort runs.  Same result either way, except the
  * order of the out-of-range pairs among themselves (key = total_rows, behind everything: by sample with the
  * global sort, by field with this one; they are ignored later). */

@@ -456,23 +456,30 @@ static int run_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t
 // field-major (field f's pairs at [f*B, (f+1)*B) in sample order), which sorts them by field for free, and the radix
 // passes then run inside each field on the bits ITS ids need: ceil(bits(V_f) / 9) passes of equal width <= 9 bits -
 // one pass for a table of up to 511 rows, three for ten million - instead of three passes over every pair for
-// 26-bit global row numbers.  A field is a segment of Tf = ceil(B / 4096) tiles.  A sort is the builder and ONE
-// launch per pass: a pass's block ranks its tile, publishes the tile's digit counts (one word per digit with a
-// "written" bit, so a word is its own flag), and reads the counts of the other Tf - 1 tiles of its field as they
-// appear - no histogram launch, no scan launch, no read-modify-write on global memory (a device-scope atomic is one
-// fabric transaction: a per-tile flush of digit counts by integer atomics was measured at +10 us per launch).
-// Blocks wait only for blocks of their own field, at most 31 block indices away, so with workgroups dispatched in
-// index order the wait ends as soon as the field's blocks have ranked their tiles; a wait that lasts FS_WAIT_TICKS
-// stops the kernel instead of hanging it.  Blocks of fields whose passes are done return at once; a field's last
-// pass writes the final split arrays with key = row_offset[f] + id.  Ids outside their table travel as id = V_f
-// (behind every valid id of the field); the last pass moves them behind all fields with key = total_rows, ordered by
-// field.  The count words of pass p live in region p & 1; the builder clears region 0 and a pass's block clears its
-// own slot of the other region for the next pass, so nothing has to be cleared between calls.
+// 26-bit global row numbers.  A field is a segment of Tf = ceil(B / 4096) tiles, so a scatter block finds its
+// offsets from the Tf digit counts of its own field: no scan launch.  Two forms of a pass:
+//   Tf <= FS_FUSED_MAX_TF (B <= 16384): ONE launch.  A block ranks its tile, publishes the tile's digit counts (one
+//     word per digit with a "written" bit, so a word is its own flag), and reads the counts of the other Tf - 1
+//     tiles of its field as they appear - no read-modify-write on global memory (a device-scope atomic is one fabric
+//     transaction: a per-tile flush of digit counts by integer atomics was measured at +10 us per launch).  Blocks
+//     wait only for blocks of their own field, at most three block indices away, so with workgroups dispatched in
+//     index order the wait ends as soon as the field's blocks have ranked their tiles; a wait that lasts
+//     FS_WAIT_TICKS stops the kernel instead of hanging it.  The count words of pass p live in region p & 1; the
+//     builder clears region 0 and a pass's block clears its own slot of the other region for the next pass, so
+//     nothing has to be cleared between calls.
+//   more tiles: a histogram launch, then the scatter, which requests the finished counts together with its keys.
+//     A field's 16 blocks are dispatched at different times when other kernels share the GPU, and blocks that wait
+//     hold their CU meanwhile: inside the DeepFM step at B = 65536 waiting passes made the step 1.7 % slower although
+//     the sort alone is 4 us faster with them.
+// Blocks of fields whose passes are done return at once; a field's last pass writes the final split arrays with
+// key = row_offset[f] + id.  Ids outside their table travel as id = V_f (behind every valid id of the field); the
+// last pass moves them behind all fields with key = total_rows, ordered by field.
 // ---------------------------------------------------------------------------------------
 constexpr int FS_BINS = 512;
 constexpr int FS_MAX_TF = 32;            // tiles per field (B <= 131072): a scatter thread holds one count per tile
 constexpr int FS_SB = 128;               // samples per builder block
 constexpr int FS_FG = 32;                // fields per builder block
+constexpr int FS_FUSED_MAX_TF = 4;          // tiles per field up to which a pass is one launch
 constexpr uint32_t FS_WRITTEN = 0x80000000u;             // a published count word (counts are <= 4096)
 constexpr unsigned long long FS_WAIT_TICKS = 200000000ull;   // 2 s of the 100 MHz wall clock
 
@@ -536,11 +543,53 @@ __global__ __launch_bounds__(256) void fs_build_kernel(const int32_t* __restrict
   if ((int)threadIdx.x < fgc) inv_fine[(int64_t)(f0 + threadIdx.x) * gridDim.x + blockIdx.x] = ninv[threadIdx.x];
 }
 
+// counts[f][t][digit] of one pass for the fields that still have one; block (f, t) = blockIdx.x; the first pass also
+// counts the tile's invalid lookups into inv_tile[f][t].  Used for batches of more than FS_FUSED_MAX_TF tiles per
+// field, where the scatter reads finished counts instead of waiting for them.
+__global__ __launch_bounds__(SORT_THREADS) void fs_hist_kernel(const uint2* __restrict__ in,
+                                                              const int64_t* __restrict__ row_offset, int B, int Tf,
+                                                              int pass, int rmode, uint32_t* __restrict__ counts,
+                                                              uint32_t* __restrict__ inv_tile) {
+  __shared__ uint32_t hist[FS_BINS];
+  __shared__ uint32_t ninv;
+  const int f = blockIdx.x / Tf, t = blockIdx.x - f * Tf;
+  uint32_t Vs;
+  int passes, rb;
+  fs_plan(row_offset[f + 1] - row_offset[f], rmode, Vs, passes, rb);
+  if (pass >= passes) return;
+  const int shift = pass * rb;
+  const uint32_t mask = (1u << rb) - 1u;
+  const int left = B - t * SORT_TILE;
+  const uint32_t cnt = left < SORT_TILE ? (uint32_t)left : (uint32_t)SORT_TILE;
+  const uint2* tile = in + ((uint32_t)f * (uint32_t)B + (uint32_t)t * SORT_TILE);
+  uint32_t k[SORT_CHUNKS];
+#pragma unroll
+  for (int c = 0; c < SORT_CHUNKS; ++c) {
+    const uint32_t i = c * SORT_THREADS + threadIdx.x;
+    k[c] = i < cnt ? tile[i].x : 0u;
+  }
+  hist[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) ninv = 0u;
+  __syncthreads();
+  uint32_t bad = 0u;
+#pragma unroll
+  for (int c = 0; c < SORT_CHUNKS; ++c) {
+    const bool valid = c * SORT_THREADS + threadIdx.x < cnt;
+    hist_add_chunk(hist, (k[c] >> shift) & mask, valid);
+    bad += (uint32_t)__popcll(__ballot(valid && k[c] == Vs));
+  }
+  if (pass == 0 && bad != 0u && (threadIdx.x & 63) == 0) atomicAdd(&ninv, bad);
+  __syncthreads();
+  counts[(int64_t)blockIdx.x * FS_BINS + threadIdx.x] = hist[threadIdx.x];
+  if (pass == 0 && threadIdx.x == 0) inv_tile[blockIdx.x] = ninv;
+}
+
 // One pass's stable scatter inside the fields: block (f, t) = blockIdx.x moves tile t of field f.  in / out: the uint2
 // pairs between passes; keys_out / src_out: the final arrays (written by a field's last pass); counts / counts_next:
 // this pass's and the next pass's [F][Tf][512] count words; inv_fine: [F][nb] invalid lookups per builder block
 // (nb = ceil(B / 128)); inv_tile: [F][Tf] the same per tile, written by pass 0 for the later launches.  The ranking
 // inside the tile is that of radix_scatter_kernel.
+template <bool FUSED>
 __global__ __launch_bounds__(SORT_THREADS) void fs_scatter_kernel(
     const uint2* __restrict__ in, uint2* __restrict__ out, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ src_out, const int64_t* __restrict__ row_offset, int B, int F, int Tf, int pass, int rmode,
@@ -580,12 +629,28 @@ __global__ __launch_bounds__(SORT_THREADS) void fs_scatter_kernel(
       val[c] = kv.y;
     }
   }
-  // invalid lookups (last pass only): in the fields before this one, in this field, in all.  Pass 0 reads the
-  // builder's counts (the other tiles' sums are being written by this launch), later passes pass 0's per-tile sums.
+  // !FUSED: a histogram launch finished the counts before this one; they are requested with the keys (digit d =
+  // threadIdx.x: the field's count over its Tf tiles and the count in the tiles before this one)
+  uint32_t gb[1] = {0u}, sc = 0u;
+  if (!FUSED) {
+    const uint32_t* ccol = counts + (int64_t)f * Tf * RBINS + threadIdx.x;
+    uint32_t cc[FS_MAX_TF];
+#pragma unroll
+    for (int tt = 0; tt < FS_MAX_TF; ++tt) cc[tt] = tt < Tf ? ccol[(int64_t)tt * RBINS] : 0u;
+#pragma unroll
+    for (int tt = 0; tt < FS_MAX_TF; ++tt) {
+      gb[0] += cc[tt];
+      if (tt < t) sc += cc[tt];
+    }
+  }
+  // invalid lookups (last pass only): in the fields before this one, in this field, in all.  A fused pass 0 reads the
+  // builder's counts (the other tiles' sums are being written by this very launch); every other pass reads the
+  // per-tile sums an earlier launch wrote.
   uint32_t inv_before = 0u, inv_f = 0u, inv_total = 0u;
   if (last) {
-    const uint32_t* src = pass == 0 ? inv_fine : inv_tile;
-    const int per = pass == 0 ? nb : Tf;
+    const bool fine = FUSED && pass == 0;
+    const uint32_t* src = fine ? inv_fine : inv_tile;
+    const int per = fine ? nb : Tf;
     for (int g = threadIdx.x; g < F * per; g += SORT_THREADS) {
       const uint32_t c = src[g];
       const int gf = g / per;
@@ -594,14 +659,14 @@ __global__ __launch_bounds__(SORT_THREADS) void fs_scatter_kernel(
       if (gf == f) inv_f += c;
     }
   }
-  if (pass == 0 && wave == 0) {
+  if (FUSED && pass == 0 && wave == 0) {
     const int g = t * FINE_PER_TILE + lane;
     uint32_t c = (lane < FINE_PER_TILE && g < nb) ? inv_fine[(int64_t)f * nb + g] : 0u;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
     if (lane == 0) inv_tile[blockIdx.x] = c;
   }
-  if (!last) counts_next[(int64_t)blockIdx.x * RBINS + threadIdx.x] = 0u;
+  if (FUSED && !last) counts_next[(int64_t)blockIdx.x * RBINS + threadIdx.x] = 0u;
   for (int i = threadIdx.x; i < SORT_WAVES * RBINS / 2; i += SORT_THREADS) (&whist32[0][0])[i] = 0u;
   for (int i = threadIdx.x; i < SORT_TILE; i += SORT_THREADS) lds64[i] = 0ull;
   if (last) {
@@ -613,7 +678,8 @@ __global__ __launch_bounds__(SORT_THREADS) void fs_scatter_kernel(
     }
     if (lane == 0) { inv_red[0][wave] = inv_total; inv_red[1][wave] = inv_before; inv_red[2][wave] = inv_f; }
   }
-  __syncthreads();
+  if (!FUSED) block_excl_scan<1>(gb, wtot_a, lane, wave);  // its barrier also orders the clearing above
+  else __syncthreads();
   if (last) {
     inv_total = inv_before = inv_f = 0u;
 #pragma unroll
@@ -655,9 +721,10 @@ __global__ __launch_bounds__(SORT_THREADS) void fs_scatter_kernel(
   }
   uint32_t* col = counts + (int64_t)f * Tf * RBINS + threadIdx.x;
   const uint32_t mine = ts[0];
-  __hip_atomic_store(col + (int64_t)t * RBINS, mine | FS_WRITTEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (FUSED) __hip_atomic_store(col + (int64_t)t * RBINS, mine | FS_WRITTEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   block_excl_scan<1>(ts, wtot_b, lane, wave);
   tstart[threadIdx.x] = ts[0];
+  if (!FUSED) goff[threadIdx.x] = gb[0] + sc - ts[0];
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < SORT_CHUNKS; ++c) {
@@ -667,11 +734,10 @@ __global__ __launch_bounds__(SORT_THREADS) void fs_scatter_kernel(
       lds64[tstart[d] + whist[wave * RBINS + d] + rank[c]] = (unsigned long long)key[c] | ((unsigned long long)val[c] << 32);
     }
   }
-  // the field's count of digit d (over its Tf tiles) and the count in the tiles before this one, as the other
-  // tiles publish theirs; every outstanding word is requested in each round
-  uint32_t gb[1], sc = 0u;
-  bool gave_up = false;
-  {
+  if (FUSED) {
+    // the field's count of digit d (over its Tf tiles) and the count in the tiles before this one, as the other
+    // tiles publish theirs; every outstanding word is requested in each round
+    bool gave_up = false;
     uint32_t tot = mine;
     uint32_t pending = (Tf >= 32 ? 0xFFFFFFFFu : (1u << Tf) - 1u) & ~(1u << t);
     const unsigned long long t0 = wall_clock64();
@@ -697,10 +763,10 @@ __global__ __launch_bounds__(SORT_THREADS) void fs_scatter_kernel(
       if (pending != 0u) __builtin_amdgcn_s_sleep(8);
     }
     gb[0] = tot;
+    if (__syncthreads_or(gave_up)) __builtin_trap();      // a tile of this field never arrived: stop, do not hang
+    block_excl_scan<1>(gb, wtot_a, lane, wave);
+    goff[threadIdx.x] = gb[0] + sc - ts[0];
   }
-  if (__syncthreads_or(gave_up)) __builtin_trap();        // a tile of this field never arrived: stop, do not hang
-  block_excl_scan<1>(gb, wtot_a, lane, wave);
-  goff[threadIdx.x] = gb[0] + sc - ts[0];
   __syncthreads();
   if (!last) {
 #pragma unroll
@@ -860,14 +926,30 @@ static void fs_sort(const int32_t* idx, const int64_t* row_offset, int B, int F,
   uint32_t* counts[2] = {(uint32_t*)p, (uint32_t*)p + words};
   uint32_t* inv_tile = counts[1] + words;                  // [F][Tf]
   uint32_t* inv_fine = inv_tile + (size_t)F * Tf;          // [F][nb]
+  // one launch per pass while a field has few tiles (its blocks are dispatched together, and the launches are what
+  // the sort costs); with more tiles a histogram launch per pass and no waiting inside the scatter: beside other
+  // kernels a field's blocks become resident at different times, and blocks that wait hold their CU meanwhile
+  // (measured inside the DeepFM step at B = 65536: the step 1 % slower with waiting passes, although the sort alone
+  // is 10 us faster).  CTR_FS_FUSED_MAX_TF moves the border (measurement switch).
+  static const int fused_max_tf = getenv("CTR_FS_FUSED_MAX_TF") ? atoi(getenv("CTR_FS_FUSED_MAX_TF")) : FS_FUSED_MAX_TF;
+  const bool fused = Tf <= fused_max_tf;
   hipLaunchKernelGGL(fs_build_kernel, dim3((unsigned)nb, (unsigned)cdiv(F, FS_FG)), dim3(256), 0, st, idx, row_offset, B,
-                     F, N, rmode, pa, inv_fine, counts[0], words);
+                     F, N, rmode, pa, inv_fine, counts[0], fused ? words : (int64_t)0);
   for (int ps = 0; ps < pmax; ++ps) {
     const uint2* in = (ps & 1) ? pb : pa;
     uint2* out = (ps & 1) ? pa : pb;
-    hipLaunchKernelGGL(fs_scatter_kernel, dim3((unsigned)(F * Tf)), dim3(SORT_THREADS), 0, st, in, out, keys_out, src_out,
-                       row_offset, B, F, Tf, ps, rmode, total_rows, counts[ps & 1], counts[(ps + 1) & 1], inv_fine, nb,
-                       inv_tile);
+    uint32_t* cur = fused ? counts[ps & 1] : counts[0];
+    if (fused) {
+      hipLaunchKernelGGL(fs_scatter_kernel<true>, dim3((unsigned)(F * Tf)), dim3(SORT_THREADS), 0, st, in, out, keys_out,
+                         src_out, row_offset, B, F, Tf, ps, rmode, total_rows, cur, counts[(ps + 1) & 1], inv_fine, nb,
+                         inv_tile);
+    } else {
+      hipLaunchKernelGGL(fs_hist_kernel, dim3((unsigned)(F * Tf)), dim3(SORT_THREADS), 0, st, in, row_offset, B, Tf, ps,
+                         rmode, cur, inv_tile);
+      hipLaunchKernelGGL(fs_scatter_kernel<false>, dim3((unsigned)(F * Tf)), dim3(SORT_THREADS), 0, st, in, out, keys_out,
+                         src_out, row_offset, B, F, Tf, ps, rmode, total_rows, cur, counts[(ps + 1) & 1], inv_fine, nb,
+                         inv_tile);
+    }
   }
 }
 
