@@ -315,6 +315,13 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
                            global_batch=world * B,
                            parallelism='dp%d + %s-sharded tables' % (world, shard) if world > 1 else 'single'),
                final_loss=loss if np.isfinite(loss) else None)
+    tb = getattr(getattr(model, 'tables', None), 'touched', None)
+    if tb is not None:
+        # the decay pass of tf.train.AdamOptimizer skips rows that never received a gradient (m = v = 0: the step
+        # leaves them as they are), so its cost follows the share of rows with optimizer state
+        out['rows_with_optimizer_state'] = dict(
+            share=float((tb != 0).sum().item()) / tb.numel(), after_steps=int(model.global_step),
+            note='rows without state are exact no-ops of the dense Adam step and are not read')
     if eager_blocks is not None:
         out['step_runs_as'] = 'captured graph replay (launch-bound step: batch <= %d and narrow towers, as run() does)' % GRAPH_MAX_BATCH
         out['eager'] = dict(value=B * steps / float(np.median(eager_blocks)), timing=timing_of(eager_blocks, steps))
@@ -610,6 +617,8 @@ def main():
                                          args.shard, light=True)
         legs['deepfm_tf1_adam'] = leg(run_model, 'DeepFM_tf1adam', args, sess, rank, world, dist, st, wu, args.batch,
                                       args.embed, args.shard, light=True)
+        legs['deepfm_tf1_adam_uniform_ids'] = leg(run_model, 'DeepFM_tf1adam', args, sess, rank, world, dist, st, wu,
+                                                  args.batch, args.embed, args.shard, alpha=0.0, light=True)
         for v in ('PNN', 'PNN_outer', 'AFM', 'AFM_pairs', 'ESMM', 'NFM'):      # BASELINE configs[3] (+ ESMM of configs[4])
             legs[v] = leg(run_model, v, args, sess, rank, world, dist, st, wu, 65536, 16, 'table', light=True)
         for h in (32, 128):                                                    # BASELINE configs[4]

@@ -270,9 +270,14 @@ int ctr_emb_sparse_apply_fm(const uint32_t* keys_sorted, const uint32_t* src_sor
 /* tf.train.AdamOptimizer on an embedding variable (DeepFM/DeepFM.py:32,100) moves EVERY row each step: rows
  * without a gradient still decay m and v and take the step lr * m / (sqrt(v) + eps).  In two parts without a dense
  * gradient buffer: ctr_emb_sparse_apply (CTR_OPT_ADAM) on the rows that received a gradient, then
- * ctr_adam_untouched_rows on all others - the rows to skip are marked in a byte per table row by
- * ctr_mark_rows(value = 1) from the sorted keys before, and unmarked with value = 0 after (the map is all zeros
- * between steps).  tables, m, v: contiguous [rows, E], E % 4 == 0. */
+ * ctr_adam_untouched_rows on all others.  A byte per table row tells the second part what to do: bit 0 = updated by
+ * the first part in this step (skip), bit 1 = the row's m or v may be nonzero.  ctr_mark_rows(value = 1) sets both bits
+ * on the rows the sorted keys name before the pass, ctr_mark_rows(value = 0) clears bit 0 on them after it.  A row
+ * whose byte is 0 has no optimizer state: the formulas leave such a row exactly as it is (m = v = 0: no decay, no
+ * step), so the pass does not even read it - on tables of tens of millions of rows, most of which never receive a
+ * gradient, that is most of the work.  Start from a map of zeros together with zero m and v; a caller that fills m or
+ * v by other means (a restored checkpoint) sets the bytes of those rows, or of all rows, to 2.  Values with m = v = +0
+ * inside rows with state are skipped as well (same result).  tables, m, v: contiguous [rows, E], E % 4 == 0. */
 int ctr_mark_rows(const uint32_t* keys_sorted, int64_t n_items, int64_t total_rows, uint8_t* touched, int value,
                   void* stream);
 int ctr_adam_untouched_rows(float* tables, float* m, float* v, int64_t rows, int E, const uint8_t* touched,

@@ -453,39 +453,68 @@ __global__ __launch_bounds__(256) void dense_update_kernel(float* __restrict__ p
   }
 }
 
-// touched[key] = 1 for every table row that heads a run of the sorted pairs (keys outside the tables mark nothing).
+// A row's byte: bit 0 = the row heads a run of this step's sorted pairs (the row-wise pass updates it), bit 1 = the
+// row has received a gradient since the map was cleared, i.e. its m and v may be nonzero.
+// touched[key] = 3 for every table row that heads a run of the sorted pairs (keys outside the tables mark nothing).
 __global__ __launch_bounds__(256) void mark_rows_kernel(const uint32_t* __restrict__ keys, int64_t n, int64_t total_rows,
                                                        uint8_t* __restrict__ touched) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const uint32_t k = keys[i];
-    if ((int64_t)k < total_rows && (i == 0 || keys[i - 1] != k)) touched[k] = 1;
+    if ((int64_t)k < total_rows && (i == 0 || keys[i - 1] != k)) touched[k] = 3;
   }
 }
 
 // tf.train.AdamOptimizer's step on the rows that received no gradient: m = b1 m, v = b2 v, w -= lr m / (sqrt(v) + eps)
 // (the expressions of dense_update_kernel with g = 0, so the same bits), four floats per thread; rows marked in
-// `touched` were updated by the row-wise pass and are skipped.
+// `touched` (bit 0) were updated by the row-wise pass and are skipped.  Four floats whose m and v are all +0 stay
+// exactly as they are under these expressions (b1 * 0 = 0, b2 * 0 = 0, w - lr * 0 / (0 + eps) = w), so rows without
+// optimizer state cost nothing but their byte: a row whose byte is 0 has never received a gradient and is not read
+// at all, and among the others w is requested, and anything written, only by waves that hold a value with state.
+// On tables of tens of millions of rows most rows have never received a gradient, so most waves stop after one byte.
 __global__ __launch_bounds__(256) void adam_untouched_kernel(float* __restrict__ w, float* __restrict__ m,
                                                             float* __restrict__ v, int64_t n4, int q_per_row,
                                                             uint8_t* __restrict__ touched, Opt o) {
   o = resolve_opt(o);
-  constexpr int U = 4;                                   // quads per thread and trip: twelve row loads in flight
+  constexpr int U = 4;                                   // quads per thread and trip: eight row loads in flight
   const int64_t stride = (int64_t)gridDim.x * 256;
+  // exact only while 0 / (0 + eps) is 0 and lr * 0 is 0
+  const bool may_skip = o.eps > 0.f && o.LR() - o.LR() == 0.f;
   for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += U * stride) {
     float4 mm[U], vv[U], p[U];
-    bool go[U];
+    bool live[U];
+    bool any_live = false;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t i = i0 + u * stride;
-      go[u] = i < n4 && !touched[i / q_per_row];
-      const int64_t j = i < n4 ? i : 0;
+      const uint8_t t = touched[i < n4 ? i / q_per_row : 0];
+      live[u] = i < n4 && !(t & 1) && ((t & 2) || !may_skip);
+      any_live = any_live || live[u];
+    }
+    if (!__any(any_live)) continue;                      // the whole wave: rows that never received a gradient
+    any_live = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = live[u] ? i0 + u * stride : 0;
       mm[u] = reinterpret_cast<const float4*>(m)[j];
       vv[u] = reinterpret_cast<const float4*>(v)[j];
-      p[u] = reinterpret_cast<const float4*>(w)[j];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (!go[u]) continue;
+      const uint32_t bits = __float_as_uint(mm[u].x) | __float_as_uint(mm[u].y) | __float_as_uint(mm[u].z) |
+                            __float_as_uint(mm[u].w) | __float_as_uint(vv[u].x) | __float_as_uint(vv[u].y) |
+                            __float_as_uint(vv[u].z) | __float_as_uint(vv[u].w);
+      live[u] = live[u] && (bits != 0u || !may_skip);
+      any_live = any_live || live[u];
+    }
+    if (!__any(any_live)) continue;                      // the whole wave: nothing here has optimizer state
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * stride;
+      p[u] = reinterpret_cast<const float4*>(w)[live[u] ? i : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!live[u]) continue;
       const int64_t i = i0 + u * stride;
       const float g = 0.f;
       float4 a = mm[u], c = vv[u], x = p[u];
@@ -502,12 +531,13 @@ __global__ __launch_bounds__(256) void adam_untouched_kernel(float* __restrict__
   }
 }
 
-// second launch: clears the marks (a row's threads of the pass above all read its mark, so none of them may clear it)
+// second launch: clears bit 0 of the marks (a row's threads of the pass above all read its mark, so none of them may
+// clear it); bit 1 stays
 __global__ __launch_bounds__(256) void unmark_rows_kernel(const uint32_t* __restrict__ keys, int64_t n, int64_t total_rows,
                                                          uint8_t* __restrict__ touched) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const uint32_t k = keys[i];
-    if ((int64_t)k < total_rows && (i == 0 || keys[i - 1] != k)) touched[k] = 0;
+    if ((int64_t)k < total_rows && (i == 0 || keys[i - 1] != k)) touched[k] = 2;
   }
 }
 

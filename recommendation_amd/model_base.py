@@ -468,6 +468,8 @@ class CTRModel(GraphOwner):
                     rows = None if full is None else self._local_rows(f, full)
                 if rows is not None:
                     self.tables.table(fl, buf).copy_(rows)
+        if self.tables.touched is not None:
+            self.tables.touched.fill_(2)      # restored m / v: every row may have optimizer state
 
     # ---- step ------------------------------------------------------------------------------
     def _lr(self):

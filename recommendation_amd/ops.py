@@ -577,7 +577,9 @@ def emb_sparse_apply(keys, src, n_items, *, N, E, total_rows, dz, opt, ws, table
 def adam_untouched_rows(keys, n_items, *, total_rows, E, opt, tables, slot0, slot1, touched):
     """tf.train.AdamOptimizer's step on the table rows that received no gradient this step (m, v decay and the row
     still moves); the rows the sorted `keys` name were updated by emb_sparse_apply and are skipped.  touched: uint8
-    [total_rows], all zeros on entry and on return."""
+    [total_rows]; bit 0 is clear on entry and on return, bit 1 marks the rows that have optimizer state (set here on
+    the rows `keys` names; rows whose byte is 0 must have m = v = 0 and are not read - fill the map with 2 after
+    writing m or v by other means)."""
     for t in (tables, slot0, slot1):
         if not t.is_contiguous() or t.numel() < total_rows * E:
             raise ValueError('adam_untouched_rows takes contiguous [total_rows, E] tensors')

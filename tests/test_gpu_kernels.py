@@ -289,6 +289,48 @@ def test_sparse_optimizers_match_tf1_formulas(ops_ws, kind, E):
     assert np.array_equal(out[~touched], W[~touched])             # untouched rows are not written
 
 
+@pytest.mark.parametrize('E', [8, 16, 64])
+def test_adam_pass_over_the_rows_without_a_gradient(ops_ws, E):
+    """ctr_adam_untouched_rows: tf.train.AdamOptimizer's step on every row the sorted keys do not name - the bits of
+    ctr_dense_update with a zero gradient.  Most rows have no optimizer state (m = v = +0): those are skipped by the
+    kernel (their byte in the row map is 0: not even read) and must come out unchanged, as the formula leaves them;
+    rows with state (a -0.0 in m included) decay and move; the rows the keys name are left alone, their bit 0 is
+    cleared again and bit 1 records that they now have state."""
+    ops, ws = ops_ws
+    rng = np.random.default_rng(E)
+    total = 70001
+    W = rng.standard_normal((total, E)).astype(np.float32)
+    m0 = np.zeros((total, E), dtype=np.float32)
+    v0 = np.zeros((total, E), dtype=np.float32)
+    state = rng.random(total) < 0.2
+    state[60000:] = False                                   # a long stretch without state: whole waves skip
+    m0[state] = (rng.standard_normal((int(state.sum()), E)) * 0.1).astype(np.float32)
+    v0[state] = (np.abs(rng.standard_normal((int(state.sum()), E))) * 0.01).astype(np.float32)
+    m0[5, 0], v0[5, :] = -0.0, 0.0                          # negative zero alone is state too
+    m0[5, 1:] = 0.0
+    m0[7, :], v0[7, :] = 0.0, 0.0
+    v0[7, 3] = 1e-30                                        # one tiny v in an otherwise empty row
+    named = np.sort(rng.choice(total, 3000, replace=False)).astype(np.int32)
+    keys = dev(np.concatenate([np.repeat(named, 2), np.full(5, total, dtype=np.int32)]))   # runs, and ignored pairs
+    opt = ops.make_opt(1, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8)
+    dW, dm, dv = dev(W), dev(m0), dev(v0)
+    has_state = state.copy()
+    has_state[[5, 7]] = True
+    has_state[100:200] = True                               # marked, yet without state: read and left alone
+    touched = dev((has_state * 2).astype(np.uint8))
+    ops.adam_untouched_rows(keys, keys.numel(), total_rows=total, E=E, opt=opt, tables=dW, slot0=dm, slot1=dv,
+                            touched=touched)
+    rW, rm, rv = dev(W), dev(m0), dev(v0)
+    ops.dense_update(rW, torch.zeros_like(rW), opt, rm, rv)
+    for got, ref, orig in ((dW, rW, W), (dm, rm, m0), (dv, rv, v0)):
+        got, ref = got.cpu().numpy(), ref.cpu().numpy()
+        ref[named] = orig[named]
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    want = has_state * 2
+    want[named] = 2                                         # bit 0 cleared again, bit 1 left on the named rows
+    assert np.array_equal(touched.cpu().numpy(), want.astype(np.uint8))
+
+
 @pytest.mark.parametrize('E', [4, 16, 64])
 def test_sparse_adam_with_m_and_v_side_by_side_leaves_the_same_bits(ops_ws, E):
     """ctr_emb_sparse_apply_ld: Adam's slots as the two column blocks of one [rows, 2E] buffer (row pitch 2E) against
