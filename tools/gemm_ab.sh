@@ -1,4 +1,6 @@
-# the tower products with the library in the tree against a second build (CTRHIP_LIB), same box, same process order
+# the tower products with the library in the tree against a second build (CTRHIP_LIB), same box, same process order.
+# The second build: compile the other version of csrc/gemm.hip to an object of its own and link it with the tree's other
+# objects into recommendation_amd/lib/exp/libctrhip_base.so (the hipcc lines of csrc/Makefile), here, before the GPU call.
 set -e
 B=$PWD/recommendation_amd/lib/exp/libctrhip_base.so
 for mode in "" dcn; do
