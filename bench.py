@@ -79,6 +79,7 @@ MODEL_ARGS = {
     # (DeepFM/DeepFM.py:32,100): m and v of EVERY row decay and every row moves, each step
     'DeepFM_tf1adam': dict(deep_layers=[256, 128, 64, 32], dropout_fm=0.5, dropout_deep=0.2, adam_mode='tf1',
                            table_grads=False),
+    'DCN_tf1adam': dict(deep_layers=[1024, 1024, 1024], cross_layer_num=6, dropout=0.2, adam_mode='tf1', table_grads=False),
 }
 
 
@@ -222,7 +223,7 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
     from recommendation_amd import ops
     from recommendation_amd.synthetic import CRITEO_1TB, CRITEO_KAGGLE, make_batches, scaled
     dev = sess.device
-    is_dcn = variant == 'DCN'
+    is_dcn = variant.startswith('DCN')
     # DeepFM: BASELINE configs[1] (Criteo-Kaggle cardinalities).  DCN: configs[2] per-GPU share —
     # Criteo-1TB cardinalities / 8 (one GPU of the 8-GPU shard), dim 64, 6 cross layers, 1024x3 tower.
     cards = CRITEO_KAGGLE if not is_dcn else scaled(CRITEO_1TB, 8 // min(world, 8))
@@ -318,10 +319,24 @@ def run_model(variant, args, sess, rank, world, dist, steps, warmup, batch, embe
     tb = getattr(getattr(model, 'tables', None), 'touched', None)
     if tb is not None:
         # the decay pass of tf.train.AdamOptimizer skips rows that never received a gradient (m = v = 0: the step
-        # leaves them as they are), so its cost follows the share of rows with optimizer state
+        # leaves them as they are), so its cost follows the share of rows with optimizer state: the share reached on
+        # the synthetic batches (a cycle of 8) above, and the other end - every row given state - timed here
+        share, at = float((tb != 0).sum().item()) / tb.numel(), int(model.global_step)
+        model.tables.slot1.fill_(1e-30)
+        tb.fill_(2)
+        for i in range(2):
+            model.train_step(*batches[i % len(batches)])
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            model.train_step(*batches[i % len(batches)])
+        barrier()
+        dta = time.perf_counter() - t0
         out['rows_with_optimizer_state'] = dict(
-            share=float((tb != 0).sum().item()) / tb.numel(), after_steps=int(model.global_step),
-            note='rows without state are exact no-ops of the dense Adam step and are not read')
+            share=share, after_steps=at,
+            note='rows without state are exact no-ops of the dense Adam step and are not read',
+            every_row_with_state=dict(value=world * B * steps / dta, ms_per_step=1e3 * dta / steps,
+                                      note='v of every row set to 1e-30 first: the same steps with all rows decaying'))
     if eager_blocks is not None:
         out['step_runs_as'] = 'captured graph replay (launch-bound step: batch <= %d and narrow towers, as run() does)' % GRAPH_MAX_BATCH
         out['eager'] = dict(value=B * steps / float(np.median(eager_blocks)), timing=timing_of(eager_blocks, steps))
@@ -617,6 +632,7 @@ def main():
                                          args.shard, light=True)
         legs['deepfm_tf1_adam'] = leg(run_model, 'DeepFM_tf1adam', args, sess, rank, world, dist, st, wu, args.batch,
                                       args.embed, args.shard, light=True)
+        legs['dcn_tf1_adam'] = leg(run_model, 'DCN_tf1adam', args, sess, rank, world, dist, st, wu, 8192, 64, 'row', light=True)
         legs['deepfm_tf1_adam_uniform_ids'] = leg(run_model, 'DeepFM_tf1adam', args, sess, rank, world, dist, st, wu,
                                                   args.batch, args.embed, args.shard, alpha=0.0, light=True)
         for v in ('PNN', 'PNN_outer', 'AFM', 'AFM_pairs', 'ESMM', 'NFM'):      # BASELINE configs[3] (+ ESMM of configs[4])

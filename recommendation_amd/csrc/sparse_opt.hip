@@ -465,69 +465,101 @@ __global__ __launch_bounds__(256) void mark_rows_kernel(const uint32_t* __restri
 }
 
 // tf.train.AdamOptimizer's step on the rows that received no gradient: m = b1 m, v = b2 v, w -= lr m / (sqrt(v) + eps)
-// (the expressions of dense_update_kernel with g = 0, so the same bits), four floats per thread; rows marked in
-// `touched` (bit 0) were updated by the row-wise pass and are skipped.  Four floats whose m and v are all +0 stay
-// exactly as they are under these expressions (b1 * 0 = 0, b2 * 0 = 0, w - lr * 0 / (0 + eps) = w), so rows without
-// optimizer state cost nothing but their byte: a row whose byte is 0 has never received a gradient and is not read
-// at all, and among the others w is requested, and anything written, only by waves that hold a value with state.
-// On tables of tens of millions of rows most rows have never received a gradient, so most waves stop after one byte.
+// (the expressions of dense_update_kernel with g = 0, so the same bits); rows marked in `touched` (bit 0) were
+// updated by the row-wise pass and are skipped.  Four floats whose m and v are all +0 stay exactly as they are under
+// these expressions (b1 * 0 = 0, b2 * 0 = 0, w - lr * 0 / (0 + eps) = w), so rows without optimizer state cost
+// nothing but their byte: on tables of tens of millions of rows most rows have never received a gradient.
+// A wave walks chunks of 1024 rows: a lane reads the bytes of 16 rows at once, the rows to work on (bit 0 clear, bit 1
+// set) are listed in the wave's piece of LDS, and the wave then takes the listed rows' quads 128 at a time: m and v
+// first, w - and anything written - only where some value has state.
+constexpr int AU_ROWS = 1024;        // rows per wave chunk (16 per lane)
 __global__ __launch_bounds__(256) void adam_untouched_kernel(float* __restrict__ w, float* __restrict__ m,
-                                                            float* __restrict__ v, int64_t n4, int q_per_row,
-                                                            uint8_t* __restrict__ touched, Opt o) {
+                                                            float* __restrict__ v, int64_t rows, int q_per_row,
+                                                            const uint8_t* __restrict__ touched, Opt o) {
+  __shared__ uint32_t lists[4][AU_ROWS];
   o = resolve_opt(o);
-  constexpr int U = 4;                                   // quads per thread and trip: eight row loads in flight
-  const int64_t stride = (int64_t)gridDim.x * 256;
   // exact only while 0 / (0 + eps) is 0 and lr * 0 is 0
   const bool may_skip = o.eps > 0.f && o.LR() - o.LR() == 0.f;
-  for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += U * stride) {
-    float4 mm[U], vv[U], p[U];
-    bool live[U];
-    bool any_live = false;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + u * stride;
-      const uint8_t t = touched[i < n4 ? i / q_per_row : 0];
-      live[u] = i < n4 && !(t & 1) && ((t & 2) || !may_skip);
-      any_live = any_live || live[u];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  volatile uint32_t* list = lists[wave];
+  const int64_t nchunks = (rows + AU_ROWS - 1) / AU_ROWS;
+  for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (int64_t)gridDim.x * 4) {
+    const int64_t r0 = chunk * AU_ROWS + lane * 16;
+    uint32_t by[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};     // past the end: "skip"
+    if (r0 + 16 <= rows) {
+      const uint4 q = *reinterpret_cast<const uint4*>(touched + r0);
+      by[0] = q.x; by[1] = q.y; by[2] = q.z; by[3] = q.w;
+    } else {
+      for (int k = 0; k < 16; ++k)
+        if (r0 + k < rows) by[k >> 2] = (by[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | ((uint32_t)touched[r0 + k] << (8 * (k & 3)));
     }
-    if (!__any(any_live)) continue;                      // the whole wave: rows that never received a gradient
-    any_live = false;
+    uint32_t mask = 0u;                                  // bit k: row r0 + k is worked on
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t j = live[u] ? i0 + u * stride : 0;
-      mm[u] = reinterpret_cast<const float4*>(m)[j];
-      vv[u] = reinterpret_cast<const float4*>(v)[j];
+    for (int k = 0; k < 16; ++k) {
+      const uint32_t t = (by[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+      if (!(t & 1u) && ((t & 2u) || !may_skip)) mask |= 1u << k;
     }
+    const uint32_t cnt = (uint32_t)__popc(mask);
+    uint32_t incl = cnt;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t bits = __float_as_uint(mm[u].x) | __float_as_uint(mm[u].y) | __float_as_uint(mm[u].z) |
-                            __float_as_uint(mm[u].w) | __float_as_uint(vv[u].x) | __float_as_uint(vv[u].y) |
-                            __float_as_uint(vv[u].z) | __float_as_uint(vv[u].w);
-      live[u] = live[u] && (bits != 0u || !may_skip);
-      any_live = any_live || live[u];
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+      if (lane >= d) incl += up;
     }
-    if (!__any(any_live)) continue;                      // the whole wave: nothing here has optimizer state
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    if (total == 0u) continue;                           // the whole chunk: rows that never received a gradient
+    uint32_t pos = incl - cnt;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + u * stride;
-      p[u] = reinterpret_cast<const float4*>(w)[live[u] ? i : 0];
-    }
+    for (int k = 0; k < 16; ++k)
+      if (mask & (1u << k)) list[pos++] = (uint32_t)(lane * 16 + k);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t n = total * (uint32_t)q_per_row;      // quads of the listed rows
+    const int64_t rbase = chunk * AU_ROWS;
+    constexpr int U = 2;
+    for (uint32_t base = 0; base < n; base += 64 * U) {
+      float4 mm[U], vv[U], p[U];
+      int64_t j[U];
+      bool live[U];
+      bool any_live = false;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!live[u]) continue;
-      const int64_t i = i0 + u * stride;
-      const float g = 0.f;
-      float4 a = mm[u], c = vv[u], x = p[u];
-      a.x = o.b1 * a.x + (1.f - o.b1) * g; a.y = o.b1 * a.y + (1.f - o.b1) * g;
-      a.z = o.b1 * a.z + (1.f - o.b1) * g; a.w = o.b1 * a.w + (1.f - o.b1) * g;
-      c.x = o.b2 * c.x + (1.f - o.b2) * g * g; c.y = o.b2 * c.y + (1.f - o.b2) * g * g;
-      c.z = o.b2 * c.z + (1.f - o.b2) * g * g; c.w = o.b2 * c.w + (1.f - o.b2) * g * g;
-      x.x -= o.LR() * a.x / (sqrtf(c.x) + o.eps); x.y -= o.LR() * a.y / (sqrtf(c.y) + o.eps);
-      x.z -= o.LR() * a.z / (sqrtf(c.z) + o.eps); x.w -= o.LR() * a.w / (sqrtf(c.w) + o.eps);
-      reinterpret_cast<float4*>(m)[i] = a;
-      reinterpret_cast<float4*>(v)[i] = c;
-      reinterpret_cast<float4*>(w)[i] = x;
+      for (int u = 0; u < U; ++u) {
+        const uint32_t idx = base + u * 64 + lane;
+        const bool ok = idx < n;
+        const uint32_t li = ok ? idx / (uint32_t)q_per_row : 0u;
+        const uint32_t qq = ok ? idx - li * (uint32_t)q_per_row : 0u;
+        j[u] = (rbase + list[li]) * q_per_row + qq;
+        mm[u] = reinterpret_cast<const float4*>(m)[j[u]];
+        vv[u] = reinterpret_cast<const float4*>(v)[j[u]];
+        live[u] = ok;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t bits = __float_as_uint(mm[u].x) | __float_as_uint(mm[u].y) | __float_as_uint(mm[u].z) |
+                              __float_as_uint(mm[u].w) | __float_as_uint(vv[u].x) | __float_as_uint(vv[u].y) |
+                              __float_as_uint(vv[u].z) | __float_as_uint(vv[u].w);
+        live[u] = live[u] && (bits != 0u || !may_skip);
+        any_live = any_live || live[u];
+      }
+      if (!__any(any_live)) continue;                    // listed rows whose state is all zeros (marked, never updated)
+#pragma unroll
+      for (int u = 0; u < U; ++u) p[u] = reinterpret_cast<const float4*>(w)[j[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!live[u]) continue;
+        const float g = 0.f;
+        float4 a = mm[u], c = vv[u], x = p[u];
+        a.x = o.b1 * a.x + (1.f - o.b1) * g; a.y = o.b1 * a.y + (1.f - o.b1) * g;
+        a.z = o.b1 * a.z + (1.f - o.b1) * g; a.w = o.b1 * a.w + (1.f - o.b1) * g;
+        c.x = o.b2 * c.x + (1.f - o.b2) * g * g; c.y = o.b2 * c.y + (1.f - o.b2) * g * g;
+        c.z = o.b2 * c.z + (1.f - o.b2) * g * g; c.w = o.b2 * c.w + (1.f - o.b2) * g * g;
+        x.x -= o.LR() * a.x / (sqrtf(c.x) + o.eps); x.y -= o.LR() * a.y / (sqrtf(c.y) + o.eps);
+        x.z -= o.LR() * a.z / (sqrtf(c.z) + o.eps); x.w -= o.LR() * a.w / (sqrtf(c.w) + o.eps);
+        reinterpret_cast<float4*>(m)[j[u]] = a;
+        reinterpret_cast<float4*>(v)[j[u]] = c;
+        reinterpret_cast<float4*>(w)[j[u]] = x;
+      }
     }
+    __builtin_amdgcn_wave_barrier();                     // the list is rewritten by the next chunk
   }
 }
 
@@ -756,10 +788,12 @@ extern "C" int ctr_adam_untouched_rows(float* tables, float* m, float* v, int64_
   CTR_REQUIRE(tables && m && v && touched, "ctr_adam_untouched_rows: null pointer");
   CTR_REQUIRE(((uintptr_t)tables % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
               "ctr_adam_untouched_rows: 16-byte alignment");
-  const int64_t n4 = rows * (E / 4);
-  const int64_t blocks = cdiv(n4, 256) < 16384 ? cdiv(n4, 256) : 16384;
-  hipLaunchKernelGGL(adam_untouched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tables, m, v, n4,
-                     E / 4, const_cast<uint8_t*>(touched), make_opt(opt));
+  CTR_REQUIRE(((uintptr_t)touched % 16) == 0, "ctr_adam_untouched_rows: the row map must be 16-byte aligned");
+  CTR_REQUIRE(rows < ((int64_t)1 << 40) && (int64_t)AU_ROWS * (E / 4) < 0xFFFFFFFFll, "ctr_adam_untouched_rows: size");
+  const int64_t chunks = cdiv(rows, AU_ROWS);
+  const int64_t blocks = cdiv(chunks, 4) < 8192 ? cdiv(chunks, 4) : 8192;
+  hipLaunchKernelGGL(adam_untouched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tables, m, v, rows,
+                     E / 4, touched, make_opt(opt));
   CTR_LAUNCH_CHECK();
   return CTR_OK;
 }
