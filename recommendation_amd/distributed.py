@@ -350,7 +350,13 @@ class ShardedFront(_SortBesideExchange):
         self._sort_beside(sort, exchange, ws)
         if not self.nf_own:
             return
-        if opt.kind == OPT_ADAM and not lazy:
+        if opt.kind == OPT_ADAM and not lazy and t.grad is None:
+            # every row moves (tf.train.AdamOptimizer) without a dense gradient buffer, as in engine.EmbedFront
+            ops.emb_sparse_apply(bf['keys'], bf['src'], n_items, N=self.nf_own, E=E, total_rows=t.total_rows,
+                                 dz=bf['grows'], opt=opt, tables=t.weight, slot0=t.slot0, slot1=t.slot1, ws=ws)
+            ops.adam_untouched_rows(bf['keys'], n_items, total_rows=t.total_rows, E=E, opt=opt, tables=t.weight,
+                                    slot0=t.slot0, slot1=t.slot1, touched=t.touched)
+        elif opt.kind == OPT_ADAM and not lazy:
             t.grad.zero_()
             ops.emb_sparse_apply(bf['keys'], bf['src'], n_items, N=self.nf_own, E=E, total_rows=t.total_rows,
                                  dz=bf['grows'], opt=ops.make_opt(OPT_GRAD_ONLY), slot0=t.grad, ws=ws)
@@ -508,7 +514,12 @@ class RowShardedFront(_SortBesideExchange):
             lambda sws: ops.emb_sort(bf['recv_keys'][:n_recv].view(n_recv, 1), self.shard_offset, N=1, total_rows=total,
                                      rmode=False, keys_out=bf['skeys'], src_out=bf['ssrc'], ws=sws),
             lambda: self.comm.all_to_all(bf['rows'].view(-1)[:n_recv * E], bf['back'].view(-1)[:n_recv * E]), ws)
-        if opt.kind == OPT_ADAM and not lazy:
+        if opt.kind == OPT_ADAM and not lazy and t.grad is None:
+            ops.emb_sparse_apply(bf['skeys'], bf['ssrc'], n_recv, N=1, E=E, total_rows=total, dz=bf['rows'][:n_recv],
+                                 opt=opt, tables=t.weight, slot0=t.slot0, slot1=t.slot1, ws=ws)
+            ops.adam_untouched_rows(bf['skeys'], n_recv, total_rows=total, E=E, opt=opt, tables=t.weight,
+                                    slot0=t.slot0, slot1=t.slot1, touched=t.touched)
+        elif opt.kind == OPT_ADAM and not lazy:
             t.grad.zero_()
             ops.emb_sparse_apply(bf['skeys'], bf['ssrc'], n_recv, N=1, E=E, total_rows=total, dz=bf['rows'][:n_recv],
                                  opt=ops.make_opt(OPT_GRAD_ONLY), slot0=t.grad, ws=ws)

@@ -333,7 +333,7 @@ class CTRModel(GraphOwner):
             self.front = EmbedFront(self.tables, self.mode, self.cont_num, self.CONT_EMBED)
             self._own_fields = list(range(self.cate_num))
         self.tables.init_slots(self.OPTIMIZER, dense_adam=(self.adam_mode == 'tf1'),
-                               keep_grad=bool(getattr(self.args, 'table_grads', True)) or self.world > 1)
+                               keep_grad=bool(getattr(self.args, 'table_grads', True)))
         self.dense.init_slots(self.OPTIMIZER)
         # the two words the host reads back after a step share one buffer (one copy): the loss and the
         # out-of-range-id counter of the standard lookup

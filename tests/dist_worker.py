@@ -159,6 +159,9 @@ def main(model_name, shard='table', arch='tiny', dense_allreduce='ring'):
     import copy
     dcfg = copy.copy(cfg)
     dcfg.world_size, dcfg.rank, dcfg.comm, dcfg.shard = world, rank, HostStagedComm(), shard
+    if dense_allreduce == 'nobuf':                # tf.train.AdamOptimizer's every-row update without the dense gradient buffer
+        cfg.table_grads = dcfg.table_grads = False
+        dense_allreduce = 'ring'
     dcfg.dense_allreduce = dense_allreduce        # 'direct': reduce-scatter + all-gather from two all-to-alls
     m = cls(dcfg, F, C, cfg.cate_list)
     m.build()

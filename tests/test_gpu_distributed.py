@@ -14,10 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                               ('DCN', 'row', 'tiny'), ('PNN', 'row', 'tiny'),
                                               ('DeepFM', 'table', 'default'), ('DeepFM', 'row', 'default'),
                                               ('DCN', 'table', 'default'), ('DeepFM', 'table', 'tiny direct'),
-                                              ('DCN', 'row', 'default direct')])
+                                              ('DCN', 'row', 'default direct'), ('DeepFM', 'table', 'tiny nobuf'),
+                                              ('DCN', 'row', 'tiny nobuf')])
 def test_two_ranks_match_one_rank(sess, model, shard, arch):
     """'... direct': the towers' gradients summed by distributed.DirectAllReduce (two all-to-alls and a fixed-order sum)
-    instead of the transport's all-reduce."""
+    instead of the transport's all-reduce; '... nobuf': adam_mode 'tf1' as the row-wise pass plus the pass over the rows
+    without a gradient (table_grads=False) on every rank's shard."""
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
            '--master-addr', '127.0.0.1', '--master-port', '29731', os.path.join(ROOT, 'tests', 'dist_worker.py'), model, shard] + arch.split()
