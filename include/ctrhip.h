@@ -272,15 +272,18 @@ int ctr_emb_sparse_apply_fm(const uint32_t* keys_sorted, const uint32_t* src_sor
  * gradient buffer: ctr_emb_sparse_apply (CTR_OPT_ADAM) on the rows that received a gradient, then
  * ctr_adam_untouched_rows on all others.  A byte per table row tells the second part what to do: bit 0 = updated by
  * the first part in this step (skip), bit 1 = the row's m or v may be nonzero.  ctr_mark_rows(value = 1) sets both bits
- * on the rows the sorted keys name before the pass, ctr_mark_rows(value = 0) clears bit 0 on them after it.  A row
+ * on the rows the sorted keys name before the pass; the pass clears bit 0 of every byte it reads, so the map is ready
+ * for the next step (ctr_mark_rows(value = 0) clears bit 0 on the rows the keys name, for callers that mark without
+ * running the pass).  A row
  * whose byte is 0 has no optimizer state: the formulas leave such a row exactly as it is (m = v = 0: no decay, no
  * step), so the pass does not even read it - on tables of tens of millions of rows, most of which never receive a
  * gradient, that is most of the work.  Start from a map of zeros together with zero m and v; a caller that fills m or
  * v by other means (a restored checkpoint) sets the bytes of those rows, or of all rows, to 2.  Values with m = v = +0
- * inside rows with state are skipped as well (same result).  tables, m, v: contiguous [rows, E], E % 4 == 0. */
+ * inside rows with state are skipped as well (same result).  tables, m, v: contiguous [rows, E], E % 4 == 0; the map
+ * 16-byte aligned. */
 int ctr_mark_rows(const uint32_t* keys_sorted, int64_t n_items, int64_t total_rows, uint8_t* touched, int value,
                   void* stream);
-int ctr_adam_untouched_rows(float* tables, float* m, float* v, int64_t rows, int E, const uint8_t* touched,
+int ctr_adam_untouched_rows(float* tables, float* m, float* v, int64_t rows, int E, uint8_t* touched,
                             const ctr_opt_t* opt, void* stream);
 
 /* ------------------------------------------------------------------------------------

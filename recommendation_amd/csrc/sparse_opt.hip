@@ -468,14 +468,14 @@ __global__ __launch_bounds__(256) void mark_rows_kernel(const uint32_t* __restri
 // (the expressions of dense_update_kernel with g = 0, so the same bits); rows marked in `touched` (bit 0) were
 // updated by the row-wise pass and are skipped.  Four floats whose m and v are all +0 stay exactly as they are under
 // these expressions (b1 * 0 = 0, b2 * 0 = 0, w - lr * 0 / (0 + eps) = w), so rows without optimizer state cost
-// nothing but their byte: on tables of tens of millions of rows most rows have never received a gradient.
+// nothing but their byte (bit 0 of every byte is cleared on the way: the map is ready for the next step): on tables of tens of millions of rows most rows have never received a gradient.
 // A wave walks chunks of 1024 rows: a lane reads the bytes of 16 rows at once, the rows to work on (bit 0 clear, bit 1
 // set) are listed in the wave's piece of LDS, and the wave then takes the listed rows' quads 128 at a time: m and v
 // first, w - and anything written - only where some value has state.
 constexpr int AU_ROWS = 1024;        // rows per wave chunk (16 per lane)
 __global__ __launch_bounds__(256) void adam_untouched_kernel(float* __restrict__ w, float* __restrict__ m,
                                                             float* __restrict__ v, int64_t rows, int q_per_row,
-                                                            const uint8_t* __restrict__ touched, Opt o) {
+                                                            uint8_t* __restrict__ touched, Opt o) {
   __shared__ uint32_t lists[4][AU_ROWS];
   o = resolve_opt(o);
   // exact only while 0 / (0 + eps) is 0 and lr * 0 is 0
@@ -492,6 +492,15 @@ __global__ __launch_bounds__(256) void adam_untouched_kernel(float* __restrict__
     } else {
       for (int k = 0; k < 16; ++k)
         if (r0 + k < rows) by[k >> 2] = (by[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | ((uint32_t)touched[r0 + k] << (8 * (k & 3)));
+    }
+    // this lane is the only reader of its 16 bytes: it clears the step's marks (bit 0) on its way
+    if (r0 + 16 <= rows) {
+      if ((by[0] | by[1] | by[2] | by[3]) & 0x01010101u)
+        *reinterpret_cast<uint4*>(touched + r0) = make_uint4(by[0] & ~0x01010101u, by[1] & ~0x01010101u,
+                                                             by[2] & ~0x01010101u, by[3] & ~0x01010101u);
+    } else {
+      for (int k = 0; k < 16; ++k)
+        if (r0 + k < rows && ((by[k >> 2] >> (8 * (k & 3))) & 1u)) touched[r0 + k] = (uint8_t)((by[k >> 2] >> (8 * (k & 3))) & 0xFEu);
     }
     uint32_t mask = 0u;                                  // bit k: row r0 + k is worked on
 #pragma unroll
@@ -780,7 +789,7 @@ extern "C" int ctr_mark_rows(const uint32_t* keys_sorted, int64_t n_items, int64
   return CTR_OK;
 }
 
-extern "C" int ctr_adam_untouched_rows(float* tables, float* m, float* v, int64_t rows, int E, const uint8_t* touched,
+extern "C" int ctr_adam_untouched_rows(float* tables, float* m, float* v, int64_t rows, int E, uint8_t* touched,
                                        const ctr_opt_t* opt, void* stream) {
   CTR_REQUIRE(opt && opt->kind == CTR_OPT_ADAM, "ctr_adam_untouched_rows: the optimizer must be Adam");
   CTR_REQUIRE(rows >= 0 && E >= 4 && E % 4 == 0, "ctr_adam_untouched_rows: bad size (E a multiple of 4)");

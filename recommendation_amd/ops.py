@@ -589,7 +589,6 @@ def adam_untouched_rows(keys, n_items, *, total_rows, E, opt, tables, slot0, slo
     check(lib().ctr_mark_rows(kp, int(n_items), int(total_rows), tp, 1, _stream()), 'ctr_mark_rows')
     check(lib().ctr_adam_untouched_rows(_ptr(tables, torch.float32), _ptr(slot0, torch.float32), _ptr(slot1, torch.float32),
                                         int(total_rows), E, tp, C.byref(opt), _stream()), 'ctr_adam_untouched_rows')
-    check(lib().ctr_mark_rows(kp, int(n_items), int(total_rows), tp, 0, _stream()), 'ctr_mark_rows')
 
 
 # ------------------------------------------------------------------ dense pieces
