@@ -470,18 +470,18 @@ __global__ __launch_bounds__(256) void mark_rows_kernel(const uint32_t* __restri
 // these expressions (b1 * 0 = 0, b2 * 0 = 0, w - lr * 0 / (0 + eps) = w), so rows without optimizer state cost
 // nothing but their byte (bit 0 of every byte is cleared on the way: the map is ready for the next step): on tables of tens of millions of rows most rows have never received a gradient.
 // A wave walks chunks of 1024 rows: a lane reads the bytes of 16 rows at once, the rows to work on (bit 0 clear, bit 1
-// set) are listed in the wave's piece of LDS, and the wave then takes the listed rows' quads 128 at a time: m and v
-// first, w - and anything written - only where some value has state.
+// set) are listed in the wave's piece of LDS, and the wave then takes the listed rows' quads 128 at a time: m, v and w
+// requested together, written only where some value has state.
 constexpr int AU_ROWS = 1024;        // rows per wave chunk (16 per lane)
 __global__ __launch_bounds__(256) void adam_untouched_kernel(float* __restrict__ w, float* __restrict__ m,
                                                             float* __restrict__ v, int64_t rows, int q_per_row,
                                                             uint8_t* __restrict__ touched, Opt o) {
-  __shared__ uint32_t lists[4][AU_ROWS];
+  __shared__ uint16_t lists[4][AU_ROWS];
   o = resolve_opt(o);
   // exact only while 0 / (0 + eps) is 0 and lr * 0 is 0
   const bool may_skip = o.eps > 0.f && o.LR() - o.LR() == 0.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  volatile uint32_t* list = lists[wave];
+  volatile uint16_t* list = lists[wave];
   const int64_t nchunks = (rows + AU_ROWS - 1) / AU_ROWS;
   for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (int64_t)gridDim.x * 4) {
     const int64_t r0 = chunk * AU_ROWS + lane * 16;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void adam_untouched_kernel(float* __restrict__
     uint32_t pos = incl - cnt;
 #pragma unroll
     for (int k = 0; k < 16; ++k)
-      if (mask & (1u << k)) list[pos++] = (uint32_t)(lane * 16 + k);
+      if (mask & (1u << k)) list[pos++] = (uint16_t)(lane * 16 + k);
     __builtin_amdgcn_wave_barrier();
     const uint32_t n = total * (uint32_t)q_per_row;      // quads of the listed rows
     const int64_t rbase = chunk * AU_ROWS;
@@ -539,6 +539,7 @@ __global__ __launch_bounds__(256) void adam_untouched_kernel(float* __restrict__
         j[u] = (rbase + list[li]) * q_per_row + qq;
         mm[u] = reinterpret_cast<const float4*>(m)[j[u]];
         vv[u] = reinterpret_cast<const float4*>(v)[j[u]];
+        p[u] = reinterpret_cast<const float4*>(w)[j[u]];   // listed rows have state as a rule: no second trip for w
         live[u] = ok;
       }
 #pragma unroll
@@ -550,8 +551,6 @@ __global__ __launch_bounds__(256) void adam_untouched_kernel(float* __restrict__
         any_live = any_live || live[u];
       }
       if (!__any(any_live)) continue;                    // listed rows whose state is all zeros (marked, never updated)
-#pragma unroll
-      for (int u = 0; u < U; ++u) p[u] = reinterpret_cast<const float4*>(w)[j[u]];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (!live[u]) continue;
@@ -800,7 +799,7 @@ extern "C" int ctr_adam_untouched_rows(float* tables, float* m, float* v, int64_
   CTR_REQUIRE(((uintptr_t)touched % 16) == 0, "ctr_adam_untouched_rows: the row map must be 16-byte aligned");
   CTR_REQUIRE(rows < ((int64_t)1 << 40) && (int64_t)AU_ROWS * (E / 4) < 0xFFFFFFFFll, "ctr_adam_untouched_rows: size");
   const int64_t chunks = cdiv(rows, AU_ROWS);
-  const int64_t blocks = cdiv(chunks, 4) < 8192 ? cdiv(chunks, 4) : 8192;
+  const int64_t blocks = cdiv(chunks, 4) < 32768 ? cdiv(chunks, 4) : 32768;
   hipLaunchKernelGGL(adam_untouched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tables, m, v, rows,
                      E / 4, touched, make_opt(opt));
   CTR_LAUNCH_CHECK();
