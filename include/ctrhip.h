@@ -688,6 +688,22 @@ int ctr_din_attn_mlp_wgrad(const float* q, const float* k, int B, int T, int H, 
                            const float* dscore, const float* g1, const float* g2,
                            float* dW1, float* db1, float* dW2, float* db2, float* dw3, float* db3,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* The same three calls with the sequence lengths sl [B] (NULL: as above).  The softmax that follows masks the positions
+ * from a sample's length on (DIN/DIN.py:186-190): their scores are never read and their dscore is 0, so every
+ * contribution of such a position to dq, dk and the parameter gradients is an exact zero.  With sl the kernels skip
+ * the 16-row strips that hold no valid position: score_out, d1_out, d2_out, g1_out and g2_out are left unwritten there
+ * (pass the same sl to all three calls), dk keeps its content there; everything else has the same value.  At lengths
+ * uniform in [1, T] this halves the work of the three launches. */
+int ctr_din_attn_mlp_fwd_sl(const float* q, const float* k, const int32_t* sl, int B, int T, int H, const float* W1,
+                            const float* b1, const float* W2, const float* b2, const float* w3, const float* b3,
+                            float* d1_out, float* d2_out, float* score_out, void* stream);
+int ctr_din_attn_mlp_bwd_sl(const float* q, const float* k, const int32_t* sl, int B, int T, int H, const float* W1,
+                            const float* W2, const float* w3, const float* d1, const float* d2, const float* dscore,
+                            float* g1_out, float* g2_out, float* dq_out, float* dk, int accumulate_dk, void* stream);
+int ctr_din_attn_mlp_wgrad_sl(const float* q, const float* k, const int32_t* sl, int B, int T, int H, const float* d1,
+                              const float* d2, const float* dscore, const float* g1, const float* g2,
+                              float* dW1, float* db1, float* dW2, float* db2, float* dw3, float* db3,
+                              void* workspace, size_t workspace_bytes, void* stream);
 int ctr_din_attn_pool_fwd(const float* score, const int32_t* sl, const float* K, int B, int T, int H,
                           float* att_out, float* out, void* stream);
 int ctr_din_attn_pool_bwd(const float* dout, const float* att, const int32_t* sl, const float* K,

@@ -153,6 +153,9 @@ SIGNATURES = {
     'ctr_din_attn_mlp_bwd': (i, [vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, vp]),
     'ctr_din_attn_mlp_wgrad_workspace_bytes': (sz, [i, i]),
     'ctr_din_attn_mlp_wgrad': (i, [vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'ctr_din_attn_mlp_fwd_sl': (i, [vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'ctr_din_attn_mlp_bwd_sl': (i, [vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, vp]),
+    'ctr_din_attn_mlp_wgrad_sl': (i, [vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'ctr_din_attn_pool_bwd': (i, [vp, vp, vp, vp, i, i, i, vp, vp, i, vp]),
     'ctr_bn_infer': (i, [vp, i64, i, i, vp, vp, vp, vp, f, vp, i64, vp, i64, vp]),
     'ctr_dice_fwd': (i, [vp, i64, i, i, vp, f, vp, i64, vp]),

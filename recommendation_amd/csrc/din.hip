@@ -192,18 +192,21 @@ __global__ __launch_bounds__(256) void din_attn_pool_fwd_block_kernel(const floa
   const int G = 256 / H;
   const int tg = threadIdx.x / H, h = threadIdx.x - tg * H;
   const float* Kb = K + b * T * H;
+  // masked positions have weight exactly 0 (exp of -2^32 below the maximum) unless every position is masked (length 0:
+  // uniform weights): their rows of K add nothing and are not read
+  const int Tv = len > 0 && len < T ? len : T;
   float acc = 0.f;
-  for (int t0 = tg; t0 < T; t0 += 4 * G) {
+  for (int t0 = tg; t0 < Tv; t0 += 4 * G) {
     float kv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int t = t0 + u * G;
-      kv[u] = t < T ? Kb[(int64_t)t * H + h] : 0.f;
+      kv[u] = t < Tv ? Kb[(int64_t)t * H + h] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int t = t0 + u * G;
-      if (t < T) acc += att_s[t] * kv[u];
+      if (t < Tv) acc += att_s[t] * kv[u];
     }
   }
   red[threadIdx.x] = acc;

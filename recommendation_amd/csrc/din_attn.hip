@@ -72,13 +72,20 @@ __device__ static inline void stage_fwd_weights(float* lds, const float* __restr
   }
 }
 
+// rows of sample b that count: its sequence length clamped to [0, T]; all T without lengths
+__device__ __forceinline__ int seq_rows(const int32_t* __restrict__ sl, int64_t b, int T) {
+  if (!sl) return T;
+  const int n = sl[b];
+  return n < 0 ? 0 : (n > T ? T : n);
+}
+
 template <int HT>
 __global__ __launch_bounds__(256, (HT > 4 ? 1 : 2)) void din_mlp_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, int B,
                                                          int T, const float* __restrict__ W1, const float* __restrict__ b1,
                                                          const float* __restrict__ W2, const float* __restrict__ b2,
                                                          const float* __restrict__ w3, const float* __restrict__ b3,
                                                          float* __restrict__ d1, float* __restrict__ d2,
-                                                         float* __restrict__ score) {
+                                                         float* __restrict__ score, const int32_t* __restrict__ sl) {
   constexpr int H = 16 * HT;
   using L = FwdLds<H>;
   extern __shared__ float lds[];
@@ -87,8 +94,10 @@ __global__ __launch_bounds__(256, (HT > 4 ? 1 : 2)) void din_mlp_fwd_kernel(cons
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l16 = lane & 15, kq = lane >> 4;
   const float bias3 = b3[0];
-  const int strips = (T + 15) / 16;
   for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < B; b += (int64_t)gridDim.x * 4) {
+    // positions from the sample's length on are masked out by the softmax that follows (DIN/DIN.py:186-190): their
+    // scores are never read, so whole strips of them are not computed (a strip that holds one valid row is)
+    const int strips = (seq_rows(sl, b, T) + 15) / 16;
     f32x4 qf[HT];
 #pragma unroll
     for (int j = 0; j < HT; ++j) qf[j] = *reinterpret_cast<const f32x4*>(q + b * H + 16 * j + 4 * kq);
@@ -184,7 +193,8 @@ __global__ __launch_bounds__(256, (HT > 4 ? 1 : 2)) void din_mlp_bwd_kernel(cons
                                                          const float* __restrict__ w3, const float* __restrict__ d1,
                                                          const float* __restrict__ d2, const float* __restrict__ ds,
                                                          float* __restrict__ g1, float* __restrict__ g2,
-                                                         float* __restrict__ dq, float* __restrict__ dk, int acc_k) {
+                                                         float* __restrict__ dq, float* __restrict__ dk, int acc_k,
+                                                         const int32_t* __restrict__ sl) {
   constexpr int H = 16 * HT, XT = 3 * HT, SX = 3 * H + 4;
   extern __shared__ float lds[];
   float* W2t = lds;                         // [48][DS1]
@@ -206,8 +216,10 @@ __global__ __launch_bounds__(256, (HT > 4 ? 1 : 2)) void din_mlp_bwd_kernel(cons
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l16 = lane & 15, kq = lane >> 4;
-  const int strips = (T + 15) / 16;
   for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < B; b += (int64_t)gridDim.x * 4) {
+    // masked positions have dscore = 0, hence zero g1, g2, dq and dk contributions: their strips are skipped (dk keeps
+    // what it holds there, g1 / g2 stay unwritten and are not read by the weight-gradient pass either)
+    const int strips = (seq_rows(sl, b, T) + 15) / 16;
     f32x4 qf[HT], dqa[HT];
 #pragma unroll
     for (int j = 0; j < HT; ++j) {
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(256, 1) void din_mlp_wgrad_kernel(const float* __re
                                                               int B, int T, const float* __restrict__ d1,
                                                               const float* __restrict__ d2, const float* __restrict__ ds,
                                                               const float* __restrict__ g1, const float* __restrict__ g2,
-                                                              float* __restrict__ part) {
+                                                              float* __restrict__ part, const int32_t* __restrict__ sl) {
   using WL = WgradLayout<HT, XS>;
   constexpr int HTS = WL::HTS, XT = WL::XT, HS = 16 * HTS;
   using SL = WgradLds<HTS>;
@@ -442,16 +454,25 @@ __global__ __launch_bounds__(256, 1) void din_mlp_wgrad_kernel(const float* __re
     }
     if (lane < 16) my[SL::DS + lane] = r.ds;
   };
-  const int strips = (T + 15) / 16;
-  const int64_t mine = gw < B ? (B - gw + nw - 1) / nw : 0;          // samples of this wave
-  const int64_t items = mine * strips;
+  // the wave's samples gw, gw + nw, ... and of each the strips that hold a valid row (masked positions carry zero
+  // gradients: g1, g2 and dscore of their strips are neither written nor read)
+  auto advance = [&](int64_t& b, int& s) {                   // the strip after (b, s); b >= B when there is none
+    ++s;
+    while (b < B && 16 * s >= seq_rows(sl, b, T)) {
+      b += nw;
+      s = 0;
+    }
+  };
+  int64_t b = gw, bn;
+  int s = -1, sn;
+  advance(b, s);
   Regs regs;
-  if (items > 0) load_strip(gw, 0, regs);
+  if (b < B) load_strip(b, s, regs);
   float qv[HTS];
-  for (int64_t it = 0; it < items; ++it) {
-    const int64_t b = gw + (it / strips) * nw;
-    const int s = (int)(it % strips);
-    if (s == 0) {
+  int64_t bq = -1;
+  for (; b < B; b = bn, s = sn) {
+    if (b != bq) {
+      bq = b;
 #pragma unroll
       for (int j = 0; j < HTS; ++j) qv[j] = q[b * H + c0 + 16 * j + l16];
     }
@@ -460,7 +481,10 @@ __global__ __launch_bounds__(256, 1) void din_mlp_wgrad_kernel(const float* __re
     store_strip(regs);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (it + 1 < items) load_strip(gw + ((it + 1) / strips) * nw, (int)((it + 1) % strips), regs);
+    bn = b;
+    sn = s;
+    advance(bn, sn);
+    if (bn < B) load_strip(bn, sn, regs);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int row = 4 * kq + u;                              // a product step takes rows u, 4+u, 8+u, 12+u
@@ -629,9 +653,10 @@ static int din_grid(int B, int per_cu) {
 // 32, 81 KB at 64 and 146 KB at 128 (a block re-stages it, so no more blocks than stay resident)
 static int din_blocks_per_cu(int H) { return H <= 32 ? 3 : 1; }
 
-extern "C" int ctr_din_attn_mlp_fwd(const float* q, const float* k, int B, int T, int H, const float* W1,
-                                    const float* b1, const float* W2, const float* b2, const float* w3,
-                                    const float* b3, float* d1_out, float* d2_out, float* score_out, void* stream) {
+extern "C" int ctr_din_attn_mlp_fwd_sl(const float* q, const float* k, const int32_t* sl, int B, int T, int H,
+                                       const float* W1, const float* b1, const float* W2, const float* b2,
+                                       const float* w3, const float* b3, float* d1_out, float* d2_out,
+                                       float* score_out, void* stream) {
   CTR_REQUIRE(B >= 0 && T > 0 && din_h_ok(H), "ctr_din_attn_mlp_fwd: H=%d must be 16, 32, 64 or 128 (T > 0)", H);
   CTR_REQUIRE(q && k && W1 && b1 && W2 && b2 && w3 && b3 && score_out, "ctr_din_attn_mlp_fwd: null pointer");
   CTR_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)d1_out % 16) == 0 &&
@@ -646,7 +671,7 @@ extern "C" int ctr_din_attn_mlp_fwd(const float* q, const float* k, int B, int T
       CTR_HIP(hipFuncSetAttribute((const void*)din_mlp_fwd_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)shm));                                                                    \
     hipLaunchKernelGGL(din_mlp_fwd_kernel<HT>, dim3(din_grid(B, din_blocks_per_cu(H))), dim3(256), shm, st, q, k, B, T, W1, b1, W2, \
-                       b2, w3, b3, d1_out, d2_out, score_out);                                                   \
+                       b2, w3, b3, d1_out, d2_out, score_out, sl);                                               \
   } while (0)
   if (H == 16) LAUNCH(1);
   else if (H == 32) LAUNCH(2);
@@ -657,10 +682,16 @@ extern "C" int ctr_din_attn_mlp_fwd(const float* q, const float* k, int B, int T
   return CTR_OK;
 }
 
-extern "C" int ctr_din_attn_mlp_bwd(const float* q, const float* k, int B, int T, int H, const float* W1,
-                                    const float* W2, const float* w3, const float* d1, const float* d2,
-                                    const float* dscore, float* g1_out, float* g2_out, float* dq_out, float* dk,
-                                    int accumulate_dk, void* stream) {
+extern "C" int ctr_din_attn_mlp_fwd(const float* q, const float* k, int B, int T, int H, const float* W1,
+                                    const float* b1, const float* W2, const float* b2, const float* w3,
+                                    const float* b3, float* d1_out, float* d2_out, float* score_out, void* stream) {
+  return ctr_din_attn_mlp_fwd_sl(q, k, nullptr, B, T, H, W1, b1, W2, b2, w3, b3, d1_out, d2_out, score_out, stream);
+}
+
+extern "C" int ctr_din_attn_mlp_bwd_sl(const float* q, const float* k, const int32_t* sl, int B, int T, int H,
+                                       const float* W1, const float* W2, const float* w3, const float* d1,
+                                       const float* d2, const float* dscore, float* g1_out, float* g2_out,
+                                       float* dq_out, float* dk, int accumulate_dk, void* stream) {
   CTR_REQUIRE(B >= 0 && T > 0 && din_h_ok(H), "ctr_din_attn_mlp_bwd: H=%d must be 16, 32, 64 or 128 (T > 0)", H);
   CTR_REQUIRE(q && k && W1 && W2 && w3 && d1 && d2 && dscore && g1_out && g2_out && dq_out && dk,
               "ctr_din_attn_mlp_bwd: null pointer");
@@ -677,7 +708,7 @@ extern "C" int ctr_din_attn_mlp_bwd(const float* q, const float* k, int B, int T
       CTR_HIP(hipFuncSetAttribute((const void*)din_mlp_bwd_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)shm));                                                                    \
     hipLaunchKernelGGL(din_mlp_bwd_kernel<HT>, dim3(din_grid(B, din_blocks_per_cu(H))), dim3(256), shm, st, q, k, B, T, W1, W2, w3, \
-                       d1, d2, dscore, g1_out, g2_out, dq_out, dk, accumulate_dk);                               \
+                       d1, d2, dscore, g1_out, g2_out, dq_out, dk, accumulate_dk, sl);                           \
   } while (0)
   if (H == 16) LAUNCH(1);
   else if (H == 32) LAUNCH(2);
@@ -686,6 +717,14 @@ extern "C" int ctr_din_attn_mlp_bwd(const float* q, const float* k, int B, int T
 #undef LAUNCH
   CTR_LAUNCH_CHECK();
   return CTR_OK;
+}
+
+extern "C" int ctr_din_attn_mlp_bwd(const float* q, const float* k, int B, int T, int H, const float* W1,
+                                    const float* W2, const float* w3, const float* d1, const float* d2,
+                                    const float* dscore, float* g1_out, float* g2_out, float* dq_out, float* dk,
+                                    int accumulate_dk, void* stream) {
+  return ctr_din_attn_mlp_bwd_sl(q, k, nullptr, B, T, H, W1, W2, w3, d1, d2, dscore, g1_out, g2_out, dq_out, dk,
+                                 accumulate_dk, stream);
 }
 
 static int wgrad_parts(int B) { return din_grid(B, 1) * 4; }
@@ -700,10 +739,10 @@ extern "C" size_t ctr_din_attn_mlp_wgrad_workspace_bytes(int B, int H) {
   return (size_t)wgrad_slices(H) * (wgrad_parts(B) + 1) * wgrad_part_floats(H) * sizeof(float);
 }
 
-extern "C" int ctr_din_attn_mlp_wgrad(const float* q, const float* k, int B, int T, int H, const float* d1,
-                                      const float* d2, const float* dscore, const float* g1, const float* g2,
-                                      float* dW1, float* db1, float* dW2, float* db2, float* dw3, float* db3,
-                                      void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int ctr_din_attn_mlp_wgrad_sl(const float* q, const float* k, const int32_t* sl, int B, int T, int H,
+                                         const float* d1, const float* d2, const float* dscore, const float* g1,
+                                         const float* g2, float* dW1, float* db1, float* dW2, float* db2, float* dw3,
+                                         float* db3, void* workspace, size_t workspace_bytes, void* stream) {
   CTR_REQUIRE(B > 0 && T > 0 && din_h_ok(H), "ctr_din_attn_mlp_wgrad: H=%d must be 16, 32, 64 or 128 (B, T > 0)", H);
   CTR_REQUIRE(q && k && d1 && d2 && dscore && g1 && g2 && dW1 && db1 && dW2 && db2 && dw3 && db3 && workspace,
               "ctr_din_attn_mlp_wgrad: null pointer");
@@ -723,7 +762,7 @@ extern "C" int ctr_din_attn_mlp_wgrad(const float* q, const float* k, int B, int
       CTR_HIP(hipFuncSetAttribute((const void*)din_mlp_wgrad_kernel<HT, XS>,                                        \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                           \
     hipLaunchKernelGGL((din_mlp_wgrad_kernel<HT, XS>), dim3(blocks, XS), dim3(256), shm, st, q, k, B, T, d1, d2,    \
-                       dscore, g1, g2, part);                                                                       \
+                       dscore, g1, g2, part, sl);                                                                   \
     float* tot = part + (size_t)XS * parts * WL::PART;                                                              \
     hipLaunchKernelGGL(din_mlp_wgrad_reduce_kernel, dim3((unsigned)cdiv(WL::PART, 32), XS), dim3(256), 0, st, part, \
                        parts, (int)WL::PART, (int)WL::WX, (int)WL::SB1, tot);                                       \
@@ -738,4 +777,12 @@ extern "C" int ctr_din_attn_mlp_wgrad(const float* q, const float* k, int B, int
 #undef LAUNCH
   CTR_LAUNCH_CHECK();
   return CTR_OK;
+}
+
+extern "C" int ctr_din_attn_mlp_wgrad(const float* q, const float* k, int B, int T, int H, const float* d1,
+                                      const float* d2, const float* dscore, const float* g1, const float* g2,
+                                      float* dW1, float* db1, float* dW2, float* db2, float* dw3, float* db3,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  return ctr_din_attn_mlp_wgrad_sl(q, k, nullptr, B, T, H, d1, d2, dscore, g1, g2, dW1, db1, dW2, db2, dw3, db3,
+                                   workspace, workspace_bytes, stream);
 }

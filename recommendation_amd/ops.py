@@ -1042,9 +1042,19 @@ def din_attn_mlp_supported(H, n1=80, n2=40):
     return bool(lib().ctr_din_attn_mlp_supported(int(H), int(n1), int(n2)))
 
 
+def _sl_ptr(sl, B):
+    if sl is None:
+        return None
+    if sl.dtype != torch.int32 or sl.numel() != B or not sl.is_contiguous():
+        raise ValueError('sl must be a contiguous int32 [B] tensor')
+    return C.c_void_p(sl.data_ptr())
+
+
 @_timed
-def din_attn_mlp_fwd(q, k, W1, b1, W2, b2, w3, b3, score, *, B, T, H, d1=None, d2=None):
-    """score[b,t] of the DIN attention network from q [B,H] and k [B*T,H]; d1 / d2 keep the sigmoid outputs."""
+def din_attn_mlp_fwd(q, k, W1, b1, W2, b2, w3, b3, score, *, B, T, H, d1=None, d2=None, sl=None):
+    """score[b,t] of the DIN attention network from q [B,H] and k [B*T,H]; d1 / d2 keep the sigmoid outputs.
+    sl (sequence lengths, optional, the same for _bwd and _wgrad): strips of 16 positions from a sample's length on are
+    not computed - the masked softmax never reads their scores and their gradients are zeros."""
     if q.numel() != B * H or k.numel() != B * T * H or score.numel() != B * T or tuple(W1.shape) != (4 * H, 80) \
             or tuple(W2.shape) != (80, 40) or w3.numel() != 40 or b1.numel() != 80 or b2.numel() != 40 or b3.numel() != 1:
         raise ValueError('din_attn_mlp_fwd size mismatch')
@@ -1054,13 +1064,13 @@ def din_attn_mlp_fwd(q, k, W1, b1, W2, b2, w3, b3, score, *, B, T, H, d1=None, d
     for t_ in (q, k, W1, W2):
         if not t_.is_contiguous():
             raise ValueError('din_attn_mlp_fwd: contiguous inputs required')
-    check(lib().ctr_din_attn_mlp_fwd(_ptr(q, f32), _ptr(k, f32), B, T, H, _ptr(W1, f32), _ptr(b1, f32), _ptr(W2, f32),
-                                     _ptr(b2, f32), _ptr(w3, f32), _ptr(b3, f32), _ptr(d1, f32), _ptr(d2, f32),
-                                     _ptr(score, f32), _stream()), 'ctr_din_attn_mlp_fwd')
+    check(lib().ctr_din_attn_mlp_fwd_sl(_ptr(q, f32), _ptr(k, f32), _sl_ptr(sl, B), B, T, H, _ptr(W1, f32), _ptr(b1, f32),
+                                        _ptr(W2, f32), _ptr(b2, f32), _ptr(w3, f32), _ptr(b3, f32), _ptr(d1, f32),
+                                        _ptr(d2, f32), _ptr(score, f32), _stream()), 'ctr_din_attn_mlp_fwd')
 
 
 @_timed
-def din_attn_mlp_bwd(q, k, W1, W2, w3, d1, d2, dscore, g1, g2, dq, dk, *, B, T, H, acc_k=False):
+def din_attn_mlp_bwd(q, k, W1, W2, w3, d1, d2, dscore, g1, g2, dq, dk, *, B, T, H, acc_k=False, sl=None):
     if q.numel() != B * H or k.numel() != B * T * H or dscore.numel() != B * T or d1.numel() != B * T * 80 \
             or d2.numel() != B * T * 40 or g1.numel() != B * T * 80 or g2.numel() != B * T * 40 or dq.numel() != B * H \
             or dk.numel() != B * T * H or tuple(W1.shape) != (4 * H, 80) or tuple(W2.shape) != (80, 40) or w3.numel() != 40:
@@ -1068,13 +1078,14 @@ def din_attn_mlp_bwd(q, k, W1, W2, w3, d1, d2, dscore, g1, g2, dq, dk, *, B, T, 
     for t_ in (q, k, W1, W2, d1, d2, g1, g2, dq, dk):
         if not t_.is_contiguous():
             raise ValueError('din_attn_mlp_bwd: contiguous buffers required')
-    check(lib().ctr_din_attn_mlp_bwd(_ptr(q, f32), _ptr(k, f32), B, T, H, _ptr(W1, f32), _ptr(W2, f32), _ptr(w3, f32),
-                                     _ptr(d1, f32), _ptr(d2, f32), _ptr(dscore, f32), _ptr(g1, f32), _ptr(g2, f32),
-                                     _ptr(dq, f32), _ptr(dk, f32), int(acc_k), _stream()), 'ctr_din_attn_mlp_bwd')
+    check(lib().ctr_din_attn_mlp_bwd_sl(_ptr(q, f32), _ptr(k, f32), _sl_ptr(sl, B), B, T, H, _ptr(W1, f32), _ptr(W2, f32),
+                                        _ptr(w3, f32), _ptr(d1, f32), _ptr(d2, f32), _ptr(dscore, f32), _ptr(g1, f32),
+                                        _ptr(g2, f32), _ptr(dq, f32), _ptr(dk, f32), int(acc_k), _stream()),
+          'ctr_din_attn_mlp_bwd')
 
 
 @_timed
-def din_attn_mlp_wgrad(q, k, d1, d2, dscore, g1, g2, dW1, db1, dW2, db2, dw3, db3, *, B, T, H, ws):
+def din_attn_mlp_wgrad(q, k, d1, d2, dscore, g1, g2, dW1, db1, dW2, db2, dw3, db3, *, B, T, H, ws, sl=None):
     if q.numel() != B * H or k.numel() != B * T * H or dscore.numel() != B * T or d1.numel() != B * T * 80 \
             or d2.numel() != B * T * 40 or g1.numel() != B * T * 80 or g2.numel() != B * T * 40 \
             or tuple(dW1.shape) != (4 * H, 80) or tuple(dW2.shape) != (80, 40) or dw3.numel() != 40 or db1.numel() != 80 \
@@ -1084,10 +1095,10 @@ def din_attn_mlp_wgrad(q, k, d1, d2, dscore, g1, g2, dW1, db1, dW2, db2, dw3, db
         if not t_.is_contiguous():
             raise ValueError('din_attn_mlp_wgrad: contiguous buffers required')
     wp, wn = ws.get(lib().ctr_din_attn_mlp_wgrad_workspace_bytes(B, H))
-    check(lib().ctr_din_attn_mlp_wgrad(_ptr(q, f32), _ptr(k, f32), B, T, H, _ptr(d1, f32), _ptr(d2, f32),
-                                       _ptr(dscore, f32), _ptr(g1, f32), _ptr(g2, f32), _ptr(dW1, f32), _ptr(db1, f32),
-                                       _ptr(dW2, f32), _ptr(db2, f32), _ptr(dw3, f32), _ptr(db3, f32), wp, wn,
-                                       _stream()), 'ctr_din_attn_mlp_wgrad')
+    check(lib().ctr_din_attn_mlp_wgrad_sl(_ptr(q, f32), _ptr(k, f32), _sl_ptr(sl, B), B, T, H, _ptr(d1, f32), _ptr(d2, f32),
+                                          _ptr(dscore, f32), _ptr(g1, f32), _ptr(g2, f32), _ptr(dW1, f32),
+                                          _ptr(db1, f32), _ptr(dW2, f32), _ptr(db2, f32), _ptr(dw3, f32), _ptr(db3, f32),
+                                          wp, wn, _stream()), 'ctr_din_attn_mlp_wgrad')
 
 
 @_timed

@@ -208,7 +208,7 @@ class DIN(GraphOwner):
             ops.din_attn_mlp_fwd(i_emb, h_emb, d.p('embedding/f1_att/kernel'), d.p('embedding/f1_att/bias'),
                                  d.p('embedding/f2_att/kernel'), d.p('embedding/f2_att/bias'),
                                  d.p('embedding/f3_att/kernel').reshape(-1), d.p('embedding/f3_att/bias'), b['score'],
-                                 B=B, T=T, H=H, d1=b['d1'], d2=b['d2'])
+                                 B=B, T=T, H=H, d1=b['d1'], d2=b['d2'], sl=sl)
         else:
             ops.din_concat_fwd(i_emb, h_emb, b['din_all'], B=B, T=T, H=H)
             ops.gemm(b['din_all'], d.p('embedding/f1_att/kernel'), b['d1'], bias=d.p('embedding/f1_att/bias'),
@@ -340,12 +340,12 @@ class DIN(GraphOwner):
             W1, W2 = d.p('embedding/f1_att/kernel'), d.p('embedding/f2_att/kernel')
             w3 = d.p('embedding/f3_att/kernel').reshape(-1)
             ops.din_attn_mlp_bwd(i_emb, h_emb, W1, W2, w3, b['d1'], b['d2'], ds, b['g1'], b['g2'], dq, dk, B=B, T=T, H=H,
-                                 acc_k=True)
+                                 acc_k=True, sl=sl)
             ops.din_attn_mlp_wgrad(i_emb, h_emb, b['d1'], b['d2'], ds, b['g1'], b['g2'],
                                    d.g('embedding/f1_att/kernel'), d.g('embedding/f1_att/bias'),
                                    d.g('embedding/f2_att/kernel'), d.g('embedding/f2_att/bias'),
                                    d.g('embedding/f3_att/kernel').reshape(-1), d.g('embedding/f3_att/bias'),
-                                   B=B, T=T, H=H, ws=ws)
+                                   B=B, T=T, H=H, ws=ws, sl=sl)
         else:
             self._attention_mlp_backward_unfused(b, ds, i_emb, h_emb, dq, dk, B, T)
         ops.copy2d(b['ddin'][:, H:], dq, accumulate=True)                                # i_emb also feeds the FCN

@@ -77,6 +77,46 @@ def test_din_attn_mlp_matches_the_literal_graph(sess, B, T, H):
                 assert torch.equal(o[n], out[n]), n               # overwrites, and the same bits again
 
 
+@pytest.mark.parametrize('B,T,H', [(37, 200, 32), (9, 50, 64), (300, 21, 128), (6, 16, 16)])
+def test_din_attn_mlp_with_sequence_lengths_skips_only_exact_zeros(sess, B, T, H):
+    """The _sl forms (strips of 16 positions from a sample's length on are not computed) against the plain calls with
+    the gradient of the masked positions set to zero, as the masked softmax of DIN/DIN.py:186-190 delivers it: scores
+    and kept activations of every valid position, dq, dk and all parameter gradients bit for bit; skipped strips of
+    the outputs untouched; lengths 0, 1, a multiple of 16, T and beyond T among them."""
+    from recommendation_amd import ops
+    c = _case(B, T, H, 7 * B + T + H)
+    rng = np.random.default_rng(B + T)
+    sl_np = rng.integers(0, T + 1, B).astype(np.int32)
+    sl_np[:5] = [0, 1, 16, T, T + 9][:min(5, B)]
+    valid = (np.arange(T)[None, :] < np.minimum(sl_np, T)[:, None]).reshape(-1)
+    c['ds'] = c['ds'] * torch.as_tensor(valid, dtype=torch.float64)
+    f = {n: v.to(torch.float32).to(DEV).contiguous() for n, v in c.items()}
+    sl = torch.as_tensor(sl_np, device=DEV)
+    computed = (np.arange(T)[None, :] // 16 < (np.minimum(sl_np, T)[:, None] + 15) // 16).reshape(-1)   # rows of run strips
+    cm = torch.as_tensor(computed, device=DEV)
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    outs = []
+    for lens in (None, sl):
+        fill = 0.0 if lens is None else 123.0
+        d1, d2, score = z(B * T, 80) + fill, z(B * T, 40) + fill, z(B * T) + fill
+        ops.din_attn_mlp_fwd(f['q'], f['k'], f['W1'], f['b1'], f['W2'], f['b2'], f['w3'], f['b3'], score, B=B, T=T, H=H,
+                             d1=d1, d2=d2, sl=lens)
+        g1, g2, dq = z(B * T, 80) + fill, z(B * T, 40) + fill, z(B, H)
+        dk = f['dk0'].clone()
+        ops.din_attn_mlp_bwd(f['q'], f['k'], f['W1'], f['W2'], f['w3'], d1, d2, f['ds'], g1, g2, dq, dk, B=B, T=T, H=H,
+                             acc_k=True, sl=lens)
+        w = dict(W1=z(4 * H, 80), b1=z(80), W2=z(80, 40), b2=z(40), w3=z(40), b3=z(1))
+        ops.din_attn_mlp_wgrad(f['q'], f['k'], d1, d2, f['ds'], g1, g2, w['W1'], w['b1'], w['W2'], w['b2'], w['w3'],
+                               w['b3'], B=B, T=T, H=H, ws=sess.ws, sl=lens)
+        outs.append(dict(d1=d1, d2=d2, score=score, g1=g1, g2=g2, dq=dq, dk=dk, **{'d' + n: v for n, v in w.items()}))
+    full, part = outs
+    for n in ('d1', 'd2', 'score', 'g1', 'g2'):
+        assert torch.equal(full[n][cm], part[n][cm]), n
+        assert bool((part[n][~cm] == 123.0).all()), n + ' written in a skipped strip'
+    for n in ('dq', 'dk', 'dW1', 'db1', 'dW2', 'db2', 'dw3', 'db3'):
+        assert torch.equal(full[n], part[n]), n
+
+
 def test_din_attn_mlp_rejects_unsupported_shapes(sess):
     from recommendation_amd import ops
     assert all(ops.din_attn_mlp_supported(h) for h in (16, 32, 64, 128))
