@@ -269,13 +269,17 @@ __global__ __launch_bounds__(256) void din_attn_pool_bwd_block_kernel(const floa
   for (int h = threadIdx.x; h < H; h += 256) do_s[h] = dout[b * H + h];
   __syncthreads();
   const float* Kb = K + b * T * H;
+  // masked positions (weight exactly 0 unless the length is 0: uniform weights) add nothing to the dot product and
+  // get dscore = 0: their rows of K are not read
+  const int Tv = len > 0 && len < T ? len : T;
   float dot = 0.f;
   for (int t = threadIdx.x; t < T; t += 256) {
     float da = 0.f;
-    for (int h = 0; h < H; h += 4) {
-      const float4 kv = *reinterpret_cast<const float4*>(Kb + (int64_t)t * H + h);
-      da += (do_s[h] * kv.x + do_s[h + 1] * kv.y) + (do_s[h + 2] * kv.z + do_s[h + 3] * kv.w);
-    }
+    if (t < Tv)
+      for (int h = 0; h < H; h += 4) {
+        const float4 kv = *reinterpret_cast<const float4*>(Kb + (int64_t)t * H + h);
+        da += (do_s[h] * kv.x + do_s[h + 1] * kv.y) + (do_s[h + 2] * kv.z + do_s[h + 3] * kv.w);
+      }
     const float a = att[b * T + t];
     att_s[t] = a;
     dscore[b * T + t] = da;   // staged: datt
