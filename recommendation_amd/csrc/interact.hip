@@ -250,14 +250,17 @@ __global__ __launch_bounds__(256, 2) void pnn_inner16_kernel(const float* __rest
             if (n < N) dr[n * E + l16] = dzo[t][r] + dza[t][r];
           }
       }
-      __syncthreads();   // the tiles of the previous sample are fully read
+      // the tiles are the wave's own: ordering inside the wave is all they need (no block barrier per sample)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the tiles of the previous sample are fully read
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int m = 0; m < PT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) us[(16 * m + 4 * g + r) * ES + l16] = u[m][r];
 #pragma unroll
       for (int s2 = 0; s2 < NS; ++s2) Zs[(4 * s2 + g) * ES + l16] = zf[s2];
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int e0 = 0; e0 < E; e0 += 4) {
         float av[PT], bv[NT];
