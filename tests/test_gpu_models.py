@@ -232,6 +232,32 @@ def test_graph_replayed_training_matches_eager(sess, name, mode):
         assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
 
 
+def test_graph_replay_with_the_field_sort_and_the_every_row_adam(sess):
+    """A batch of 2048 takes the field-by-field pair sort whose passes exchange their digit counts inside one launch,
+    and adam_mode 'tf1' without a gradient buffer adds the marking and the pass over the rows without a gradient:
+    four steps replayed from a captured graph leave the bits of four eager steps (weights, slots, row map)."""
+    outs = []
+    for graphed in (False, True):
+        cfg = _criteo_like_cfg('DeepFM', 'DeepFM')
+        cfg.adam_mode, cfg.table_grads = 'tf1', False
+        P = O.init_params('DeepFM', cfg, seed=4, std=0.05)
+        m = _build(sess, 'DeepFM', cfg, P)
+        losses = []
+        for step in range(4):
+            Xc, Xf, y = tiny_batch(cfg, B=2048, seed=step)
+            idx, xc, yy = m._upload(Xc, Xf, y)
+            fn = m.train_step_graphed if graphed else m.train_step
+            losses.append(float(fn(idx, xc, yy).item()))
+        outs.append((losses, m.get_params(), m.tables.slot0.cpu().numpy(), m.tables.slot1.cpu().numpy(),
+                     m.tables.touched.cpu().numpy()))
+    assert outs[0][0] == outs[1][0]
+    for k in outs[0][1]:
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+    for i in (2, 3, 4):
+        assert np.array_equal(outs[0][i], outs[1][i])
+    assert set(np.unique(outs[0][4])) <= {0, 2}
+
+
 def test_tf1_adam_without_the_dense_gradient_buffer(sess):
     """adam_mode 'tf1' moves every table row each step, as tf.train.AdamOptimizer does (DeepFM/DeepFM.py:32,100).  With
     table_grads=False it does so without the dense gradient buffer - the row-wise pass on the rows with a gradient,
